@@ -1,0 +1,53 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """One fixture file written by tests/golden/make_golden.py (outputs of the real reference)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    @property
+    def fits(self):
+        out = []
+        for i in range(int(self.z["n_fits"])):
+            out.append({k: self.z["fit%03d_%s" % (i, k)] for k in
+                        ("b1_inds", "b2_inds", "intersect_inds", "probs", "probs_new", "labels", "mu", "var")})
+        return out
+
+    def api_inputs(self):
+        """Arguments of gen_pseudo_label_gaussian_process exactly as reference gen_ps.py:79-111 casts them."""
+        z = self.z
+        wall_box = z["wall_box"].astype(np.float32) if z["wall_box"].size else []
+        wall_vol = z["wall_vol"].astype(np.float32) if z["wall_vol"].size else []
+        feats = np.concatenate([z["xyz_raw"], z["rgb"]], axis=-1).astype(np.float32)
+        return dict(coords_float=z["xyz_aligned"], mask_feats=feats, spp=z["spp"],
+                    instance_cls=z["gi_cls"].astype(np.int64), instance_box=z["gi_box"].astype(np.float32),
+                    instance_box_volume=z["gi_vol"].astype(np.float32), wall_box=wall_box,
+                    wall_box_volume=wall_vol, instance_classes=18, dataset_name="scannetv2", ground_h=0.1,
+                    training_iter=50, thresh_spp_occu=0.999)
+
+
+@pytest.fixture(params=GOLDEN_NAMES)
+def golden(request):
+    return Golden(request.param)
