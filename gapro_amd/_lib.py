@@ -1,0 +1,134 @@
+"""ctypes binding of libgapro_hip.so (the C ABI declared in include/gapro_hip.h).
+
+The library is the product: there is no Python/NumPy/torch fallback for the hot path.  If the
+shared object is missing or cannot be loaded this module raises at import of the first symbol.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgapro_hip.so")
+
+GAPRO_OK = 0
+STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "OOM", -3: "HIP", -4: "NOT_FINITE", -5: "CHOLESKY", -6: "SPP_RANGE",
+                -7: "WORKSPACE"}
+
+
+class GaproError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("libgapro_hip: %s (%d) %s" % (STATUS_NAMES.get(code, "?"), code, msg))
+        self.code = code
+
+
+class SceneHeader(C.Structure):
+    _fields_ = [("coord_min", C.c_double * 3), ("coord_max", C.c_double * 3), ("spp_min", C.c_int64),
+                ("spp_max", C.c_int64), ("feat_absmax", C.c_float), ("fixed_shift", C.c_int32),
+                ("n_spps", C.c_int32), ("status", C.c_int32)]
+
+
+class ScheduleCounts(C.Structure):
+    _fields_ = [("n_events", C.c_int32), ("n_fits", C.c_int32), ("n_event_idx", C.c_int64),
+                ("n_fit_idx", C.c_int64), ("n_fit_out", C.c_int64), ("max_m", C.c_int32), ("max_t", C.c_int32)]
+
+
+class FitDesc(C.Structure):
+    _fields_ = [("m1", C.c_int32), ("m2", C.c_int32), ("t", C.c_int32), ("b1", C.c_int32), ("b2", C.c_int32),
+                ("scene", C.c_int32), ("idx_offset", C.c_int64), ("out_offset", C.c_int64),
+                ("ws_offset", C.c_int64)]
+
+
+class FitOptions(C.Structure):
+    _fields_ = [("training_iter", C.c_int32), ("lr", C.c_double), ("jitter", C.c_double),
+                ("min_variance", C.c_double), ("eval_stale_chol", C.c_int32), ("reserved", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol of include/gapro_hip.h
+_P = C.c_void_p
+SIGNATURES = {
+    "gapro_version": (C.c_int, []),
+    "gapro_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gapro_ctx_destroy": (None, [_P]),
+    "gapro_last_error": (C.c_char_p, [_P]),
+    "gapro_partition_prepare_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "gapro_partition_prepare": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P,
+                                          C.POINTER(SceneHeader)]),
+    "gapro_partition_pool": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                       _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gapro_broadcast_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "gapro_schedule_build": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(_P)]),
+    "gapro_schedule_free": (None, [_P]),
+    "gapro_schedule_get_counts": (C.c_int, [_P, C.POINTER(ScheduleCounts)]),
+    "gapro_schedule_export_fits": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int64, C.c_int32, _P, _P]),
+    "gapro_schedule_export_events": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "gapro_schedule_merge": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "gapro_fit_options_default": (None, [C.POINTER(FitOptions)]),
+    "gapro_fit_workspace_doubles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gapro_fit_plan_workspace": (C.c_int64, [_P, C.c_int32, C.c_int32]),
+    "gapro_svgp_fit_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.POINTER(FitOptions), _P,
+                                       C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
+    "gapro_fit_workspace_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P]),
+    "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libgapro_hip.so; raises (never falls back) if it is absent or lacks a symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libgapro_hip.so not built: run gapro_amd/csrc/build.sh (or __graft_entry__.build()); "
+                          "expected at " + LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Context:
+    """One gapro_ctx per (process, device)."""
+
+    _cache = {}
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = _P()
+        rc = self.lib.gapro_ctx_create(int(device), C.byref(h))
+        if rc != GAPRO_OK:
+            raise GaproError(rc, "gapro_ctx_create(device=%d): no usable HIP device" % device)
+        self.handle = h
+        self.device = int(device)
+
+    @classmethod
+    def get(cls, device: int = 0) -> "Context":
+        ctx = cls._cache.get(device)
+        if ctx is None:
+            ctx = cls._cache[device] = cls(device)
+        return ctx
+
+    def check(self, rc: int):
+        if rc != GAPRO_OK:
+            raise GaproError(rc, (self.lib.gapro_last_error(self.handle) or b"").decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.gapro_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def default_fit_options(training_iter: int = 50) -> FitOptions:
+    opt = FitOptions()
+    load().gapro_fit_options_default(C.byref(opt))
+    opt.training_iter = int(training_iter)
+    return opt

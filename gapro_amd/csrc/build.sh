@@ -1,0 +1,8 @@
+#!/usr/bin/env bash
+# Build libgapro_hip.so in-tree for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${here}/../libgapro_hip.so"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -Wno-pass-failed \
+  -o "${out}" "${here}/ctx.hip" "${here}/partition.hip" "${here}/svgp_fit.hip" "${here}/schedule.cpp"
+echo "built ${out}"

@@ -1,0 +1,48 @@
+// Context management of libgapro_hip.so.
+#include "common.h"
+
+extern "C" {
+
+int gapro_version(void) { return GAPRO_VERSION; }
+
+int gapro_ctx_create(int device, gapro_ctx** out) {
+  if (!out) return GAPRO_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return GAPRO_ERR_HIP;
+  gapro_ctx* ctx = new (std::nothrow) gapro_ctx();
+  if (!ctx) return GAPRO_ERR_OOM;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete ctx;
+    return GAPRO_ERR_HIP;
+  }
+  ctx->n_cu = prop.multiProcessorCount;
+  if (hipHostMalloc((void**)&ctx->h_header_pinned, sizeof(gapro_scene_header), hipHostMallocDefault) != hipSuccess) {
+    delete ctx;
+    return GAPRO_ERR_OOM;
+  }
+  *out = ctx;
+  return GAPRO_OK;
+}
+
+void gapro_ctx_destroy(gapro_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->h_header_pinned) (void)hipHostFree(ctx->h_header_pinned);
+  delete ctx;
+}
+
+const char* gapro_last_error(const gapro_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+void gapro_fit_options_default(gapro_fit_options* opt) {
+  if (!opt) return;
+  opt->training_iter = 50;
+  opt->lr = 0.1;
+  opt->jitter = 1e-4;
+  opt->min_variance = 1e-6;
+  opt->eval_stale_chol = 0;
+  opt->reserved = 0;
+}
+
+}  // extern "C"

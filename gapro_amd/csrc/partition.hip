@@ -1,0 +1,412 @@
+// Scene partition kernels: scene statistics, dense superpoint ranks, fused point-in-box
+// membership + superpoint pooling, label broadcast.
+//
+// Replaces reference gapro/gen_ps_utils.py:312-326 (torch.unique, coordinate range) and
+// :347-363 (is_within_bb_torch + three torch_scatter means + threshold) and :478-480.
+// All of it is HBM-bound streaming work: one coalesced pass over the point arrays, box corners in
+// LDS, integer atomics for the per-superpoint tallies (bit-reproducible, order-independent).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxStatBlocks = 1024;
+constexpr int kScanChunk = 2048;  // elements per block in the rank scan (256 threads x 8)
+
+struct StatsPartial {
+  double mn[3], mx[3];
+  long long smin, smax;
+  float fabsmax;
+  int pad;
+};
+
+struct PrepareWorkspace {  // device layout, all offsets 16-byte aligned
+  gapro_scene_header header;
+  StatsPartial partials[kMaxStatBlocks];
+};
+
+__device__ inline double wave_min(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline long long wave_min_ll(long long v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    long long t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ inline long long wave_max_ll(long long v) {
+  for (int o = 32; o > 0; o >>= 1) {
+    long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+__device__ inline float wave_max_f(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- K1: per-block partial statistics ---------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_stats(long long n, int d, const double* __restrict__ coords,
+                                                    const float* __restrict__ feats,
+                                                    const long long* __restrict__ spp,
+                                                    StatsPartial* __restrict__ partials) {
+  const long long tid = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const long long stride = (long long)gridDim.x * kThreads;
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  long long smin = 0x7fffffffffffffffLL, smax = -0x7fffffffffffffffLL - 1;
+  float fa = 0.f;
+  for (long long i = tid; i < n; i += stride) {
+    const double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    mn[0] = fmin(mn[0], x); mx[0] = fmax(mx[0], x);
+    mn[1] = fmin(mn[1], y); mx[1] = fmax(mx[1], y);
+    mn[2] = fmin(mn[2], z); mx[2] = fmax(mx[2], z);
+    const long long s = spp[i];
+    smin = s < smin ? s : smin;
+    smax = s > smax ? s : smax;
+  }
+  const long long nf = n * d;
+  for (long long i = tid; i < nf; i += stride) fa = fmaxf(fa, fabsf(feats[i]));
+
+  __shared__ StatsPartial sh[kThreads / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = 0; k < 3; ++k) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); }
+  smin = wave_min_ll(smin); smax = wave_max_ll(smax); fa = wave_max_f(fa);
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) { sh[w].mn[k] = mn[k]; sh[w].mx[k] = mx[k]; }
+    sh[w].smin = smin; sh[w].smax = smax; sh[w].fabsmax = fa;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    StatsPartial p = sh[0];
+    for (int j = 1; j < kThreads / 64; ++j) {
+      for (int k = 0; k < 3; ++k) { p.mn[k] = fmin(p.mn[k], sh[j].mn[k]); p.mx[k] = fmax(p.mx[k], sh[j].mx[k]); }
+      p.smin = sh[j].smin < p.smin ? sh[j].smin : p.smin;
+      p.smax = sh[j].smax > p.smax ? sh[j].smax : p.smax;
+      p.fabsmax = fmaxf(p.fabsmax, sh[j].fabsmax);
+    }
+    partials[blockIdx.x] = p;
+  }
+}
+
+// ---- K1b: fold partials into the scene header --------------------------------------------------
+__global__ void k_stats_final(long long n, int n_partials, long long range_cap, PrepareWorkspace* ws) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  StatsPartial p = ws->partials[0];
+  for (int j = 1; j < n_partials; ++j) {
+    const StatsPartial& q = ws->partials[j];
+    for (int k = 0; k < 3; ++k) { p.mn[k] = fmin(p.mn[k], q.mn[k]); p.mx[k] = fmax(p.mx[k], q.mx[k]); }
+    p.smin = q.smin < p.smin ? q.smin : p.smin;
+    p.smax = q.smax > p.smax ? q.smax : p.smax;
+    p.fabsmax = fmaxf(p.fabsmax, q.fabsmax);
+  }
+  gapro_scene_header h;
+  for (int k = 0; k < 3; ++k) { h.coord_min[k] = p.mn[k]; h.coord_max[k] = p.mx[k]; }
+  h.spp_min = p.smin; h.spp_max = p.smax; h.feat_absmax = p.fabsmax;
+  // fixed-point exponent: |rint(x 2^k)| * n < 2^61  (same rule as oracle/gen_ps_oracle.py:fixed_point_shift)
+  int k = 0;
+  if (p.fabsmax > 0.f && isfinite(p.fabsmax)) {
+    int e; (void)frexpf(p.fabsmax, &e);
+    const int lg = n > 1 ? 64 - __clzll((unsigned long long)(n - 1)) : 0;
+    k = 61 - e - lg;
+    k = k < -1000 ? -1000 : (k > 1000 ? 1000 : k);
+  }
+  h.fixed_shift = k;
+  h.n_spps = 0;
+  h.status = GAPRO_OK;
+  // 128-bit-safe range check
+  const unsigned long long range = (unsigned long long)p.smax - (unsigned long long)p.smin;
+  if (range >= (unsigned long long)range_cap) h.status = GAPRO_ERR_SPP_RANGE;
+  ws->header = h;
+}
+
+// ---- K2: presence flags -------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_flags(long long n, const long long* __restrict__ spp,
+                                                    const PrepareWorkspace* __restrict__ ws,
+                                                    unsigned* __restrict__ flags) {
+  if (ws->header.status != GAPRO_OK) return;
+  const long long smin = ws->header.spp_min;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) flags[spp[i] - smin] = 1u;
+}
+
+// ---- K3: exclusive scan of the flags -> dense ranks ---------------------------------------------
+__device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* total) {
+  __shared__ unsigned wsum[kThreads / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned inc = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+  for (int j = 0; j < kThreads / 64; ++j) {
+    if (j < w) base += wsum[j];
+    tot += wsum[j];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_scan_blocksum(const PrepareWorkspace* __restrict__ ws,
+                                                            const unsigned* __restrict__ flags,
+                                                            unsigned* __restrict__ bsum) {
+  if (ws->header.status != GAPRO_OK) return;
+  const long long range = ws->header.spp_max - ws->header.spp_min + 1;
+  const long long base = (long long)blockIdx.x * kScanChunk;
+  if (base >= range) return;
+  unsigned s = 0;
+  for (int j = 0; j < kScanChunk / kThreads; ++j) {
+    const long long i = base + (long long)threadIdx.x * (kScanChunk / kThreads) + j;
+    if (i < range) s += flags[i];
+  }
+  unsigned tot;
+  (void)block_exclusive_scan(s, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kThreads) void k_scan_offsets(PrepareWorkspace* __restrict__ ws,
+                                                           unsigned* __restrict__ bsum) {
+  if (ws->header.status != GAPRO_OK) return;
+  const long long range = ws->header.spp_max - ws->header.spp_min + 1;
+  const int nb = (int)((range + kScanChunk - 1) / kScanChunk);
+  unsigned carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += kThreads) {
+    const int i = b0 + threadIdx.x;
+    const unsigned v = i < nb ? bsum[i] : 0u;
+    unsigned tot;
+    const unsigned ex = block_exclusive_scan(v, &tot);
+    if (i < nb) bsum[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) ws->header.n_spps = (int)carry;
+}
+
+__global__ __launch_bounds__(kThreads) void k_scan_final(const PrepareWorkspace* __restrict__ ws,
+                                                         unsigned* __restrict__ flags_to_rank,
+                                                         const unsigned* __restrict__ bsum) {
+  if (ws->header.status != GAPRO_OK) return;
+  const long long range = ws->header.spp_max - ws->header.spp_min + 1;
+  const long long base = (long long)blockIdx.x * kScanChunk;
+  if (base >= range) return;
+  constexpr int per = kScanChunk / kThreads;
+  unsigned v[per];
+  unsigned s = 0;
+  for (int j = 0; j < per; ++j) {
+    const long long i = base + (long long)threadIdx.x * per + j;
+    v[j] = i < range ? flags_to_rank[i] : 0u;
+    s += v[j];
+  }
+  unsigned tot;
+  unsigned ex = block_exclusive_scan(s, &tot) + bsum[blockIdx.x];
+  for (int j = 0; j < per; ++j) {
+    const long long i = base + (long long)threadIdx.x * per + j;
+    if (i < range) flags_to_rank[i] = ex;
+    ex += v[j];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_rank_lookup(long long n, const long long* __restrict__ spp,
+                                                          const PrepareWorkspace* __restrict__ ws,
+                                                          const unsigned* __restrict__ rank,
+                                                          int* __restrict__ spp_inv) {
+  if (ws->header.status != GAPRO_OK) return;
+  const long long smin = ws->header.spp_min;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride)
+    spp_inv[i] = (int)rank[spp[i] - smin];
+}
+
+// ---- K4: fused membership + pooling ------------------------------------------------------------
+// One thread per point.  Box corners (with the +-0.005 margin applied in float64, as
+// gen_ps_utils.py:350 does) sit in LDS; every lane reads the same corner -> LDS broadcast.
+__global__ __launch_bounds__(kThreads) void k_pool(long long n, int d, int nb, int shift,
+                                                   const double* __restrict__ coords,
+                                                   const float* __restrict__ feats,
+                                                   const int* __restrict__ spp_inv,
+                                                   const double* __restrict__ boxes,
+                                                   unsigned long long* __restrict__ feat_sum,
+                                                   int* __restrict__ occ_count, int* __restrict__ point_count) {
+  extern __shared__ double sh_box[];  // [nb][6]: lo xyz, hi xyz
+  for (int j = threadIdx.x; j < nb * 6; j += kThreads) {
+    const int c = j % 6;
+    sh_box[j] = c < 3 ? boxes[j] - 0.005 : boxes[j] + 0.005;
+  }
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    const int r = spp_inv[i];
+    atomicAdd(&point_count[r], 1);
+    const float* f = feats + i * d;
+    for (int k = 0; k < d; ++k) {
+      const long long q = __double2ll_rn(ldexp((double)f[k], shift));
+      atomicAdd(&feat_sum[(long long)r * d + k], (unsigned long long)q);
+    }
+    int* occ_row = occ_count + (long long)r * nb;
+    for (int b = 0; b < nb; ++b) {
+      const double* bx = sh_box + 6 * b;
+      const bool in = (x >= bx[0]) & (y >= bx[1]) & (z >= bx[2]) & (x <= bx[3]) & (y <= bx[4]) & (z <= bx[5]);
+      if (in) atomicAdd(&occ_row[b], 1);
+    }
+  }
+}
+
+// ---- K5: per-superpoint finalisation -----------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_pool_finalize(int n_spps, int d, int nb, int shift, float thresh,
+                                                            const long long* __restrict__ feat_sum,
+                                                            const int* __restrict__ occ_count,
+                                                            const int* __restrict__ point_count,
+                                                            float* __restrict__ feats_spp,
+                                                            unsigned long long* __restrict__ occ_bits,
+                                                            int* __restrict__ n_bbs) {
+  const int s = blockIdx.x * kThreads + threadIdx.x;
+  if (s >= n_spps) return;
+  const int pc = point_count[s] > 0 ? point_count[s] : 1;  // torch_scatter clamps the count at 1
+  const float pcf = (float)pc;
+  const int words = (nb + 63) / 64;
+  int nbb = 0;
+  for (int w = 0; w < words; ++w) {
+    unsigned long long bits = 0;
+    const int b_end = min(nb, (w + 1) * 64);
+    for (int b = w * 64; b < b_end; ++b) {
+      // scatter-mean of occupancy.float(): one IEEE float32 division of two integers (gen_ps_utils.py:359-362)
+      const float mean = (float)occ_count[(long long)s * nb + b] / pcf;
+      if (mean >= thresh) bits |= 1ull << (b - w * 64);
+    }
+    occ_bits[(long long)s * words + w] = bits;
+    nbb += __popcll(bits);
+  }
+  n_bbs[s] = nbb;
+  const double pcd = (double)pc;
+  for (int k = 0; k < d; ++k)
+    feats_spp[(long long)s * d + k] = (float)(ldexp((double)feat_sum[(long long)s * d + k], -shift) / pcd);
+}
+
+// ---- K6: superpoint -> point broadcast ----------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_broadcast(long long n, const int* __restrict__ spp_inv,
+                                                        const int* __restrict__ sem_spp,
+                                                        const int* __restrict__ inst_spp,
+                                                        const float* __restrict__ prob_spp,
+                                                        int* __restrict__ sem, int* __restrict__ inst,
+                                                        float* __restrict__ prob) {
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const int r = spp_inv[i];
+    sem[i] = sem_spp[r];
+    inst[i] = inst_spp[r];
+    prob[i] = prob_spp[r];
+  }
+}
+
+inline int grid_for(long long n, int cap = 2048) {
+  long long g = (n + kThreads - 1) / kThreads;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+size_t gapro_partition_prepare_workspace_bytes(int64_t n_points, int64_t spp_range_cap) {
+  (void)n_points;
+  if (spp_range_cap < 1) spp_range_cap = 1;
+  size_t bytes = align_up(sizeof(PrepareWorkspace), 256);
+  bytes += align_up((size_t)spp_range_cap * sizeof(unsigned), 256);
+  bytes += align_up(((size_t)spp_range_cap / kScanChunk + 2) * sizeof(unsigned), 256);
+  return bytes;
+}
+
+int gapro_partition_prepare(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_t feat_dim,
+                            const double* d_coords, const float* d_feats, const int64_t* d_spp,
+                            int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
+                            int32_t* d_spp_inv, gapro_scene_header* h_header) {
+  if (!ctx) return GAPRO_ERR_BAD_ARG;
+  if (n_points <= 0 || feat_dim <= 0 || !d_coords || !d_feats || !d_spp || !d_workspace || !d_spp_inv || !h_header ||
+      spp_range_cap < 1)
+    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_prepare: bad argument");
+  if (workspace_bytes < gapro_partition_prepare_workspace_bytes(n_points, spp_range_cap))
+    return gapro_fail(ctx, GAPRO_ERR_WORKSPACE, "gapro_partition_prepare: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  char* base = (char*)d_workspace;
+  PrepareWorkspace* ws = (PrepareWorkspace*)base;
+  unsigned* flags = (unsigned*)(base + align_up(sizeof(PrepareWorkspace), 256));
+  unsigned* bsum = (unsigned*)((char*)flags + align_up((size_t)spp_range_cap * sizeof(unsigned), 256));
+
+  const int g_stats = grid_for(n_points, kMaxStatBlocks);
+  hipLaunchKernelGGL(k_stats, dim3(g_stats), dim3(kThreads), 0, stream, (long long)n_points, (int)feat_dim, d_coords,
+                     d_feats, (const long long*)d_spp, ws->partials);
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, stream, (long long)n_points, g_stats,
+                     (long long)spp_range_cap, ws);
+  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)spp_range_cap * sizeof(unsigned), stream));
+  const int g_pts = grid_for(n_points);
+  hipLaunchKernelGGL(k_flags, dim3(g_pts), dim3(kThreads), 0, stream, (long long)n_points, (const long long*)d_spp, ws,
+                     flags);
+  const int g_scan = (int)((spp_range_cap + kScanChunk - 1) / kScanChunk);
+  hipLaunchKernelGGL(k_scan_blocksum, dim3(g_scan), dim3(kThreads), 0, stream, ws, flags, bsum);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(kThreads), 0, stream, ws, bsum);
+  hipLaunchKernelGGL(k_scan_final, dim3(g_scan), dim3(kThreads), 0, stream, ws, flags, bsum);
+  hipLaunchKernelGGL(k_rank_lookup, dim3(g_pts), dim3(kThreads), 0, stream, (long long)n_points,
+                     (const long long*)d_spp, ws, flags, d_spp_inv);
+  GAPRO_LAUNCH_CHECK(ctx);
+  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_header_pinned, &ws->header, sizeof(gapro_scene_header),
+                                      hipMemcpyDeviceToHost, stream));
+  GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));
+  *h_header = *ctx->h_header_pinned;
+  if (h_header->status != GAPRO_OK)
+    return gapro_fail(ctx, h_header->status,
+                      "gapro_partition_prepare: superpoint id range [%lld, %lld] exceeds capacity %lld",
+                      (long long)h_header->spp_min, (long long)h_header->spp_max, (long long)spp_range_cap);
+  return GAPRO_OK;
+}
+
+int gapro_partition_pool(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_t feat_dim, int32_t n_boxes,
+                         int32_t n_spps, int32_t fixed_shift, float thresh_spp_occu, const double* d_coords,
+                         const float* d_feats, const int32_t* d_spp_inv, const double* d_boxes,
+                         int64_t* d_feat_sum, int32_t* d_occ_count, int32_t* d_point_count, float* d_feats_spp,
+                         uint64_t* d_occ_bits, int32_t* d_n_bbs) {
+  if (!ctx) return GAPRO_ERR_BAD_ARG;
+  if (n_points <= 0 || feat_dim <= 0 || n_boxes <= 0 || n_spps <= 0 || !d_coords || !d_feats || !d_spp_inv ||
+      !d_boxes || !d_feat_sum || !d_occ_count || !d_point_count || !d_feats_spp || !d_occ_bits || !d_n_bbs)
+    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_pool: bad argument");
+  const size_t lds = (size_t)n_boxes * 6 * sizeof(double);
+  if (lds > 64 * 1024) return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_pool: too many boxes (%d)", n_boxes);
+  hipStream_t stream = (hipStream_t)stream_;
+  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_feat_sum, 0, (size_t)n_spps * feat_dim * sizeof(int64_t), stream));
+  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_occ_count, 0, (size_t)n_spps * n_boxes * sizeof(int32_t), stream));
+  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_point_count, 0, (size_t)n_spps * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(k_pool, dim3(grid_for(n_points)), dim3(kThreads), lds, stream, (long long)n_points, (int)feat_dim,
+                     (int)n_boxes, (int)fixed_shift, d_coords, d_feats, d_spp_inv, d_boxes,
+                     (unsigned long long*)d_feat_sum, d_occ_count, d_point_count);
+  hipLaunchKernelGGL(k_pool_finalize, dim3((n_spps + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, (int)n_spps,
+                     (int)feat_dim, (int)n_boxes, (int)fixed_shift, thresh_spp_occu, (const long long*)d_feat_sum,
+                     d_occ_count, d_point_count, d_feats_spp, (unsigned long long*)d_occ_bits, d_n_bbs);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+int gapro_broadcast_labels(gapro_ctx* ctx, void* stream_, int64_t n_points, const int32_t* d_spp_inv,
+                           const int32_t* d_sem_spp, const int32_t* d_inst_spp, const float* d_prob_spp,
+                           int32_t* d_sem, int32_t* d_inst, float* d_prob) {
+  if (!ctx) return GAPRO_ERR_BAD_ARG;
+  if (n_points <= 0 || !d_spp_inv || !d_sem_spp || !d_inst_spp || !d_prob_spp || !d_sem || !d_inst || !d_prob)
+    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_broadcast_labels: bad argument");
+  hipLaunchKernelGGL(k_broadcast, dim3(grid_for(n_points)), dim3(kThreads), 0, (hipStream_t)stream_,
+                     (long long)n_points, d_spp_inv, d_sem_spp, d_inst_spp, d_prob_spp, d_sem, d_inst, d_prob);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+"""Host orchestration of the pseudo-label path on one GPU: enumerate -> batch-fit -> ordered merge.
+
+Mirrors what reference gapro/gen_ps_utils.py:293-482 does for one scene, but staged so that any
+number of scenes share each device launch:
+
+  stage A  gapro_partition_prepare   scene stats + dense superpoint ranks        (device)
+  stage B  gapro_partition_pool      membership + pooling in one pass            (device)
+  stage C  gapro_schedule_build      static pair schedule                         (host, C++)
+  stage D  gapro_svgp_fit_batch      every GP fit of every scene in ONE launch    (device)
+  stage E  gapro_schedule_merge      ordered merge, fallback, label tables        (host, C++)
+  stage F  gapro_broadcast_labels    superpoint -> point                          (device)
+
+torch is used only to own device memory and streams; all arithmetic happens in libgapro_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Context, FitDesc, SceneHeader, ScheduleCounts
+
+
+def _ptr(t) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if isinstance(t, torch.Tensor):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def _stream_handle(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _to_np(x, dtype):
+    if isinstance(x, torch.Tensor):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(np.asarray(x), dtype=dtype)
+
+
+@dataclass
+class SceneJob:
+    """Inputs of one gen_pseudo_label_gaussian_process call (reference gen_ps_utils.py:293-307)."""
+    coords: torch.Tensor  # f64[N,3] device
+    feats: torch.Tensor  # f32[N,D] device
+    spp: torch.Tensor  # i64[N] device
+    instance_cls: np.ndarray  # i64[Bi]
+    instance_box: np.ndarray  # f32[Bi,6]
+    instance_box_volume: np.ndarray  # f32[Bi]
+    wall_box: np.ndarray  # f32[Bw,6] (may be empty)
+    wall_box_volume: np.ndarray  # f32[Bw]
+    instance_classes: int = 18
+    ground_h: float = 0.1
+    thresh_spp_occu: float = 0.8
+    # --- filled by the stages ---
+    header: Optional[SceneHeader] = None
+    spp_inv: Optional[torch.Tensor] = None
+    n_spps: int = 0
+    boxes: Optional[np.ndarray] = None
+    boxes_cls: Optional[np.ndarray] = None
+    boxes_volume: Optional[np.ndarray] = None
+    feats_row_base: int = 0
+    dev: dict = field(default_factory=dict)
+    host: dict = field(default_factory=dict)
+    schedule: Optional[C.c_void_p] = None
+    counts: Optional[ScheduleCounts] = None
+    fit_base: int = 0
+    out_base: int = 0
+    outputs: Optional[tuple] = None
+
+    @property
+    def n_points(self):
+        return int(self.coords.shape[0])
+
+    @property
+    def n_boxes(self):
+        return int(self.boxes.shape[0])
+
+
+def make_job(coords_float, mask_feats, spp, instance_cls, instance_box, instance_box_volume, wall_box,
+             wall_box_volume, instance_classes=18, ground_h=0.1, thresh_spp_occu=0.8, device=None) -> SceneJob:
+    device = torch.device(device if device is not None else "cuda:0")
+
+    def dev(x, dtype):
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+        return t.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+
+    coords = dev(coords_float, torch.float64)
+    feats = dev(mask_feats, torch.float32)  # mask_feats.float()  gen_ps_utils.py:315
+    if feats.dim() != 2 or coords.dim() != 2 or coords.shape[1] != 3 or feats.shape[0] != coords.shape[0]:
+        raise ValueError("coords_float must be [N,3] and mask_feats [N,D]")
+    sp = dev(spp, torch.int64).reshape(-1)
+    if sp.shape[0] != coords.shape[0]:
+        raise ValueError("spp must have one id per point")
+    ibox = _to_np(instance_box, np.float32).reshape(-1, 6)
+    has_wall = wall_box is not None and len(wall_box) > 0
+    return SceneJob(coords, feats, sp, _to_np(instance_cls, np.int64).reshape(-1), ibox,
+                    _to_np(instance_box_volume, np.float32).reshape(-1),
+                    _to_np(wall_box, np.float32).reshape(-1, 6) if has_wall else np.zeros((0, 6), np.float32),
+                    _to_np(wall_box_volume, np.float32).reshape(-1) if has_wall else np.zeros((0,), np.float32),
+                    int(instance_classes), float(ground_h), float(thresh_spp_occu))
+
+
+class Pipeline:
+    def __init__(self, device=0, training_iter=50, init_mean_std=0.0, seed=0, eval_stale_chol=False,
+                 spp_range_cap=None):
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        if not torch.cuda.is_available():
+            raise RuntimeError("gapro_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        torch.cuda.set_device(self.device)
+        self.ctx = Context.get(self.device.index)
+        self.lib = self.ctx.lib
+        self.opt = _lib.default_fit_options(training_iter)
+        self.opt.eval_stale_chol = 1 if eval_stale_chol else 0
+        self.init_mean_std = float(init_mean_std)
+        self.seed = int(seed)
+        self.spp_range_cap = spp_range_cap
+        self.last_stats = {}
+
+    # ------------------------------------------------------------------ stage A
+    def _prepare(self, job: SceneJob):
+        n = job.n_points
+        cap = int(self.spp_range_cap) if self.spp_range_cap else max(4 * n, 1 << 20)
+        nbytes = self.lib.gapro_partition_prepare_workspace_bytes(n, cap)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        job.spp_inv = torch.empty(n, dtype=torch.int32, device=self.device)
+        hdr = SceneHeader()
+        self.ctx.check(self.lib.gapro_partition_prepare(
+            self.ctx.handle, _stream_handle(self.device), n, int(job.feats.shape[1]), _ptr(job.coords),
+            _ptr(job.feats), _ptr(job.spp), cap, _ptr(ws), nbytes, _ptr(job.spp_inv), C.byref(hdr)))
+        job.header = hdr
+        job.n_spps = int(hdr.n_spps)
+        # boxes = cat(instance, wall, floor) with torch's dtype promotion (gen_ps_utils.py:317-345)
+        mn = np.array(list(hdr.coord_min), dtype=np.float64)
+        mx = np.array(list(hdr.coord_max), dtype=np.float64)
+        floor = np.array([[mn[0], mn[1], mn[2], mx[0], mx[1], mn[2] + job.ground_h]], dtype=np.float64)
+        floor_vol = np.prod(np.maximum(floor[:, 3:] - floor[:, :3], 0.001), axis=1)
+        nw = len(job.wall_box)
+        job.boxes = np.ascontiguousarray(np.concatenate(
+            [job.instance_box.astype(np.float64), job.wall_box.astype(np.float64), floor], 0))
+        job.boxes_cls = np.ascontiguousarray(np.concatenate(
+            [job.instance_cls, np.full(nw + 1, job.instance_classes, dtype=np.int64)]))
+        job.boxes_volume = np.ascontiguousarray(np.concatenate(
+            [job.instance_box_volume.astype(np.float64), job.wall_box_volume.astype(np.float64), floor_vol]))
+
+    # ------------------------------------------------------------------ stage B
+    def _pool(self, job: SceneJob, feats_spp_all: torch.Tensor):
+        S, B, D = job.n_spps, job.n_boxes, int(job.feats.shape[1])
+        W = (B + 63) // 64
+        d = job.dev
+        d["boxes"] = torch.from_numpy(job.boxes).to(self.device, non_blocking=True)
+        d["feat_sum"] = torch.empty((S, D), dtype=torch.int64, device=self.device)
+        d["occ_count"] = torch.empty((S, B), dtype=torch.int32, device=self.device)
+        d["point_count"] = torch.empty(S, dtype=torch.int32, device=self.device)
+        d["occ_bits"] = torch.empty((S, W), dtype=torch.int64, device=self.device)
+        d["n_bbs"] = torch.empty(S, dtype=torch.int32, device=self.device)
+        d["feats_spp"] = feats_spp_all[job.feats_row_base:job.feats_row_base + S]
+        self.ctx.check(self.lib.gapro_partition_pool(
+            self.ctx.handle, _stream_handle(self.device), job.n_points, D, B, S, int(job.header.fixed_shift),
+            C.c_float(job.thresh_spp_occu), _ptr(job.coords), _ptr(job.feats), _ptr(job.spp_inv), _ptr(d["boxes"]),
+            _ptr(d["feat_sum"]), _ptr(d["occ_count"]), _ptr(d["point_count"]), _ptr(d["feats_spp"]),
+            _ptr(d["occ_bits"]), _ptr(d["n_bbs"])))
+
+    # ------------------------------------------------------------------ stage C
+    def _schedule(self, job: SceneJob):
+        h = job.host
+        h["occ_bits"] = np.ascontiguousarray(job.dev["occ_bits"].cpu().numpy().view(np.uint64))
+        h["n_bbs"] = np.ascontiguousarray(job.dev["n_bbs"].cpu().numpy())
+        sched = C.c_void_p()
+        rc = self.lib.gapro_schedule_build(job.n_spps, job.n_boxes, _ptr(job.boxes), _ptr(h["occ_bits"]),
+                                           _ptr(h["n_bbs"]), C.byref(sched))
+        if rc != 0:
+            raise _lib.GaproError(rc, "gapro_schedule_build")
+        job.schedule = sched
+        cnt = ScheduleCounts()
+        self.lib.gapro_schedule_get_counts(sched, C.byref(cnt))
+        job.counts = cnt
+
+    # ------------------------------------------------------------------ run
+    def run(self, jobs: Sequence[SceneJob], keep_debug: bool = False):
+        """Process a batch of scenes; fills job.outputs = (sem i32[N], inst i32[N], prob f32[N], mu f32[S],
+        var f32[S]) as device tensors (same lengths as the reference returns)."""
+        lib, ctx, devc = self.lib, self.ctx, self.device
+        for job in jobs:
+            self._prepare(job)
+        D = int(jobs[0].feats.shape[1])
+        base = 0
+        for job in jobs:
+            if int(job.feats.shape[1]) != D:
+                raise ValueError("all scenes of a batch must share the feature dimension")
+            job.feats_row_base = base
+            base += job.n_spps
+        feats_spp_all = torch.empty((base, D), dtype=torch.float32, device=devc)
+        for job in jobs:
+            self._pool(job, feats_spp_all)
+        for job in jobs:  # .cpu() synchronises
+            self._schedule(job)
+
+        # ---- stage D: one launch for every fit of every scene
+        n_fits = sum(j.counts.n_fits for j in jobs)
+        n_idx = sum(j.counts.n_fit_idx for j in jobs)
+        n_out = sum(j.counts.n_fit_out for j in jobs)
+        descs = (FitDesc * max(n_fits, 1))()
+        h_idx = np.zeros(max(n_idx, 1), dtype=np.int32)
+        fo = io = oo = 0
+        for si, job in enumerate(jobs):
+            job.fit_base, job.out_base = fo, oo
+            if job.counts.n_fits:
+                rc = lib.gapro_schedule_export_fits(
+                    job.schedule, job.feats_row_base, io, oo, si,
+                    C.cast(C.byref(descs, fo * C.sizeof(FitDesc)), C.c_void_p), _ptr(h_idx[io:]))
+                if rc != 0:
+                    raise _lib.GaproError(rc, "gapro_schedule_export_fits")
+            fo += job.counts.n_fits
+            io += job.counts.n_fit_idx
+            oo += job.counts.n_fit_out
+        res = None
+        if n_fits:
+            res = self.fit_descs(feats_spp_all, descs, n_fits, h_idx, n_out, keep_debug=keep_debug)
+
+        # ---- stage E + F
+        for job in jobs:
+            S = job.n_spps
+            sem_spp = np.empty(S, np.int32)
+            inst_spp = np.empty(S, np.int32)
+            prob_spp = np.empty(S, np.float32)
+            mu_spp = np.empty(S, np.float32)
+            var_spp = np.empty(S, np.float32)
+            if job.counts.n_fits:
+                a, b = job.out_base, job.out_base + job.counts.n_fit_out
+                pn, lb, mu, var = (res["probs_new"][a:b], res["labels"][a:b], res["mu"][a:b], res["var"][a:b])
+            else:
+                pn = lb = mu = var = None
+            rc = lib.gapro_schedule_merge(job.schedule, _ptr(pn), _ptr(lb), _ptr(mu), _ptr(var),
+                                          _ptr(job.boxes_cls), _ptr(job.boxes_volume), len(job.instance_box),
+                                          job.instance_classes, _ptr(sem_spp), _ptr(inst_spp), _ptr(prob_spp),
+                                          _ptr(mu_spp), _ptr(var_spp))
+            if rc != 0:
+                raise _lib.GaproError(rc, "gapro_schedule_merge")
+            n = job.n_points
+            d_sem_spp = torch.from_numpy(sem_spp).to(devc, non_blocking=True)
+            d_inst_spp = torch.from_numpy(inst_spp).to(devc, non_blocking=True)
+            d_prob_spp = torch.from_numpy(prob_spp).to(devc, non_blocking=True)
+            sem = torch.empty(n, dtype=torch.int32, device=devc)
+            ins = torch.empty(n, dtype=torch.int32, device=devc)
+            prb = torch.empty(n, dtype=torch.float32, device=devc)
+            ctx.check(lib.gapro_broadcast_labels(ctx.handle, _stream_handle(devc), n, _ptr(job.spp_inv),
+                                                 _ptr(d_sem_spp), _ptr(d_inst_spp), _ptr(d_prob_spp), _ptr(sem),
+                                                 _ptr(ins), _ptr(prb)))
+            job.outputs = (sem, ins, prb, torch.from_numpy(mu_spp).to(devc), torch.from_numpy(var_spp).to(devc))
+            job.host.update(sem_spp=sem_spp, inst_spp=inst_spp, prob_spp=prob_spp)
+            if not keep_debug:
+                lib.gapro_schedule_free(job.schedule)
+                job.schedule = None
+        self.last_stats = dict(n_fits=n_fits, n_fit_out=n_out, fit=res)
+        return [j.outputs for j in jobs]
+
+    # ------------------------------------------------------------------ stage D
+    def fit_descs(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
+                  init_mean: Optional[np.ndarray] = None, keep_debug: bool = False):
+        lib, ctx, devc = self.lib, self.ctx, self.device
+        D = int(feats_spp.shape[1])
+        ws_bytes = int(lib.gapro_fit_plan_workspace(C.cast(descs, C.c_void_p), n_fits, D))
+        if init_mean is None and self.init_mean_std > 0.0:
+            # gpytorch: variational mean <- 0 + mean_init_std * randn on first call
+            rng = np.random.default_rng(self.seed)
+            init_mean = self.init_mean_std * rng.standard_normal(len(h_idx))
+        d_descs = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(devc)
+        d_idx = torch.from_numpy(h_idx).to(devc)
+        d_init = torch.from_numpy(np.ascontiguousarray(init_mean, dtype=np.float64)).to(devc) \
+            if init_mean is not None else None
+        ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=devc)
+        no = max(n_out, 1)
+        probs = torch.empty(no, dtype=torch.float32, device=devc)
+        probs_new = torch.empty(no, dtype=torch.float32, device=devc)
+        labels = torch.empty(no, dtype=torch.uint8, device=devc)
+        mu = torch.empty(no, dtype=torch.float32, device=devc)
+        var = torch.empty(no, dtype=torch.float32, device=devc)
+        status = torch.empty(n_fits, dtype=torch.int32, device=devc)
+        loss = torch.empty(n_fits, dtype=torch.float64, device=devc)
+        ctx.check(lib.gapro_svgp_fit_batch(
+            ctx.handle, _stream_handle(devc), n_fits, D, _ptr(feats_spp), _ptr(d_idx), _ptr(d_descs), _ptr(d_init),
+            C.byref(self.opt), _ptr(ws), ws_bytes, _ptr(probs), _ptr(probs_new), _ptr(labels), _ptr(mu), _ptr(var),
+            _ptr(status), _ptr(loss)))
+        st = status.cpu().numpy()
+        if (st != 0).any():
+            bad = int(np.nonzero(st)[0][0])
+            raise _lib.GaproError(int(st[bad]), "fit %d of %d failed" % (bad, n_fits))
+        res = dict(probs=probs.cpu().numpy(), probs_new=probs_new.cpu().numpy(), labels=labels.cpu().numpy(),
+                   mu=mu.cpu().numpy(), var=var.cpu().numpy(), loss=loss.cpu().numpy(), status=st,
+                   ws_bytes=ws_bytes)
+        if keep_debug:
+            res["workspace"] = ws
+            res["descs"] = descs
+        return res

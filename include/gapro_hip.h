@@ -1,0 +1,206 @@
+/*
+ * gapro_hip.h -- C ABI of libgapro_hip.so: the MI355X (gfx950) implementation of GaPro's
+ * Gaussian-Process pseudo-label generator.
+ *
+ * The reference has no FFI for this path: it is plain Python on torch + gpytorch +
+ * torch_scatter (paths relative to the reference checkout):
+ *   gapro/gen_ps_utils.py:293-482            gen_pseudo_label_gaussian_process
+ *   gapro/gaussian_process_utils.py:382-445  fit_gp_spp
+ * Each entry point below names the reference lines it replaces.  A maintainer binds them
+ * with ctypes (gapro_amd/_lib.py is that binding).
+ *
+ * Conventions
+ *   - every function returns a gapro_status (0 = ok); nothing throws across the ABI;
+ *     gapro_last_error(ctx) gives the message of the last failure on that context;
+ *   - pointers named d_* are DEVICE pointers (hipMalloc'd or torch CUDA tensors), h_* are host
+ *     pointers; the caller allocates every buffer, the library owns only gapro_ctx and
+ *     gapro_schedule handles;
+ *   - `stream` is a hipStream_t passed as void* (0 = null stream); device entry points only
+ *     enqueue work unless documented "blocking";
+ *   - one ctx per (process, device); a ctx is not thread-safe, distinct ctxs are.
+ */
+#ifndef GAPRO_HIP_H
+#define GAPRO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAPRO_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+  GAPRO_OK = 0,
+  GAPRO_ERR_BAD_ARG = -1,
+  GAPRO_ERR_OOM = -2,
+  GAPRO_ERR_HIP = -3,
+  GAPRO_ERR_NOT_FINITE = -4,   /* a fit produced NaN/Inf */
+  GAPRO_ERR_CHOLESKY = -5,     /* K_ZZ + jitter*I not positive definite */
+  GAPRO_ERR_SPP_RANGE = -6,    /* superpoint id range exceeds the rank-table capacity */
+  GAPRO_ERR_WORKSPACE = -7     /* workspace too small */
+} gapro_status;
+
+typedef struct gapro_ctx gapro_ctx;
+typedef struct gapro_schedule gapro_schedule;
+
+int gapro_version(void);
+int gapro_ctx_create(int device, gapro_ctx** out);
+void gapro_ctx_destroy(gapro_ctx* ctx);
+const char* gapro_last_error(const gapro_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene partition (device).  Replaces gen_ps_utils.py:312-326 and :347-363.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Scene statistics, produced on the device by gapro_partition_prepare and copied to the host. */
+typedef struct {
+  double coord_min[3];   /* torch.min(coords_float, dim=0)        gen_ps_utils.py:317 */
+  double coord_max[3];   /* torch.max(coords_float, dim=0)        gen_ps_utils.py:318 */
+  int64_t spp_min;       /* smallest / largest superpoint id                          */
+  int64_t spp_max;
+  float feat_absmax;     /* max |mask_feats| (sets the fixed-point scale of the pooled sums) */
+  int32_t fixed_shift;   /* pooled feature sums are exact int64 sums of rint(x * 2^fixed_shift) */
+  int32_t n_spps;        /* len(torch.unique(spp))                gen_ps_utils.py:312-313 */
+  int32_t status;        /* gapro_status raised on the device (e.g. GAPRO_ERR_SPP_RANGE) */
+} gapro_scene_header;
+
+/* Bytes of device workspace gapro_partition_prepare needs for `spp_range_cap` distinct id slots. */
+size_t gapro_partition_prepare_workspace_bytes(int64_t n_points, int64_t spp_range_cap);
+
+/* BLOCKING.  coords min/max, |feats| max, and the dense rank of every point's superpoint id
+ * (the `return_inverse` output of torch.unique, gen_ps_utils.py:312).
+ *   d_coords f64[N,3], d_feats f32[N,D], d_spp i64[N]  ->  d_spp_inv i32[N], *h_header        */
+int gapro_partition_prepare(gapro_ctx* ctx, void* stream, int64_t n_points, int32_t feat_dim,
+                            const double* d_coords, const float* d_feats, const int64_t* d_spp,
+                            int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
+                            int32_t* d_spp_inv, gapro_scene_header* h_header);
+
+/* Fused point-in-box membership + superpoint pooling (gen_ps_utils.py:349-363) in one pass over
+ * the points.  Box corners are the float64 `boxes` of gen_ps_utils.py:329-341 (float32-rounded
+ * instance/wall corners held in float64, then the float64 floor box); the +-0.005 margin is
+ * applied inside, in float64.
+ *   in : d_coords f64[N,3], d_feats f32[N,D], d_spp_inv i32[N], d_boxes f64[B,6]
+ *   tmp: d_feat_sum i64[S,D]  (zeroed by the call)
+ *   out: d_occ_count i32[S,B], d_point_count i32[S], d_feats_spp f32[S,D],
+ *        d_occ_bits u64[S, ceil(B/64)]  (bit b of row s = bb_occupancy_spp[s,b]),
+ *        d_n_bbs i32[S]                 (n_bbs_per_spp, gen_ps_utils.py:363)
+ * `thresh_spp_occu` is compared as float32, as torch does.             */
+int gapro_partition_pool(gapro_ctx* ctx, void* stream, int64_t n_points, int32_t feat_dim,
+                         int32_t n_boxes, int32_t n_spps, int32_t fixed_shift, float thresh_spp_occu,
+                         const double* d_coords, const float* d_feats, const int32_t* d_spp_inv,
+                         const double* d_boxes, int64_t* d_feat_sum, int32_t* d_occ_count,
+                         int32_t* d_point_count, float* d_feats_spp, uint64_t* d_occ_bits,
+                         int32_t* d_n_bbs);
+
+/* Superpoint -> point broadcast of the three point-length outputs (gen_ps_utils.py:478-480). */
+int gapro_broadcast_labels(gapro_ctx* ctx, void* stream, int64_t n_points, const int32_t* d_spp_inv,
+                           const int32_t* d_sem_spp, const int32_t* d_inst_spp, const float* d_prob_spp,
+                           int32_t* d_sem, int32_t* d_inst, float* d_prob);
+
+/* ------------------------------------------------------------------------------------------
+ * Static pair schedule and merge (host).  Replaces the control flow of gen_ps_utils.py:365-476.
+ * Which pairs are fitted and on which superpoints depends only on (boxes, bb_occupancy_spp),
+ * never on GP outputs, so the whole schedule is enumerated before any fit runs.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t n_events;       /* containment verdicts + GP fits, in reference order */
+  int32_t n_fits;
+  int64_t n_event_idx;    /* total length of all intersect index lists */
+  int64_t n_fit_idx;      /* total length of all [b1_inds | b2_inds | intersect_inds] lists */
+  int64_t n_fit_out;      /* total number of test superpoints over all fits */
+  int32_t max_m;          /* largest m1+m2 of any fit */
+  int32_t max_t;          /* largest |intersect_inds| of any fit */
+} gapro_schedule_counts;
+
+/* One GP fit of the batch.  Index lists live in one int32 array laid out
+ * [b1_inds (m1) | b2_inds (m2) | intersect_inds (t)] at idx_offset; values are ROWS of the
+ * feats_spp array handed to gapro_svgp_fit_batch (superpoint index + feats_row_base). */
+typedef struct {
+  int32_t m1, m2, t;
+  int32_t b1, b2;        /* the two boxes (informational) */
+  int32_t scene;         /* caller tag (informational) */
+  int64_t idx_offset;    /* into the index array */
+  int64_t out_offset;    /* into the per-test-superpoint outputs */
+  int64_t ws_offset;     /* into the workspace, in doubles (filled by gapro_fit_plan_workspace) */
+} gapro_fit_desc;
+
+/* h_boxes f64[B,6], h_occ_bits u64[S,ceil(B/64)], h_n_bbs i32[S] (outputs of gapro_partition_pool). */
+int gapro_schedule_build(int32_t n_spps, int32_t n_boxes, const double* h_boxes,
+                         const uint64_t* h_occ_bits, const int32_t* h_n_bbs, gapro_schedule** out);
+void gapro_schedule_free(gapro_schedule* s);
+int gapro_schedule_get_counts(const gapro_schedule* s, gapro_schedule_counts* out);
+/* Export the fits: h_descs[n_fits], h_idx i32[n_fit_idx].  `feats_row_base` is added to every
+ * index, `idx_base`/`out_base` to the offsets, `scene` is copied into the descs (for batching
+ * several scenes into one gapro_svgp_fit_batch call). */
+int gapro_schedule_export_fits(const gapro_schedule* s, int32_t feats_row_base, int64_t idx_base,
+                               int64_t out_base, int32_t scene, gapro_fit_desc* h_descs, int32_t* h_idx);
+/* Export the events for inspection/tests: kind (0 contain, 1 fit), b1, b2, winner (contain) or
+ * fit id (fit), offsets[n_events+1] into h_event_idx (superpoint indices of the intersection). */
+int gapro_schedule_export_events(const gapro_schedule* s, uint8_t* h_kind, int32_t* h_b1, int32_t* h_b2,
+                                 int32_t* h_aux, int64_t* h_offsets, int32_t* h_event_idx);
+
+/* Merge + fallback + label tables (gen_ps_utils.py:365-383, :411-423, :438-476).
+ * Fit outputs are this schedule's slices (out_offset relative to 0): probs_new f32, labels u8,
+ * mu f32, var f32, each [n_fit_out].
+ *   in : h_boxes_cls i64[B], h_boxes_volume f64[B], n_fg_instances, instance_classes
+ *   out: h_sem_spp i32[S], h_inst_spp i32[S], h_prob_spp f32[S], h_mu_spp f32[S], h_var_spp f32[S] */
+int gapro_schedule_merge(const gapro_schedule* s, const float* h_probs_new, const uint8_t* h_labels,
+                         const float* h_mu, const float* h_var, const int64_t* h_boxes_cls,
+                         const double* h_boxes_volume, int32_t n_fg_instances, int32_t instance_classes,
+                         int32_t* h_sem_spp, int32_t* h_inst_spp, float* h_prob_spp, float* h_mu_spp,
+                         float* h_var_spp);
+
+/* ------------------------------------------------------------------------------------------
+ * Batched variational-GP fit (device).  Replaces gaussian_process_utils.py:382-445 and the
+ * gpytorch objects it builds (GPClassificationModel :11-25, BernoulliLikelihood, VariationalELBO,
+ * Adam lr 0.1, 50 steps).  One workgroup trains one fit for all `training_iter` steps inside a
+ * single launch; every fit of every scene in the batch runs concurrently.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t training_iter;     /* 50   gaussian_process_utils.py:382,416 */
+  double lr;                 /* 0.1  gaussian_process_utils.py:410 */
+  double jitter;             /* 1e-4 gpytorch variational_cholesky_jitter (float32 default) */
+  double min_variance;       /* 1e-6 gpytorch settings.min_variance */
+  int32_t eval_stale_chol;   /* 0 = refactor K_ZZ with the trained parameters for prediction (default);
+                                1 = reuse the factor of the last training step */
+  int32_t reserved;
+} gapro_fit_options;
+
+void gapro_fit_options_default(gapro_fit_options* opt);
+
+/* Workspace doubles one fit with m = m1+m2 inducing points, t test points, feat_dim d needs. */
+int64_t gapro_fit_workspace_doubles(int32_t m, int32_t t, int32_t feat_dim);
+/* Fill ws_offset of every desc; returns the total workspace size in BYTES. */
+int64_t gapro_fit_plan_workspace(gapro_fit_desc* h_descs, int32_t n_fits, int32_t feat_dim);
+
+/* d_feats_spp f32[rows,D]; d_idx i32; d_descs gapro_fit_desc[n_fits] (device copies);
+ * d_init_mean f64 (optional, may be NULL = zeros): initial variational mean of fit i at
+ *   d_init_mean[idx_offset ... + m] (gpytorch adds 1e-3*randn here; zeros make runs reproducible);
+ * outputs per test superpoint at out_offset: d_probs f32, d_probs_new f32, d_labels u8,
+ *   d_mu f32, d_var f32  (pred_probs, pred_probs_new, pred_labels, pred_mu, pred_variance);
+ * d_fit_status i32[n_fits] (gapro_status per fit), d_fit_loss f64[n_fits] (last ELBO loss). */
+int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t feat_dim,
+                         const float* d_feats_spp, const int32_t* d_idx, const gapro_fit_desc* d_descs,
+                         const double* d_init_mean, const gapro_fit_options* opt, double* d_workspace,
+                         size_t workspace_bytes, float* d_probs, float* d_probs_new, uint8_t* d_labels,
+                         float* d_mu, float* d_var, int32_t* d_fit_status, double* d_fit_loss);
+
+/* ------------------------------------------------------------------------------------------
+ * Debug / test entry points (not needed by a caller of the path).
+ * ---------------------------------------------------------------------------------------- */
+/* Offsets (doubles, relative to a fit's ws_offset) of the fit's workspace regions, so tests can
+ * inspect trained parameters: out8 = {Mp, matrices, vectors, X/Z block, test points, Dinv blocks,
+ * scalars, total}.  Matrices are Mp x Mp row-major in the order LS, LS^T, Adam m/v of LS, G_LS, L,
+ * L^T, L^-1, L^-T, KX, A, A^T, B, B^T, G_A, G_KX, G_KX^T; scalars: c, rho_s, rho_l, ... , loss. */
+int gapro_fit_workspace_layout(int32_t m, int32_t t, int32_t feat_dim, int64_t* out8);
+/* C[16x16] = P^T Q for row-major P, Q with 16 columns and K rows (K % 4 == 0): checks the
+ * v_mfma_f64_16x16x4_f64 lane maps the fit kernel relies on. */
+int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream, const double* d_P, const double* d_Q, double* d_C,
+                        int32_t K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAPRO_HIP_H */

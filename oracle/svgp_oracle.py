@@ -105,7 +105,7 @@ def svgp_fit_predict_autograd(train_x, train_y, test_x, training_iter=50, dtype=
         opt.zero_grad()
         loss.backward()
         opt.step()
-        trace.append(float(loss))
+        trace.append(float(loss.item()))
     with torch.no_grad():
         if eval_chol == "fresh" or L is None:
             L = chol_factor()

@@ -1,0 +1,55 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/gapro_hip.h declares."""
+import ctypes as C
+import os
+import re
+
+from gapro_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gapro_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gapro_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+        assert n in _lib.SIGNATURES, "binding lacks " + n
+    assert lib.gapro_version() == 100
+
+
+def test_struct_layouts_match_the_header():
+    # sizes follow the C declarations (natural alignment)
+    assert C.sizeof(_lib.SceneHeader) == 3 * 8 + 3 * 8 + 8 + 8 + 4 + 4 + 4 + 4
+    assert C.sizeof(_lib.FitDesc) == 6 * 4 + 3 * 8
+    assert C.sizeof(_lib.FitOptions) == 40
+    assert C.sizeof(_lib.ScheduleCounts) == 4 + 4 + 8 + 8 + 8 + 4 + 4
+
+
+def test_fit_options_default_and_workspace_plan():
+    opt = _lib.default_fit_options()
+    assert (opt.training_iter, opt.lr, opt.jitter, opt.min_variance, opt.eval_stale_chol) == (50, 0.1, 1e-4, 1e-6, 0)
+    lib = _lib.load()
+    descs = (_lib.FitDesc * 3)()
+    for i, (m1, m2, t) in enumerate([(3, 4, 5), (40, 60, 20), (100, 120, 300)]):
+        descs[i].m1, descs[i].m2, descs[i].t = m1, m2, t
+    total = lib.gapro_fit_plan_workspace(C.cast(descs, C.c_void_p), 3, 6)
+    sizes = [lib.gapro_fit_workspace_doubles(d.m1 + d.m2, d.t, 6) for d in descs]
+    assert total == 8 * sum(sizes)
+    assert [d.ws_offset for d in descs] == [0, sizes[0], sizes[0] + sizes[1]]
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under gapro_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "gapro_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
