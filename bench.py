@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the pseudo-label hot path (BASELINE.json metric: scenes/sec pseudo-label generation).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scenes-per-step B] [--points P]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path -- gen_pseudo_label_gaussian_process of reference
+gapro/gen_ps_utils.py:293-482, i.e. partition + static schedule + every GP fit + merge + broadcast --
+over one batch of B synthetic ScanNet-shaped scenes whose inputs (coords f64, features f32,
+superpoint ids i64) are already resident in HBM.  Scenes are independent, so with N GPUs every rank
+runs its own batch (weak scaling, no data-path collective; the only collective is the MAX of the
+wall time).  Rank 0 prints ONE JSON line.
+
+`roofline` is for the dominant kernel, the batched SVGP fit: achieved = algorithmic FLOPs of one
+launch (F_fit = I(8.33 M^3 + 12 D M^2) + M^3/3 + 2 M^2 T + 2 D (M^2 + M T), summed over
+the fits of the launch) / the launch's duration measured with HIP events on the launch stream.
+`cpu_baseline` times the CPU oracle (torch float64 autograd restatement of the reference algorithm,
+kind "port") on this box's host cores on one scene of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (public datasheet); the local guide lists no FP64 row
+
+
+def build_scene_inputs(seed, n_points, feat_dim):
+    from gapro_amd.gen_ps_utils import getInstanceInfo
+    from gapro_amd.synth import make_scene
+
+    sc = make_scene(seed=seed, n_points=n_points, n_objects=25, with_walls_json=False)
+    xyz = sc.aligned_xyz()
+    _, cls, box, vol, _ = getInstanceInfo(xyz, sc.inst, sc.sem)
+    if feat_dim == 6:
+        feats = sc.default_feats().astype(np.float32)
+    else:
+        rng = np.random.default_rng(seed + 7)
+        proj = rng.standard_normal((6, feat_dim)) / np.sqrt(6.0)
+        feats = (sc.default_feats() @ proj).astype(np.float32)
+    return dict(coords_float=xyz, mask_feats=feats, spp=sc.spp, instance_cls=cls.astype(np.int64),
+                instance_box=box.astype(np.float32), instance_box_volume=vol.astype(np.float32), wall_box=[],
+                wall_box_volume=[], instance_classes=18, ground_h=0.1, thresh_spp_occu=0.999)
+
+
+def cpu_baseline(scene_kw, budget_s=25.0):
+    """Time the CPU oracle on one scene of the workload (bounded: GP fits are timed until the budget
+    is spent and the rest is extrapolated by algorithmic FLOPs)."""
+    import torch
+
+    from oracle import gen_ps_oracle as O
+    from oracle.svgp_oracle import fit_gp_spp_oracle
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.perf_counter()
+    kw = dict(scene_kw)
+    boxes, cls, vol = O.assemble_boxes(kw["coords_float"], kw["instance_cls"], kw["instance_box"],
+                                       kw["instance_box_volume"], kw["wall_box"], kw["wall_box_volume"])
+    part = O.partition(kw["coords_float"], kw["mask_feats"], kw["spp"], boxes, cls, vol, kw["thresh_spp_occu"])
+    events = O.enumerate_schedule(boxes, part.occ_spp, part.n_bbs_per_spp)
+    t_part = time.perf_counter() - t0
+    fits = [e for e in events if e.kind == "fit"]
+    D = part.feats_spp.shape[1]
+
+    def flops(e):
+        m, t = float(len(e.b1_inds) + len(e.b2_inds)), float(len(e.intersect_inds))
+        return 50 * (8.33 * m**3 + 12 * D * m * m) + m**3 / 3 + 2 * m * m * t + 2 * D * (m * m + m * t)
+
+    total_fl = sum(flops(e) for e in fits)
+    done_fl, t_fit, n_done = 0.0, 0.0, 0
+    for e in sorted(fits, key=flops):  # small to large so that the sample covers many sizes
+        t1 = time.perf_counter()
+        fit_gp_spp_oracle(part.feats_spp, e.b1_inds, e.b2_inds, e.intersect_inds, 50, impl="autograd", dtype="f64")
+        t_fit += time.perf_counter() - t1
+        done_fl += flops(e)
+        n_done += 1
+        if t_fit > budget_s:
+            break
+    est_fit = t_fit * (total_fl / done_fl) if done_fl > 0 else 0.0
+    total = t_part + est_fit
+    return {"value": 1.0 / total if total > 0 else None, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": "1 scene of the workload: partition+schedule timed fully (%.2f s), %d of %d GP fits timed "
+                      "(%.1f s, torch float64 autograd, %d threads), remaining fits extrapolated by FLOPs"
+                      % (t_part, n_done, len(fits), t_fit, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scenes-per-step", type=int, default=16)
+    ap.add_argument("--points", type=int, default=150000)
+    ap.add_argument("--feat-dim", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from gapro_amd.pipeline import Pipeline, make_job
+
+    B = args.scenes_per_step
+    # a few distinct scenes, reused cyclically; every rank gets its own seeds
+    n_distinct = min(B, 4)
+    scene_kws = [build_scene_inputs(1000 * rank + s, args.points, args.feat_dim) for s in range(n_distinct)]
+    resident = []
+    for kw in scene_kws:  # inputs live in HBM before the timed region
+        resident.append(dict(kw, coords_float=torch.from_numpy(kw["coords_float"]).to(dev),
+                             mask_feats=torch.from_numpy(kw["mask_feats"]).to(dev),
+                             spp=torch.from_numpy(kw["spp"]).to(dev)))
+    pipe = Pipeline(device=local_rank, training_iter=50)
+
+    def make_jobs():
+        return [make_job(r["coords_float"], r["mask_feats"], r["spp"], r["instance_cls"], r["instance_box"],
+                         r["instance_box_volume"], r["wall_box"], r["wall_box_volume"], 18, 0.1, 0.999, device=dev)
+                for r in (resident[i % n_distinct] for i in range(B))]
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pipe.run(make_jobs())
+    pipe.profile_fit = True
+    pipe.fit_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run(make_jobs())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fit_ms = [e0.elapsed_time(e1) for e0, e1, _ in pipe.fit_events]
+    fit_fl = [fl for _, _, fl in pipe.fit_events]
+    stats = pipe.last_stats
+    if rank == 0:
+        avg_ms = float(np.mean(fit_ms)) if fit_ms else 0.0
+        achieved = (float(np.mean(fit_fl)) / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0
+        descs = stats.get("fit") or {}
+        out = {
+            "metric": "scenes/sec pseudo-label gen (ScanNetV2-train-shaped synthetic scenes)",
+            "value": B * args.steps * world / elapsed,
+            "unit": "scenes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]-shaped scenes (single ScanNet-like scene: %d points, 25 objects, "
+                                   "D=%d, ~50-pt object / ~400-pt planar superpoints), %d scenes per step per GPU, "
+                                   "50 Adam steps per GP fit" % (args.points, args.feat_dim, B),
+                       "scenes_per_step_per_gpu": B, "points_per_scene": args.points, "feat_dim": args.feat_dim,
+                       "gp_fits_per_step_per_gpu": int(stats.get("n_fits", 0)),
+                       "parallelism": "scene-sharded x%d, no collective" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_svgp_fit (batched SVGP fit, f64 MFMA 16x16x4)",
+                         "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "flops_per_launch": float(np.mean(fit_fl)) if fit_fl else 0.0,
+                         "fits_per_s": (stats.get("n_fits", 0) / (avg_ms * 1e-3)) if avg_ms > 0 else 0.0,
+                         "fit_share_of_step": (sum(fit_ms) / (1e3 * elapsed)) if elapsed > 0 else None},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_kws[0])
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

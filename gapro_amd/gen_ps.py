@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Offline pseudo-label driver: same-flag mirror of reference gapro/gen_ps.py.
+
+    python -m gapro_amd.gen_ps [--save_folder DIR] [--use_deepfeat] [--deepfeat_folder DIR] [--eval_pslabel]
+
+The four reference flags keep their names, defaults and behaviour (gen_ps.py:15-21); scenes come from
+``<data_root>/train/*_inst_nostuff.pth`` in sorted order, finished scenes are skipped (the reference's
+resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tuple of numpy arrays
+(gen_ps.py:126-132) that ISBNet/SPFormer ``torch.load``.  Additive options:
+
+    --data_root DIR        dataset root (default dataset/scannetv2, the reference's relative path)
+    --split train|val      which scene list (reference: train)
+    --devices 0,1,..       one worker process per listed GPU; scenes are dealt round-robin over the
+                           workers (independent scenes, no collective); default: this process, cuda:0
+    --batch_scenes B       scenes whose GP fits share one launch (default 8)
+    --init_mean_std S      std of the random initial variational mean (gpytorch: 1e-3 unseeded;
+                           default 0 = deterministic), --seed seeds it
+    --broadcast_mu_var     write mu/var at point length (what the released data loaders index)
+
+Differences from the reference, on purpose: output files are written atomically (tmp + rename); a scene
+that raises is reported and skipped instead of killing the run; a scene without instances (the
+reference crashes unpacking None, gen_ps_utils.py:229-230 / gen_ps.py:72) is skipped.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import os.path as osp
+import sys
+import time
+from glob import glob
+
+import numpy as np
+import torch
+
+from .gen_ps_utils import getInstanceInfo
+from .pipeline import Pipeline, make_job
+from .scannet_planes import get_wall_boxes, read_axis_align_matrix
+
+
+def load_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
+    """gen_ps.py:37-77: load, build features from UN-aligned xyz, axis-align, boxes, wall boxes."""
+    scan_name = filename.split("/")[-1][:12]
+    xyz, rgb, semantic_label, instance_label = torch.load(filename, weights_only=False)
+    spp = torch.load(osp.join(data_root, "superpoints", scan_name + ".pth"), weights_only=False)
+    spp = spp.numpy() if isinstance(spp, torch.Tensor) else np.asarray(spp)
+    if use_deepfeat:
+        mask_feats = torch.load(osp.join(deepfeat_folder, scan_name + ".pth"), weights_only=False)
+        mask_feats = mask_feats.numpy() if isinstance(mask_feats, torch.Tensor) else np.asarray(mask_feats)
+    else:
+        mask_feats = np.concatenate([xyz, rgb], axis=-1)  # :55 (before the alignment)
+    A = read_axis_align_matrix(osp.join(data_root, "scans_transform", scan_name, scan_name + ".txt"))
+    pts = np.ones((xyz.shape[0], 4))
+    pts[:, 0:3] = xyz[:, 0:3]
+    xyz_al = np.dot(pts, A.transpose())[:, :3]  # :65-69
+    info = getInstanceInfo(xyz_al, instance_label=instance_label, semantic_label=semantic_label)
+    if info is None:
+        return None
+    _, instance_cls, instance_box, instance_box_volume, _ = info
+    wall_cls, wall_box, wall_volume = get_wall_boxes(scan_name, data_root=data_root)
+    return dict(scan_name=scan_name, coords_float=xyz_al, mask_feats=np.asarray(mask_feats, dtype=np.float32),
+                spp=spp.astype(np.int64), instance_cls=np.asarray(instance_cls).astype(np.int64),
+                instance_box=instance_box.astype(np.float32),
+                instance_box_volume=instance_box_volume.astype(np.float32),
+                wall_box=np.asarray(wall_box, dtype=np.float32) if len(wall_box) else [],
+                wall_box_volume=np.asarray(wall_volume, dtype=np.float32) if len(wall_box) else [],
+                semantic_label=semantic_label, instance_label=instance_label)
+
+
+def save_scene(save_path, outs, spp_inv=None, broadcast_mu_var=False):
+    """gen_ps.py:126-132, written atomically."""
+    sem, ins, prob, mu, var = outs
+    if broadcast_mu_var:
+        mu, var = mu[spp_inv.long()], var[spp_inv.long()]
+    tup = (sem.int().cpu().numpy(), ins.int().cpu().numpy(), prob.cpu().numpy(), mu.cpu().numpy(), var.cpu().numpy())
+    tmp = save_path + ".tmp.%d" % os.getpid()
+    torch.save(tup, tmp)
+    os.replace(tmp, save_path)
+
+
+def run_worker(filenames, args, device_index):
+    pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
+    dev = pipe.device
+    done = failed = 0
+    t0 = time.time()
+    pending = [f for f in filenames
+               if not osp.exists(osp.join(args.save_folder, f.split("/")[-1][:12] + ".pth"))]  # :39-41
+    for i in range(0, len(pending), args.batch_scenes):
+        scenes = []
+        for fn in pending[i:i + args.batch_scenes]:
+            try:
+                sc = load_scene(fn, args.data_root, args.use_deepfeat, args.deepfeat_folder)
+                if sc is None:
+                    print("[gen_ps] %s: no instances, skipped" % fn, file=sys.stderr)
+                    failed += 1
+                    continue
+                scenes.append(sc)
+            except Exception as e:  # noqa: BLE001 - one bad scene must not kill the run
+                print("[gen_ps] %s: load failed: %r" % (fn, e), file=sys.stderr)
+                failed += 1
+        if not scenes:
+            continue
+        try:
+            jobs = [make_job(s["coords_float"], s["mask_feats"], s["spp"], s["instance_cls"], s["instance_box"],
+                             s["instance_box_volume"], s["wall_box"], s["wall_box_volume"],
+                             instance_classes=18, ground_h=0.1, thresh_spp_occu=0.999, device=dev)  # :106-110
+                    for s in scenes]
+            outs = pipe.run(jobs)
+        except Exception as e:  # noqa: BLE001
+            print("[gen_ps] batch starting at %s failed: %r" % (scenes[0]["scan_name"], e), file=sys.stderr)
+            failed += len(scenes)
+            continue
+        for s, job, o in zip(scenes, jobs, outs):
+            save_scene(osp.join(args.save_folder, s["scan_name"] + ".pth"), o, job.spp_inv, args.broadcast_mu_var)
+            done += 1
+            if args.eval_pslabel:
+                from .eval_ps_labels import get_miou_scene
+
+                sem_gt = torch.from_numpy(np.asarray(s["semantic_label"])).to(dev).int()
+                ins_gt = torch.from_numpy(np.asarray(s["instance_label"])).to(dev).int()
+                sem_gt[sem_gt != -100] -= 2  # :119-120
+                sem_gt[(sem_gt == -1) | (sem_gt == -2)] = 18
+                ious = get_miou_scene(sem_gt.long(), ins_gt.long(), o[0].long(), o[1].long())
+                print("miou", ious)
+    dt = time.time() - t0
+    print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)"
+          % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0))
+    return done, failed
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser("GaPro_GenPS")
+    parser.add_argument("--save_folder", type=str, default="dataset/scannetv2/gaussian_process_kl_pseudo_labels")
+    parser.add_argument("--use_deepfeat", action="store_true")
+    parser.add_argument("--deepfeat_folder", type=str, default="dataset/scannetv2/pretrain_maskfeats2")
+    parser.add_argument("--eval_pslabel", action="store_true")
+    # additive options
+    parser.add_argument("--data_root", type=str, default="dataset/scannetv2")
+    parser.add_argument("--split", type=str, default="train", choices=["train", "val"])
+    parser.add_argument("--devices", type=str, default="0")
+    parser.add_argument("--batch_scenes", type=int, default=8)
+    parser.add_argument("--init_mean_std", type=float, default=0.0)
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--broadcast_mu_var", action="store_true")
+    parser.add_argument("--worker_rank", type=int, default=-1, help=argparse.SUPPRESS)
+    args = parser.parse_args(argv)
+
+    os.makedirs(args.save_folder, exist_ok=True)
+    filenames = sorted(glob(osp.join(args.data_root, args.split, "*_inst_nostuff.pth")))  # :27-32
+    devices = [int(d) for d in args.devices.split(",") if d != ""]
+    if args.worker_rank >= 0 or len(devices) == 1:
+        r = max(args.worker_rank, 0)
+        mine = filenames[r::len(devices)]  # independent scenes: round-robin shard, no collective
+        run_worker(mine, args, devices[r])
+    else:
+        import subprocess
+
+        procs = []
+        for r in range(len(devices)):
+            cmd = [sys.executable, "-m", "gapro_amd.gen_ps"] + (argv if argv is not None else sys.argv[1:]) + \
+                  ["--worker_rank", str(r)]
+            procs.append(subprocess.Popen(cmd))
+        rc = [p.wait() for p in procs]
+        if any(rc):
+            raise SystemExit("a worker failed: %r" % rc)
+    print("Finish")
+
+
+if __name__ == "__main__":
+    main()

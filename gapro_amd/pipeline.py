@@ -106,6 +106,19 @@ def make_job(coords_float, mask_feats, spp, instance_cls, instance_box, instance
                     int(instance_classes), float(ground_h), float(thresh_spp_occu))
 
 
+def fit_flops(descs, n_fits: int, feat_dim: int, training_iter: int) -> float:
+    """Algorithmic FLOPs of a fit batch, SURVEY.md section 8(d):
+    F_fit = I (8.33 M^3 + 12 D M^2) + (M^3/3 + 2 M^2 T + 2 D (M^2 + M T)),  M = m1 + m2."""
+    total = 0.0
+    d = float(feat_dim)
+    for i in range(n_fits):
+        m = float(descs[i].m1 + descs[i].m2)
+        t = float(descs[i].t)
+        total += training_iter * (8.33 * m**3 + 12.0 * d * m * m) + (m**3 / 3.0 + 2.0 * m * m * t
+                                                                     + 2.0 * d * (m * m + m * t))
+    return total
+
+
 class Pipeline:
     def __init__(self, device=0, training_iter=50, init_mean_std=0.0, seed=0, eval_stale_chol=False,
                  spp_range_cap=None):
@@ -122,6 +135,9 @@ class Pipeline:
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap
         self.last_stats = {}
+        # optional HIP-event timing of the fit launches (bench.py): list of (start_event, end_event, flops)
+        self.profile_fit = False
+        self.fit_events = []
 
     # ------------------------------------------------------------------ stage A
     def _prepare(self, job: SceneJob):
@@ -284,10 +300,16 @@ class Pipeline:
         var = torch.empty(no, dtype=torch.float32, device=devc)
         status = torch.empty(n_fits, dtype=torch.int32, device=devc)
         loss = torch.empty(n_fits, dtype=torch.float64, device=devc)
+        if self.profile_fit:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(devc))
         ctx.check(lib.gapro_svgp_fit_batch(
             ctx.handle, _stream_handle(devc), n_fits, D, _ptr(feats_spp), _ptr(d_idx), _ptr(d_descs), _ptr(d_init),
             C.byref(self.opt), _ptr(ws), ws_bytes, _ptr(probs), _ptr(probs_new), _ptr(labels), _ptr(mu), _ptr(var),
             _ptr(status), _ptr(loss)))
+        if self.profile_fit:
+            ev1.record(torch.cuda.current_stream(devc))
+            self.fit_events.append((ev0, ev1, fit_flops(descs, n_fits, D, int(self.opt.training_iter))))
         st = status.cpu().numpy()
         if (st != 0).any():
             bad = int(np.nonzero(st)[0][0])

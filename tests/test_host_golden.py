@@ -133,3 +133,17 @@ def test_schedule_rejects_bad_arguments():
     sched = C.c_void_p()
     assert lib.gapro_schedule_build(0, 1, None, None, None, C.byref(sched)) == -1
     assert lib.gapro_schedule_get_counts(None, None) == -1
+
+
+def test_get_miou_scene_matches_reference(golden):
+    """gen_ps --eval_pslabel metric (eval_ps_labels.py:100-147) on the reference's own outputs."""
+    import torch
+    from gapro_amd.eval_ps_labels import get_miou_scene
+
+    gt_sem = torch.from_numpy(golden["sem_gt"]).int()
+    gt_ins = torch.from_numpy(golden["inst_gt"]).int()
+    gt_sem[gt_sem != -100] -= 2  # gen_ps.py:119-120
+    gt_sem[(gt_sem == -1) | (gt_sem == -2)] = 18
+    ious = get_miou_scene(gt_sem.long(), gt_ins.long(), torch.from_numpy(golden["out_sem"]).long(),
+                          torch.from_numpy(golden["out_inst"]).long())
+    np.testing.assert_array_equal(ious.numpy(), golden["ref_ious"])
