@@ -443,8 +443,15 @@ __device__ __noinline__ void forward_products(const Fit& f, int ncols) {
   __syncthreads();
 }
 
+#ifdef GAPRO_PROFILE
+constexpr int kProfSlots = 20;
+#endif
 struct Shared {
   Fit f;
+#ifdef GAPRO_PROFILE
+  unsigned long long prof[kProfSlots];
+  unsigned long long t_last;
+#endif
   double red[NW];
   double dblk[16 * 17];
   double dinv[16 * 17];
@@ -478,6 +485,19 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
   double* gmu = f.vec[V_GMU];
   double* gv = f.vec[V_GV];
   double last_loss = 0.0;
+#ifdef GAPRO_PROFILE
+  // diagnostic build only: per-phase wall-clock shares (100 MHz ticks), see tools/bench_fit.py --profile
+  auto stamp = [&](int id) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned long long t = wall_clock64();
+      sh.prof[id] += t - sh.t_last;
+      sh.t_last = t;
+    }
+  };
+#else
+  auto stamp = [&](int) {};
+#endif
 
   auto refresh_hypers = [&]() {
     __syncthreads();
@@ -489,11 +509,15 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
     __syncthreads();
   };
   auto factorize = [&]() {
+    stamp(19);
     build_kzz(f, sh.s, sh.inv_l2, jitter);
     __syncthreads();
+    stamp(0);
     cholesky_blocked(f, sh.dblk, sh.dinv, &sh.status);
+    stamp(1);
     tri_inverse(f);
     __syncthreads();
+    stamp(2);
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
@@ -503,7 +527,9 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
     factorize();
     build_kx(f, f.X, M, s, inv_l2);
     __syncthreads();
+    stamp(3);
     forward_products<TU>(f, M);
+    stamp(4);
     weighted_colsum(A, vm, Mp, f.vec[V_MU], sh.part);  // mu (without c)
     column_variance(f, s, jitter, sh.part);
     // quadrature: E_n, dE/dmu, dE/dvar  (BernoulliLikelihood.expected_log_prob, 20-point Gauss-Hermite)
@@ -552,6 +578,7 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
     for (int i = threadIdx.x; i < M; i += NT) kl_part += vm[i] * vm[i];
     const double kl = 0.5 * (block_sum(kl_part, sh.red) - Nd);
     last_loss = -(e_sum / Nd - kl / Nd);
+    stamp(6);
 
     // ------------------------------- backward ------------------------------
     // G_m = A g_mu + m / N  (through AT, coalesced)
@@ -563,6 +590,7 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
                 NoScale(), [=](int i, int n, double v) {
                   GA[(size_t)i * Mp + n] = 2.0 * gv[n] * v + vm[i] * gmu[n] - 2.0 * A[(size_t)i * Mp + n] * gv[n];
                 });
+    stamp(7);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL' ; n runs over the M train columns
     gemm_tn<TU>(mt, mt, true, AT, BMT, Mp, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                 [=](int k) { return 2.0 * gv[k]; },
@@ -575,33 +603,39 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
                   GLS[(size_t)i * Mp + j] = g;
                 });
     __syncthreads();
+    stamp(8);
     // G_KX = LI^T G_A   (P = LI[k][i], non-zero for k >= i)
     gemm_tn<TU>(mt, mt, false, f.mat[B_LI], GA, Mp, [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                 NoScale(), [=](int i, int n, double v) { GKX[(size_t)i * Mp + n] = v; GKXT[(size_t)n * Mp + i] = v; });
     __syncthreads();
+    stamp(9);
     // G_L = -tril(G_KX A^T)  -> BM buffer (lower tiles; strict upper of diagonal tiles zeroed)
     double* GL = BM;
     gemm_tn<TU>(mt, mt, true, GKXT, AT, Mp, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; }, NoScale(),
                 [=](int i, int j, double v) { GL[(size_t)i * Mp + j] = (j <= i) ? -v : 0.0; });
     __syncthreads();
+    stamp(10);
     // Pm = Phi(tril(L^T G_L)) -> GA buffer   (k >= max(i0, j0) = i0 on lower tiles)
     double* Pm = GA;
     gemm_tn<TU>(mt, mt, true, f.mat[B_L], GL, Mp, [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                 NoScale(),
                 [=](int i, int j, double v) { Pm[(size_t)i * Mp + j] = (j < i) ? v : (j == i ? 0.5 * v : 0.0); });
     __syncthreads();
+    stamp(11);
     // T1 = LI^T Pm, stored transposed -> BMT buffer   (k >= max(i0, j0))
     double* T1T = BMT;
     gemm_tn<TU>(mt, mt, false, f.mat[B_LI], Pm, Mp,
                 [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; }, NoScale(),
                 [=](int i, int j, double v) { T1T[(size_t)j * Mp + i] = v; });
     __syncthreads();
+    stamp(12);
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer   (k >= j0)
     double* G = BM;
     double* GT = GKXT;
     gemm_tn<TU>(mt, mt, false, T1T, f.mat[B_LI], Mp, [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                 NoScale(), [=](int i, int j, double v) { G[(size_t)i * Mp + j] = v; GT[(size_t)j * Mp + i] = v; });
     __syncthreads();
+    stamp(13);
     // kernel weights: Wzz = sym(G) o (s Ezz) -> BM buffer in place, Wzx = G_KX o KX -> GKX in place;
     // scalar sums for d/ds and d/dl
     double gs_part = 0.0, gl_part = 0.0;
@@ -624,6 +658,7 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
     }
     const double g_s = block_sum(gs_part, sh.red) + gv_sum;
     const double g_l = block_sum(gl_part, sh.red) / (ell * ell * ell);
+    stamp(14);
     // G_Z[i][d] = -(1/l^2) ( sum_j 2 Wzz[i][j] (Z_i - Z_j)[d] + sum_n Wzx[i][n] (Z_i - X_n)[d] )
     for (int idx = threadIdx.x; idx < M * D; idx += NT) {
       const int i = idx / D, d = idx - i * D;
@@ -636,6 +671,7 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
       f.gZ[idx] = -inv_l2 * acc;
     }
     __syncthreads();
+    stamp(15);
 
     // ------------------------------- Adam ----------------------------------
     const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
@@ -662,6 +698,7 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
       adam(sh.rho_l, f.scal[S_MRL], f.scal[S_VRL], g_l * sigmoid(sh.rho_l));
     }
     __syncthreads();
+    stamp(16);
   }
 
   // ------------------------------- prediction ------------------------------
@@ -691,6 +728,11 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
     }
     __syncthreads();
   }
+  stamp(17);
+#ifdef GAPRO_PROFILE
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+#endif
   if (threadIdx.x == 0) {
     f.scal[S_C] = sh.c;
     f.scal[S_RS] = sh.rho_s;
@@ -761,6 +803,10 @@ __global__ __launch_bounds__(NT) void k_svgp_fit(int n_fits, int D, const float*
     sh.rho_s = 0.0;
     sh.rho_l = 0.0;
     sh.status = GAPRO_OK;
+#ifdef GAPRO_PROFILE
+    for (int i = 0; i < kProfSlots; ++i) sh.prof[i] = 0;
+    sh.t_last = wall_clock64();
+#endif
   }
   __syncthreads();
   if (Mp >= 128)

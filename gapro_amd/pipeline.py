@@ -238,7 +238,11 @@ class Pipeline:
             oo += job.counts.n_fit_out
         res = None
         if n_fits:
-            res = self.fit_descs(feats_spp_all, descs, n_fits, h_idx, n_out, keep_debug=keep_debug)
+            # longest-processing-time-first: workgroups are dispatched in block order, so launching the
+            # expensive fits (cost ~ M^3) first keeps the tail of the launch short
+            order = sorted(range(n_fits), key=lambda i: -(descs[i].m1 + descs[i].m2))
+            sorted_descs = (FitDesc * n_fits)(*[descs[i] for i in order])
+            res = self.fit_descs(feats_spp_all, sorted_descs, n_fits, h_idx, n_out, keep_debug=keep_debug)
 
         # ---- stage E + F
         for job in jobs:

@@ -281,8 +281,13 @@ def make_scene(
     )
 
 
-def make_gp_problem(seed: int, m1: int, m2: int, t: int, d: int = 6, sep: float = 1.4):
+def make_gp_problem(seed: int, m1: int, m2: int, t: int, d: int = 6, sep: float = 1.4, std: float = 1.0):
     """Config-5 style direct GP problem: two Gaussian blobs in R^d.
+
+    ``std`` scales the whole problem.  With the kernel's initial lengthscale ln 2 = 0.69, blobs of unit
+    std in d = 32 put every pair of points ~8 lengthscales apart (kernel values ~1e-29): the fit is then
+    driven by rounding noise that Adam's normalisation amplifies, and no two float64 implementations
+    agree (DESIGN.md "Precision").  Use std ~0.3 for d = 32 to get a well-conditioned problem.
 
     Returns feats_spp f32[m1+m2+t, d] and the three index vectors that
     ``fit_gp_spp`` takes (reference gaussian_process_utils.py:382).
@@ -294,7 +299,7 @@ def make_gp_problem(seed: int, m1: int, m2: int, t: int, d: int = 6, sep: float 
     b = rng.normal(0, 1, size=(m2, d)) + mu[None, :]
     w = rng.random(t)[:, None]
     c = rng.normal(0, 1, size=(t, d)) + w * mu[None, :]
-    feats = np.concatenate([a, b, c], 0).astype(np.float32)
+    feats = (std * np.concatenate([a, b, c], 0)).astype(np.float32)
     b1 = np.arange(0, m1, dtype=np.int64)
     b2 = np.arange(m1, m1 + m2, dtype=np.int64)
     it = np.arange(m1 + m2, m1 + m2 + t, dtype=np.int64)
