@@ -36,7 +36,8 @@ class ScheduleCounts(C.Structure):
 
 class FitDesc(C.Structure):
     _fields_ = [("m1", C.c_int32), ("m2", C.c_int32), ("t", C.c_int32), ("b1", C.c_int32), ("b2", C.c_int32),
-                ("scene", C.c_int32), ("idx_offset", C.c_int64), ("out_offset", C.c_int64),
+                ("scene", C.c_int32), ("slot", C.c_int32), ("reserved", C.c_int32), ("idx_offset", C.c_int64),
+                ("out_offset", C.c_int64),
                 ("ws_offset", C.c_int64)]
 
 
@@ -67,7 +68,7 @@ SIGNATURES = {
     "gapro_fit_options_default": (None, [C.POINTER(FitOptions)]),
     "gapro_fit_workspace_doubles": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "gapro_fit_plan_workspace": (C.c_int64, [_P, C.c_int32, C.c_int32]),
-    "gapro_svgp_fit_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.POINTER(FitOptions), _P,
+    "gapro_svgp_fit_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.POINTER(FitOptions), _P,
                                        C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_fit_workspace_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P]),
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),

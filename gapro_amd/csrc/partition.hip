@@ -96,15 +96,34 @@ __global__ __launch_bounds__(kThreads) void k_stats(long long n, int d, const do
 }
 
 // ---- K1b: fold partials into the scene header --------------------------------------------------
-__global__ void k_stats_final(long long n, int n_partials, long long range_cap, PrepareWorkspace* ws) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  StatsPartial p = ws->partials[0];
-  for (int j = 1; j < n_partials; ++j) {
+__global__ __launch_bounds__(kThreads) void k_stats_final(long long n, int n_partials, long long range_cap,
+                                                          PrepareWorkspace* ws) {
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  long long smin = 0x7fffffffffffffffLL, smax = -0x7fffffffffffffffLL - 1;
+  float fa = 0.f;
+  for (int j = threadIdx.x; j < n_partials; j += kThreads) {
     const StatsPartial& q = ws->partials[j];
-    for (int k = 0; k < 3; ++k) { p.mn[k] = fmin(p.mn[k], q.mn[k]); p.mx[k] = fmax(p.mx[k], q.mx[k]); }
-    p.smin = q.smin < p.smin ? q.smin : p.smin;
-    p.smax = q.smax > p.smax ? q.smax : p.smax;
-    p.fabsmax = fmaxf(p.fabsmax, q.fabsmax);
+    for (int k = 0; k < 3; ++k) { mn[k] = fmin(mn[k], q.mn[k]); mx[k] = fmax(mx[k], q.mx[k]); }
+    smin = q.smin < smin ? q.smin : smin;
+    smax = q.smax > smax ? q.smax : smax;
+    fa = fmaxf(fa, q.fabsmax);
+  }
+  __shared__ StatsPartial sh[kThreads / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = 0; k < 3; ++k) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); }
+  smin = wave_min_ll(smin); smax = wave_max_ll(smax); fa = wave_max_f(fa);
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) { sh[w].mn[k] = mn[k]; sh[w].mx[k] = mx[k]; }
+    sh[w].smin = smin; sh[w].smax = smax; sh[w].fabsmax = fa;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  StatsPartial p = sh[0];
+  for (int j = 1; j < kThreads / 64; ++j) {
+    for (int k = 0; k < 3; ++k) { p.mn[k] = fmin(p.mn[k], sh[j].mn[k]); p.mx[k] = fmax(p.mx[k], sh[j].mx[k]); }
+    p.smin = sh[j].smin < p.smin ? sh[j].smin : p.smin;
+    p.smax = sh[j].smax > p.smax ? sh[j].smax : p.smax;
+    p.fabsmax = fmaxf(p.fabsmax, sh[j].fabsmax);
   }
   gapro_scene_header h;
   for (int k = 0; k < 3; ++k) { h.coord_min[k] = p.mn[k]; h.coord_max[k] = p.mx[k]; }
@@ -120,7 +139,6 @@ __global__ void k_stats_final(long long n, int n_partials, long long range_cap, 
   h.fixed_shift = k;
   h.n_spps = 0;
   h.status = GAPRO_OK;
-  // 128-bit-safe range check
   const unsigned long long range = (unsigned long long)p.smax - (unsigned long long)p.smin;
   if (range >= (unsigned long long)range_cap) h.status = GAPRO_ERR_SPP_RANGE;
   ws->header = h;
@@ -348,7 +366,7 @@ int gapro_partition_prepare(gapro_ctx* ctx, void* stream_, int64_t n_points, int
   const int g_stats = grid_for(n_points, kMaxStatBlocks);
   hipLaunchKernelGGL(k_stats, dim3(g_stats), dim3(kThreads), 0, stream, (long long)n_points, (int)feat_dim, d_coords,
                      d_feats, (const long long*)d_spp, ws->partials);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, stream, (long long)n_points, g_stats,
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(kThreads), 0, stream, (long long)n_points, g_stats,
                      (long long)spp_range_cap, ws);
   GAPRO_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)spp_range_cap * sizeof(unsigned), stream));
   const int g_pts = grid_for(n_points);

@@ -1,5 +1,6 @@
 // Batched whitened-SVGP classifier fit for gfx950 (MI355X): one workgroup = one GP fit, the whole
-// Adam loop inside one launch.
+// Adam loop inside one launch.  LDS-staged kernel (M_p <= 512); svgp_fit_large.hip is the generic
+// fallback with the same arithmetic.
 //
 // Replaces reference gapro/gaussian_process_utils.py:382-445 (fit_gp_spp) and the gpytorch objects
 // it builds (:11-25): CholeskyVariationalDistribution + whitened VariationalStrategy with learned
@@ -8,31 +9,49 @@
 // autograd on the device: the backward pass is the hand-derived one of SURVEY.md Appendix B.5,
 // restated and checked against torch autograd in oracle/svgp_oracle.py.
 //
-// Arithmetic: float64 throughout (the reference runs its Cholesky/solves in float64 and the rest in
-// float32; float64 everywhere is a superset and is what makes "variances within 1e-4" testable
-// against a float64 ground truth -- DESIGN.md "Precision").  Every M x M x M contraction is a
-// TN-form MFMA product (v_mfma_f64_16x16x4_f64):  C[i][j] = sum_k P[k][i] * Q[k][j]  with both
-// operands row-major in k, so that fragment loads are 128-byte row segments; matrices that are
-// needed in both orientations are written in both by the producing epilogue.
+// Arithmetic: float64 throughout (DESIGN.md "Precision").  Every M x M x M contraction is a TN-form
+// MFMA product (v_mfma_f64_16x16x4_f64):  C[i][j] = sum_k P[k][i] * Q[k][j], both operands row-major
+// in k so that fragment loads are 128-byte row segments; a matrix needed in both orientations is
+// written in both by the producing epilogue (transposed copies go through an LDS tile so that the
+// global stores stay row-contiguous).
 //
-//   forward : Kzz -> L (blocked left-looking Cholesky) -> LI = L^-1 (block-column parallel)
+// Per Adam step:
+//   forward : Kzz tiles are evaluated on the fly inside the blocked left-looking Cholesky (16-wide
+//             panels, MFMA updates, panel held in LDS, diagonal block factored in registers by one
+//             wave) -> L, L^T;  LI = L^-1 (one 16-wide block column per wave, blocks kept in registers)
 //             KX = k(Z, X);  A = LI KX;  B = LS^T A;  mu = A^T m + c;  var = s + eps + |B|^2 - |A|^2
-//             E = Gauss-Hermite( log Phi(y f) );  loss = -(sum E - KL) / N
-//   backward: G_m, G_c, G_LS = tril(A G_B^T) + KL',  G_A = m g_mu^T + LS G_B - 2 A diag(g_v)
-//             G_KX = LI^T G_A;  G_L = -tril(G_KX A^T);  G_Kzz = LI^T Phi(L^T G_L) LI (symmetrised)
-//             G_s, G_l, G_Z through the RBF kernel;  softplus' = sigmoid
+//             g_mu, g_v from the 20-point Gauss-Hermite rule of log Phi(y f)
+//   backward: G_m, G_c;  G_A = m g_mu^T + LS G_B - 2 A diag(g_v);  G_LS = tril(A G_B^T) + KL' with the
+//             Adam update of LS fused into the epilogue;  G_KX = LI^T G_A;  G_L = -tril(G_KX A^T);
+//             G_Kzz = LI^T Phi(L^T G_L) LI;  one fused pass turns G_Kzz, G_KX into G_s, G_l, G_Z
+//             (kernel values recomputed from the LDS copies of Z and X) and applies Adam to Z
 //   Adam    : torch.optim.Adam defaults (beta 0.9/0.999, eps 1e-8), lr 0.1
+// Inducing points Z and training points X live transposed in LDS ([d][i]) so that a thread that owns
+// column j reads its own point conflict-free and the row point as an LDS broadcast.
 #include <math.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
+
+void gapro_launch_fit_large(hipStream_t stream, int n_fits, int feat_dim, const float* d_feats_spp, const int* d_idx,
+                            const gapro_fit_desc* d_descs, const double* d_init_mean, const gapro_fit_options& opt,
+                            double* d_workspace, float* d_probs, float* d_probs_new, unsigned char* d_labels,
+                            float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss);
 
 namespace {
 
 constexpr int NT = 512;       // threads per fit
 constexpr int NW = NT / 64;   // waves per fit
-constexpr int NGH = 20;       // Gauss-Hermite nodes (gpytorch settings.num_gauss_hermite_locs)
+constexpr int kMaxMpLds = 512;          // largest padded M the LDS-staged kernel takes
+constexpr int kMaxDynLds = 150 * 1024;  // dynamic LDS budget (160 KiB per CU minus the static part)
+constexpr int kRedSlots = 8;            // values reduced across row groups per pass
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+// LDS pointers carry their address space explicitly: ds_read/ds_write instead of flat accesses, and no
+// generic->local casts for the optimiser to trip over.
+typedef __attribute__((address_space(3))) double ldsd;
 
 // numpy.polynomial.hermite.hermgauss(20): positive nodes (ascending) and their weights; the rule is
 // symmetric.  Printed with repr() from NumPy 2.2.
@@ -46,7 +65,7 @@ __constant__ double c_gh_w[10] = {0.4622436696006101,     0.28667550536283415,  
 
 inline __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
-// ---- workspace layout (doubles) -------------------------------------------------------------------
+// ---- workspace layout (doubles); identical to svgp_fit_large.hip -----------------------------------
 enum MatId {
   B_LS = 0, B_LST, B_MLS, B_VLS, B_GLS, B_L, B_LT, B_LI, B_U, B_KX, B_A, B_AT, B_BM, B_BMT, B_GA, B_GKX, B_GKXT,
   B_COUNT
@@ -74,7 +93,22 @@ inline __host__ __device__ Layout make_layout(int m, int t, int d) {
   return L;
 }
 
-// scalars kept in the workspace tail (also visible to tests)
+// dynamic LDS of the staged kernel: Zt[D][Mp] | Pt[D][Mp] | scratch
+inline __host__ __device__ int scratch_doubles(int Mp) {
+  const int a = kRedSlots * NT;     // cross-group reductions / quadrature partials
+  const int b = Mp * 17 + 64 * 17;  // Cholesky block column (row stride 17) + slack
+  const int c = NW * 16 * 17;       // per-wave transpose tiles
+  int m = a > b ? a : b;
+  return m > c ? m : c;
+}
+inline __host__ __device__ long long staged_lds_bytes(int m, int d) {
+  const int Mp = round_up(m > 0 ? m : 1, 32);
+  return 8LL * (2LL * d * Mp + scratch_doubles(Mp));
+}
+inline __host__ __device__ bool staged_ok(int m, int d) {
+  return round_up(m > 0 ? m : 1, 32) <= kMaxMpLds && d <= 32 && staged_lds_bytes(m, d) <= kMaxDynLds;
+}
+
 enum ScalId { S_C = 0, S_RS, S_RL, S_MC, S_MRS, S_MRL, S_VC, S_VRS, S_VRL, S_LOSS, S_STATUS };
 
 struct Fit {
@@ -83,6 +117,23 @@ struct Fit {
   double* vec[V_COUNT];
   double *X, *Z, *mZ, *vZ, *gZ, *Xt, *dinv, *dinvT, *scal;
 };
+
+#ifdef GAPRO_PROFILE
+constexpr int kProfSlots = 20;
+#endif
+struct Shared {
+  Fit f;
+#ifdef GAPRO_PROFILE
+  unsigned long long prof[kProfSlots];
+  unsigned long long t_last;
+#endif
+  double red[NW];
+  double dblk[16 * 17];
+  double dinv[16 * 17];
+  double c, rho_s, rho_l, s, ell, inv_l2;
+  int status;
+};
+__shared__ Shared g_sh;  // one fit per workgroup
 
 // ---- small helpers ---------------------------------------------------------------------------------
 __device__ inline double softplus(double x) { return log1p(exp(-fabs(x))) + fmax(x, 0.0); }
@@ -108,26 +159,46 @@ __device__ inline double wave_sum(double v) {
 }
 
 // Deterministic block sum (fixed tree), result broadcast to every thread.
-__device__ inline double block_sum(double v, double* sh /* >= NW doubles */) {
+__device__ inline double block_sum(double v) {
   v = wave_sum(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) g_sh.red[threadIdx.x >> 6] = v;
   __syncthreads();
   double t = 0.0;
-  for (int w = 0; w < NW; ++w) t += sh[w];
+  for (int w = 0; w < NW; ++w) t += g_sh.red[w];
   return t;
 }
 
+// squared distance between staged points: At[d][i] and Bt[d][j], leading dimension Mp
+__device__ inline double sqdist_t(const ldsd* At, int i, const ldsd* Bt, int j, int D, int Mp) {
+  double s = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double t = At[d * Mp + i] - Bt[d * Mp + j];
+    s += t * t;
+  }
+  return s;
+}
+
+// stage n points [n][D] (global, row-major) transposed into LDS dst[D][Mp]; columns >= n are zeroed
+__device__ inline void stage_points_t(ldsd* dst, const double* src, int n, int D, int Mp) {
+  for (int e = threadIdx.x; e < D * Mp; e += NT) {
+    const int d = e / Mp, i = e - d * Mp;
+    dst[e] = i < n ? src[(size_t)i * D + d] : 0.0;
+  }
+}
+
 // ---- TN-form MFMA product ---------------------------------------------------------------------------
-//   C[i][j] = sum_{k in [klo,khi)} P[k][i] * (Q[k][j] * qscale(k)),  ld = leading dimension of P and Q
-// Each wave owns (16 TU) x (16 TU) output tiles, round-robin.  `lower_only` enumerates tiles with
-// ti >= tj.  kr(i0, j0, &klo, &khi) restricts the contraction range (multiples of 4) to where the
-// triangular operands are non-zero.  epi(i, j, value) stores the result (and any transposed copy).
+//   C[i][j] = sum_{k in [klo,khi)} P[k][i] * Q[k][j] (* qscale[k] if SCALE),  ld = leading dimension
+// Each wave owns (16 TU) x (16 TU) output tiles, round-robin; `lower_only` enumerates tiles ti >= tj.
+// kr(i0, j0, &klo, &khi) restricts the contraction (multiples of 16) to where triangular operands are
+// non-zero.  epi(i0, j0, tile) consumes one 16x16 result tile in MFMA C layout.  Fragments of the next
+// 16-deep block are loaded before the MFMAs of the current one are issued.
 // MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3): A[i = l & 15][k = l >> 4],
 // B[k = l >> 4][j = l & 15], C/D register r -> row (l >> 4) + 4 r, col l & 15.
-template <int TU, typename KRange, typename QScale, typename Epi>
+template <int TU, bool SCALE, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const double* __restrict__ P,
-                               const double* __restrict__ Q, int ld, KRange kr, QScale qs, Epi epi) {
+                                     const double* __restrict__ Q, int ld, const double* __restrict__ qscale,
+                                     KRange kr, Epi epi) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
   constexpr int TS = 16 * TU;
@@ -150,321 +221,496 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
     for (int u = 0; u < TU; ++u)
 #pragma unroll
       for (int v = 0; v < TU; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int k = klo; k < khi; k += 4) {
-      const double* prow = P + (size_t)(k + lq) * ld + i0 + lr;
-      const double* qrow = Q + (size_t)(k + lq) * ld + j0 + lr;
-      const double sc = qs(k + lq);
-      double a[TU], b[TU];
+    const double* pbase = P + (size_t)lq * ld + i0 + lr;
+    const double* qbase = Q + (size_t)lq * ld + j0 + lr;
+    double a0[4][TU], b0[4][TU], a1[4][TU], b1[4][TU];
+    auto load_block = [&](int k, double (&a)[4][TU], double (&b)[4][TU]) {
 #pragma unroll
-      for (int u = 0; u < TU; ++u) a[u] = prow[16 * u];
+      for (int s = 0; s < 4; ++s) {
+        const double* pr = pbase + (size_t)(k + 4 * s) * ld;
+        const double* qr = qbase + (size_t)(k + 4 * s) * ld;
+        const double sc = SCALE ? qscale[k + 4 * s + lq] : 1.0;
 #pragma unroll
-      for (int v = 0; v < TU; ++v) b[v] = qrow[16 * v] * sc;
+        for (int u = 0; u < TU; ++u) a[s][u] = pr[16 * u];
 #pragma unroll
-      for (int u = 0; u < TU; ++u)
+        for (int v = 0; v < TU; ++v) b[s][v] = SCALE ? qr[16 * v] * sc : qr[16 * v];
+      }
+    };
+    auto mma_block = [&](double (&a)[4][TU], double (&b)[4][TU]) {
 #pragma unroll
-        for (int v = 0; v < TU; ++v) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int v = 0; v < TU; ++v)
+            acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], b[s][v], acc[u][v], 0, 0, 0);
+    };
+    if (klo < khi) {
+      load_block(klo, a0, b0);
+      int k = klo;
+      while (true) {
+        if (k + 16 < khi) load_block(k + 16, a1, b1);
+        mma_block(a0, b0);
+        k += 16;
+        if (k >= khi) break;
+        if (k + 16 < khi) load_block(k + 16, a0, b0);
+        mma_block(a1, b1);
+        k += 16;
+        if (k >= khi) break;
+      }
     }
 #pragma unroll
     for (int u = 0; u < TU; ++u)
 #pragma unroll
-      for (int v = 0; v < TU; ++v)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) epi(i0 + 16 * u + lq + 4 * r, j0 + 16 * v + lr, acc[u][v][r]);
+      for (int v = 0; v < TU; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
   }
 }
 
-struct NoScale {
-  __device__ double operator()(int) const { return 1.0; }
-};
+// Store a 16x16 accumulator tile (C layout) row-major at Cm[i0.., j0..] and/or transposed at CT[j0.., i0..].
+// The transposed copy goes through a per-wave LDS tile so that its global stores are 128-byte rows too.
+__device__ inline void store_tile(const d4& v, double* __restrict__ Cm, double* __restrict__ CT, int ld, int i0, int j0,
+                                  ldsd* tile /* per-wave 16x17 */) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  if (Cm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cm[(size_t)(i0 + lq + 4 * r) * ld + j0 + lr] = v[r];
+  }
+  if (CT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(lq + 4 * r) * 17 + lr] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) CT[(size_t)(j0 + lq + 4 * r) * ld + i0 + lr] = tile[lr * 17 + lq + 4 * r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
 
-// ---- Cholesky of the padded Kzz (in B_L, lower) -> L, LT; Dinv blocks -------------------------------
-// Left-looking, 16-wide panels.  Panel kb: (1) S = Kzz[:,kb] - L[:, <kb] L[kb, <kb]^T  (MFMA, TN via
-// LT), (2) wave 0 factors the 16x16 diagonal block and inverts it, (3) the panel below is
-// S * Dinv^T.  The padded tail (index >= M) is an identity block.
-__device__ __noinline__ void cholesky_blocked(const Fit& f, double* sh_d /* 16x17 */, double* sh_dinv /* 16x17 */,
-                                 int* sh_status) {
-  const int Mp = f.Mp, nb = Mp / 16;
+// ---- Cholesky of Kzz + jitter I, fused with the kernel evaluation -----------------------------------
+// Left-looking, 16-wide block columns.  Block column kb:
+//   (1) S = Kzz[:, kb] - L[:, <kb] L[kb, <kb]^T : the Kzz tile is evaluated from the staged inducing
+//       points straight into the MFMA accumulator, the update reads L^T (TN form); S goes to an LDS panel
+//   (2) wave 0 factors the 16x16 diagonal block held one row per lane in registers (cross-lane
+//       broadcasts, no LDS round trips) and inverts it (column per lane)
+//   (3) panel below = S * Dinv^T, computed in LDS, then written once to L (rows) and L^T (rows)
+// The padded tail (index >= M) is an identity block.  Strict upper triangle of L stays zero.
+__device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double s, double inv_l2, double jitter) {
+  const Fit& f = g_sh.f;
+  Shared& sh = g_sh;
+  const int Mp = f.Mp, M = f.M, D = f.D, nb = Mp / 16;
   double* L = f.mat[B_L];
   double* LT = f.mat[B_LT];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
   for (int kb = 0; kb < nb; ++kb) {
-    // (1) update block column kb
+    // (1)
     for (int ib = kb + wave; ib < nb; ib += NW) {
       d4 acc;
+      const int col = 16 * kb + lr;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = L[(size_t)(16 * ib + lq + 4 * r) * Mp + 16 * kb + lr];
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ib + lq + 4 * r;
+        double v = 0.0;
+        if (row < M && col < M) {
+          v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+          if (row == col) v += jitter;
+        } else if (row == col) {
+          v = 1.0;
+        }
+        acc[r] = v;
+      }
+      const double* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
+      const double* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
 #pragma unroll 4
-      for (int q = 0; q < 16 * kb; q += 4) {
-        const double a = LT[(size_t)(q + lq) * Mp + 16 * ib + lr];
-        const double b = LT[(size_t)(q + lq) * Mp + 16 * kb + lr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a, b, acc, 0, 0, 0);
-      }
-      if (ib == kb) {
+      for (int q = 0; q < 16 * kb; q += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[(size_t)q * Mp], pb[(size_t)q * Mp], acc, 0, 0, 0);
+      ldsd* dst = panel + (16 * (ib - kb)) * 17;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sh_d[(lq + 4 * r) * 17 + lr] = acc[r];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) L[(size_t)(16 * ib + lq + 4 * r) * Mp + 16 * kb + lr] = acc[r];
-      }
+      for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
     }
     __syncthreads();
-    // (2) diagonal block: unblocked Cholesky + inverse, one wave
+    // (2)
     if (wave == 0) {
+      double a[16];
+      const int r = lane & 15;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = panel[r * 17 + c];
+      bool bad = false;
+#pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double d = sh_d[j * 17 + j];
+        double d = __shfl(a[j], j, 64);
         if (!(d > 0.0)) {  // not positive definite (or NaN): flag it, keep going with a tiny pivot
-          if (lane == 0) *sh_status = GAPRO_ERR_CHOLESKY;
+          bad = true;
           d = 1e-30;
         }
-        d = sqrt(d);
-        __builtin_amdgcn_wave_barrier();
-        if (lane > j && lane < 16) sh_d[lane * 17 + j] /= d;
-        if (lane == 0) sh_d[j * 17 + j] = d;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // trailing rank-1 update of the lower triangle: 256 (r, c) slots over 64 lanes
+        const double sd = sqrt(d);
+        const double lj = (r == j) ? sd : a[j] / sd;  // column j of L: rows >= j are meaningful
+        a[j] = lj;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int idx = lane + 64 * e;
-          const int r = idx >> 4, c = idx & 15;
-          if (r > j && c > j && c <= r) sh_d[r * 17 + c] -= sh_d[r * 17 + j] * sh_d[c * 17 + j];
+        for (int c = j + 1; c < 16; ++c) {
+          const double lc = __shfl(lj, c, 64);  // L[c][j]
+          a[c] -= lj * lc;                      // only rows r >= c are used later
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
-      // inverse of the lower-triangular block, one column per lane (forward substitution)
-      if (lane < 16) {
-        const int c = lane;
-        double x[16];
+      if (bad && lane == 0) sh.status = GAPRO_ERR_CHOLESKY;
+      // inverse of the lower-triangular block: lane c computes column c by forward substitution;
+      // L[rr][q] is broadcast from lane rr's registers
+      double x[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          double s = (r == c) ? 1.0 : 0.0;
+      for (int rr = 0; rr < 16; ++rr) {
+        double acc = (rr == r) ? 1.0 : 0.0;
 #pragma unroll
-          for (int q = 0; q < r; ++q) s -= (q >= c) ? sh_d[r * 17 + q] * x[q] : 0.0;
-          x[r] = (r >= c) ? s / sh_d[r * 17 + r] : 0.0;
+        for (int q = 0; q < rr; ++q) {
+          const double lrq = __shfl(a[q], rr, 64);
+          acc -= (q >= r) ? lrq * x[q] : 0.0;
         }
+        const double lrr = __shfl(a[rr], rr, 64);
+        x[rr] = (rr >= r) ? acc / lrr : 0.0;
+      }
+      if (lane < 16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sh_dinv[r * 17 + c] = x[r];
+        for (int c = 0; c < 16; ++c) {
+          sh.dblk[r * 17 + c] = (c <= r) ? a[c] : 0.0;  // L_kk
+          sh.dinv[c * 17 + r] = x[c];                   // Dinv[c][r]: lane r holds column r
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // write the diagonal block (lower, zero upper) to L and LT, and Dinv / Dinv^T to the workspace
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int idx = lane + 64 * e;
-        const int r = idx >> 4, c = idx & 15;
-        const double v = (c <= r) ? sh_d[r * 17 + c] : 0.0;
-        L[(size_t)(16 * kb + r) * Mp + 16 * kb + c] = v;
-        LT[(size_t)(16 * kb + c) * Mp + 16 * kb + r] = v;
-        const double di = sh_dinv[r * 17 + c];
-        f.dinv[(size_t)kb * 256 + r * 16 + c] = di;
-        f.dinvT[(size_t)kb * 256 + c * 16 + r] = di;
+        const int rr = idx >> 4, cc = idx & 15;
+        L[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = sh.dblk[rr * 17 + cc];
+        LT[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = sh.dblk[cc * 17 + rr];
+        f.dinv[(size_t)kb * 256 + idx] = sh.dinv[rr * 17 + cc];
+        f.dinvT[(size_t)kb * 256 + idx] = sh.dinv[cc * 17 + rr];
       }
     }
     __syncthreads();
-    // (3) panel below the diagonal block: L[i][16kb + c] = sum_{q <= c} S[i][16kb + q] Dinv[c][q]
+    // (3) rows below the diagonal block, in LDS: P[i][c] <- sum_{q <= c} S[i][q] Dinv[c][q]
     const int rows_below = Mp - 16 * (kb + 1);
+    ldsd* pb = panel + 16 * 17;
     for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {
-      const int i = 16 * (kb + 1) + (idx >> 4), c = idx & 15;
-      const double* srow = L + (size_t)i * Mp + 16 * kb;
-      double sv[16];
+      const int i = idx >> 4, c = idx & 15;
+      double acc = 0.0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) sv[q] = srow[q];
-      double s = 0.0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) s += (q <= c) ? sv[q] * sh_dinv[c * 17 + q] : 0.0;
-      __builtin_amdgcn_wave_barrier();  // all 16 lanes of a row have read S before any of them overwrites it
-      L[(size_t)i * Mp + 16 * kb + c] = s;
-      LT[(size_t)(16 * kb + c) * Mp + i] = s;
+      for (int q = 0; q < 16; ++q) acc += (q <= c) ? pb[i * 17 + q] * sh.dinv[c * 17 + q] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the 16 lanes of a row have all read S before any overwrites it
+      pb[i * 17 + c] = acc;
     }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L rows: 16 contiguous columns
+      const int i = idx >> 4, c = idx & 15;
+      L[(size_t)(16 * (kb + 1) + i) * Mp + 16 * kb + c] = pb[i * 17 + c];
+    }
+    if (rows_below > 0)
+      for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L^T rows: contiguous in i
+        const int c = idx / rows_below, i = idx - c * rows_below;
+        LT[(size_t)(16 * kb + c) * Mp + 16 * (kb + 1) + i] = pb[i * 17 + c];
+      }
     __syncthreads();
   }
 }
 
-// ---- LI = L^-1 (lower) and U = LI^T, one 16-wide block column per wave ----------------------------
+// ---- LI = L^-1 (lower) and U = LI^T, one 16-wide block column per wave -----------------------------
 //   LI_kk = Dinv_k;   LI_ik = -Dinv_i * sum_{j=k}^{i-1} L_ij LI_jk   (i > k)
-// Block columns are independent; inside one, block rows are sequential but need no workgroup
-// barrier (a wave re-reads only blocks it wrote itself, after a workgroup-scope fence).
-__device__ __noinline__ void tri_inverse(const Fit& f) {
+// Block columns are independent.  For nb <= NBR the blocks of the column stay in registers (an MFMA
+// result in C layout is directly the B operand of the next product: register r holds rows 4r + lane/16);
+// longer columns re-read their own blocks from memory after a workgroup-scope fence.
+template <int NBR>
+__device__ __noinline__ void tri_inverse(ldsd* tiles) {
+  const Fit& f = g_sh.f;
   const int Mp = f.Mp, nb = Mp / 16;
   const double* LT = f.mat[B_LT];
   double* LI = f.mat[B_LI];
   double* U = f.mat[B_U];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
+  ldsd* tile = tiles + wave * 16 * 17;
   for (int k = wave; k < nb; k += NW) {
-    // diagonal block (blocks above it stay zero: the buffer is zero-initialised and never written there)
+    d4 blk[NBR > 0 ? NBR : 1];
+    d4 dk;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = lq + 4 * r;
-      const double v = f.dinv[(size_t)k * 256 + rr * 16 + lr];
-      LI[(size_t)(16 * k + rr) * Mp + 16 * k + lr] = v;
-      U[(size_t)(16 * k + lr) * Mp + 16 * k + rr] = v;
-    }
+    for (int r = 0; r < 4; ++r) dk[r] = f.dinv[(size_t)k * 256 + (lq + 4 * r) * 16 + lr];
+    store_tile(dk, LI, U, Mp, 16 * k, 16 * k, tile);
+    if (NBR > 0) blk[0] = dk;
     for (int i = k + 1; i < nb; ++i) {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int j = k; j < i; ++j) {
+      if (NBR > 0) {
 #pragma unroll
-        for (int q = 0; q < 16; q += 4) {
-          const double a = LT[(size_t)(16 * j + q + lq) * Mp + 16 * i + lr];  // L[16i + lr][16j + q + lq]
-          const double b = LI[(size_t)(16 * j + q + lq) * Mp + 16 * k + lr];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        for (int jj = 0; jj < NBR; ++jj) {
+          if (jj < i - k) {
+            const double* pa = LT + (size_t)(16 * (k + jj) + lq) * Mp + 16 * i + lr;  // L[16i+lr][16(k+jj)+4s+lq]
+#pragma unroll
+            for (int sstep = 0; sstep < 4; ++sstep)
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)(4 * sstep) * Mp], blk[jj][sstep], acc, 0, 0, 0);
+          }
+        }
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int j = k; j < i; ++j) {
+#pragma unroll
+          for (int q = 0; q < 16; q += 4) {
+            const double a = LT[(size_t)(16 * j + q + lq) * Mp + 16 * i + lr];
+            const double b = LI[(size_t)(16 * j + q + lq) * Mp + 16 * k + lr];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          }
         }
       }
-      // out = -Dinv_i * acc : register r of acc holds rows 4r + lq, exactly the B operand of k-step r
       d4 out = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double a = -f.dinvT[(size_t)i * 256 + (4 * s + lq) * 16 + lr];  // -Dinv_i[lr][4s + lq]
-        out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[s], out, 0, 0, 0);
+      for (int sstep = 0; sstep < 4; ++sstep) {
+        const double a = -f.dinvT[(size_t)i * 256 + (4 * sstep + lq) * 16 + lr];  // -Dinv_i[lr][4s + lq]
+        out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[sstep], out, 0, 0, 0);
       }
+      store_tile(out, LI, U, Mp, 16 * i, 16 * k, tile);
+      if (NBR > 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = lq + 4 * r;
-        LI[(size_t)(16 * i + rr) * Mp + 16 * k + lr] = out[r];
-        U[(size_t)(16 * k + lr) * Mp + 16 * i + rr] = out[r];
+        for (int jj = 1; jj < NBR; ++jj)
+          if (jj == i - k) blk[jj] = out;
       }
     }
   }
 }
 
-// ---- kernel matrices --------------------------------------------------------------------------------
-__device__ inline double sqdist(const double* a, const double* b, int D) {
-  double s = 0.0;
-  for (int d = 0; d < D; ++d) {
-    const double t = a[d] - b[d];
-    s += t * t;
-  }
-  return s;
+// ---- elementwise passes, thread-per-column ------------------------------------------------------------
+// Threads are laid out as G row groups x Mp columns (Mp <= NT).  A thread owns one column and walks rows
+// group, group+G, ...; per-column partial results of the G groups are combined in a fixed order through
+// `red` ([kRedSlots][NT] doubles).
+struct ColMap {
+  int G, col, grp;
+  bool active;
+};
+__device__ inline ColMap col_map(int Mp) {
+  ColMap c;
+  c.G = NT / Mp;
+  c.col = threadIdx.x % Mp;
+  c.grp = threadIdx.x / Mp;
+  c.active = c.grp < c.G;
+  return c;
 }
 
-// Kzz + jitter*I (lower incl. diagonal, zero strict upper, identity on the padded tail) into B_L.
-__device__ __noinline__ void build_kzz(const Fit& f, double s, double inv_l2, double jitter) {
-  const int Mp = f.Mp, M = f.M, D = f.D;
-  double* L = f.mat[B_L];
-  for (int idx = threadIdx.x; idx < Mp * Mp; idx += NT) {
-    const int i = idx / Mp, j = idx - i * Mp;
-    double v = 0.0;
-    if (i < M && j <= i) {
-      v = s * exp(-0.5 * inv_l2 * sqdist(f.Z + (size_t)i * D, f.Z + (size_t)j * D, D));
-      if (i == j) v += jitter;
-    } else if (i >= M && i == j) {
-      v = 1.0;
-    }
-    L[idx] = v;
-  }
-}
-
-// KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for n < ncols (points P), zero elsewhere.
-__device__ __noinline__ void build_kx(const Fit& f, const double* pts, int ncols, double s, double inv_l2) {
+// KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for k < M, n < ncols, zero elsewhere (Pt: staged points)
+__device__ __noinline__ void build_kx(const ldsd* Zt, const ldsd* Pt, int ncols, double s, double inv_l2) {
+  const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   double* KX = f.mat[B_KX];
-  for (int idx = threadIdx.x; idx < Mp * Mp; idx += NT) {
-    const int k = idx / Mp, n = idx - k * Mp;
+  const ColMap cm = col_map(Mp);
+  if (!cm.active) return;
+  const int n = cm.col;
+  for (int k = cm.grp; k < Mp; k += cm.G) {
     double v = 0.0;
-    if (k < M && n < ncols) v = s * exp(-0.5 * inv_l2 * sqdist(f.Z + (size_t)k * D, pts + (size_t)n * D, D));
-    KX[idx] = v;
+    if (k < M && n < ncols) v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Pt, n, D, Mp));
+    KX[(size_t)k * Mp + n] = v;
   }
 }
 
-// out[c] = sum_r w[r] * Mtx[r][c]  for c < Mp (deterministic: fixed row partition, fixed order)
-__device__ __noinline__ void weighted_colsum(const double* Mtx, const double* w, int Mp, double* out, double* sh_part) {
-  const int G = NT / Mp > 0 ? NT / Mp : 1;  // row groups (Mp <= NT) or 1
-  __syncthreads();
-  for (int c0 = 0; c0 < Mp; c0 += NT) {
-    const int c = c0 + (threadIdx.x % (Mp < NT ? Mp : NT));
-    const int g = Mp < NT ? threadIdx.x / Mp : 0;
-    if (g < G && c < Mp) {
-      double s = 0.0;
-      for (int r = g; r < Mp; r += G) s += w[r] * Mtx[(size_t)r * Mp + c];
-      sh_part[g * (Mp < NT ? Mp : NT) + (c - c0)] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < (Mp < NT ? Mp : NT) && c0 + (int)threadIdx.x < Mp) {
-      double s = 0.0;
-      for (int g2 = 0; g2 < G; ++g2) s += sh_part[g2 * (Mp < NT ? Mp : NT) + threadIdx.x];
-      out[c0 + threadIdx.x] = s;
-    }
-    __syncthreads();
-  }
-}
-
-// var[n] = s + jitter + sum_i (BM[i][n]^2 - A[i][n]^2), clamped at min_variance (gradient 0 if clamped)
-__device__ __noinline__ void column_variance(const Fit& f, double s, double jitter, double* sh_part) {
+// mu[n] = sum_i m[i] A[i][n],  var[n] = s + jitter + sum_i (BM[i][n]^2 - A[i][n]^2)
+__device__ __noinline__ void mean_var(double s, double jitter, ldsd* red) {
+  const Fit& f = g_sh.f;
   const int Mp = f.Mp;
   const double* A = f.mat[B_A];
   const double* BM = f.mat[B_BM];
-  const int W = Mp < NT ? Mp : NT;
-  const int G = NT / Mp > 0 ? NT / Mp : 1;
-  __syncthreads();
-  for (int c0 = 0; c0 < Mp; c0 += NT) {
-    const int c = c0 + (threadIdx.x % W);
-    const int g = Mp < NT ? threadIdx.x / Mp : 0;
-    if (g < G && c < Mp) {
-      double acc = 0.0;
-      for (int r = g; r < Mp; r += G) {
-        const double b = BM[(size_t)r * Mp + c], a = A[(size_t)r * Mp + c];
-        acc += b * b - a * a;
-      }
-      sh_part[g * W + (c - c0)] = acc;
+  const double* m = f.vec[V_M];
+  const ColMap cm = col_map(Mp);
+  double pm = 0.0, pv = 0.0;
+  if (cm.active) {
+    for (int i = cm.grp; i < Mp; i += cm.G) {
+      const double a = A[(size_t)i * Mp + cm.col], b = BM[(size_t)i * Mp + cm.col];
+      pm += m[i] * a;
+      pv += b * b - a * a;
     }
+  }
+  red[threadIdx.x] = pm;
+  red[NT + threadIdx.x] = pv;
+  __syncthreads();
+  if (threadIdx.x < Mp) {
+    double sm = 0.0, sv = 0.0;
+    for (int g = 0; g < cm.G; ++g) {
+      sm += red[g * Mp + threadIdx.x];
+      sv += red[NT + g * Mp + threadIdx.x];
+    }
+    f.vec[V_MU][threadIdx.x] = sm;
+    f.vec[V_VAR][threadIdx.x] = s + jitter + sv;
+  }
+  __syncthreads();
+}
+
+// out[c] = sum_r w[r] Mtx[r][c]
+__device__ __noinline__ void weighted_colsum(const double* Mtx, const double* w, int Mp, double* out, ldsd* red) {
+  const ColMap cm = col_map(Mp);
+  double p = 0.0;
+  if (cm.active)
+    for (int r = cm.grp; r < Mp; r += cm.G) p += w[r] * Mtx[(size_t)r * Mp + cm.col];
+  red[threadIdx.x] = p;
+  __syncthreads();
+  if (threadIdx.x < Mp) {
+    double sacc = 0.0;
+    for (int g = 0; g < cm.G; ++g) sacc += red[g * Mp + threadIdx.x];
+    out[threadIdx.x] = sacc;
+  }
+  __syncthreads();
+}
+
+// Expected log-likelihood terms: 20-point Gauss-Hermite of log Phi(y f), ten threads per point (one per
+// symmetric node pair).  Writes g_mu[n] = -dE/dmu / N and g_v[n] = -dE/dvar / N (0 where the variance
+// was clamped), returns sum_n E_n when want_e.
+__device__ __noinline__ double quadrature(double c, double min_variance, double Nd, bool want_e, ldsd* red,
+                                          double* g_c, double* gv_sum) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, M = f.M;
+  double* gmu = f.vec[V_GMU];
+  double* gv = f.vec[V_GV];
+  double e_tot = 0.0, gc_part = 0.0, gvs_part = 0.0;
+  constexpr int PPR = NT / 10;  // points per round
+  const int q = threadIdx.x % 10, nl = threadIdx.x / 10;
+  for (int n0 = 0; n0 < M; n0 += PPR) {
+    const int n = n0 + nl;
+    double E = 0.0, dmu = 0.0, dvar = 0.0;
+    const bool on = nl < PPR && n < M;
+    if (on) {
+      const double mu = f.vec[V_MU][n] + c;
+      const double vraw = f.vec[V_VAR][n];
+      const double var = vraw < min_variance ? min_variance : vraw;
+      const double sd = sqrt(2.0 * var);
+      const double y = f.vec[V_Y][n];
+      const double t = c_gh_t[q], w = c_gh_w[q];
+      double lp, r;
+      log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
+      E += w * lp; dmu += w * r; dvar -= w * t * r;
+      log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
+      E += w * lp; dmu += w * r; dvar += w * t * r;
+    }
+    red[threadIdx.x] = E;
+    red[NT + threadIdx.x] = dmu;
+    red[2 * NT + threadIdx.x] = dvar;
     __syncthreads();
-    if (threadIdx.x < W && c0 + (int)threadIdx.x < Mp) {
-      double acc = 0.0;
-      for (int g2 = 0; g2 < G; ++g2) acc += sh_part[g2 * W + threadIdx.x];
-      f.vec[V_VAR][c0 + threadIdx.x] = s + jitter + acc;
+    if (on && q == 0) {
+      double se = 0.0, sm = 0.0, sv = 0.0;
+      for (int qq = 0; qq < 10; ++qq) {
+        se += red[threadIdx.x + qq];
+        sm += red[NT + threadIdx.x + qq];
+        sv += red[2 * NT + threadIdx.x + qq];
+      }
+      const double ipi = 0.56418958354775628695;  // 1/sqrt(pi)
+      const double vraw = f.vec[V_VAR][n];
+      const bool clamped = vraw < min_variance;
+      const double var = clamped ? min_variance : vraw;
+      const double y = f.vec[V_Y][n];
+      const double g1 = -(ipi * sm * y) / Nd;
+      const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
+      gmu[n] = g1;
+      gv[n] = g2;
+      e_tot += ipi * se;
+      gc_part += g1;
+      gvs_part += g2;
     }
     __syncthreads();
   }
+  for (int n = M + threadIdx.x; n < Mp; n += NT) {
+    gmu[n] = 0.0;
+    gv[n] = 0.0;
+  }
+  *g_c = block_sum(gc_part);
+  *gv_sum = block_sum(gvs_part);
+  return want_e ? block_sum(e_tot) : 0.0;
 }
 
-// A = LI * KX (+ AT), then BMT = A^T LS (+ BM), over `ncol_tiles` 16TU-wide column tiles
-template <int TU>
-__device__ __noinline__ void forward_products(const Fit& f, int ncols) {
-  const int Mp = f.Mp;
-  constexpr int TS = 16 * TU;
-  const int mt = Mp / TS, nt = (ncols + TS - 1) / TS;
-  double* A = f.mat[B_A];
-  double* AT = f.mat[B_AT];
-  double* BM = f.mat[B_BM];
-  double* BMT = f.mat[B_BMT];
-  // A[i][n] = sum_k U[k][i] KX[k][n],  U[k][i] = LI[i][k] = 0 for k > i
-  gemm_tn<TU>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp,
-              [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; }, NoScale(),
-              [=](int i, int n, double v) { A[(size_t)i * Mp + n] = v; AT[(size_t)n * Mp + i] = v; });
-  __syncthreads();
-  // BMT[n][j] = sum_i A[i][n] LS[i][j],  LS[i][j] = 0 for i < j
-  gemm_tn<TU>(nt, mt, false, A, f.mat[B_LS], Mp,
-              [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; }, NoScale(),
-              [=](int n, int j, double v) { BMT[(size_t)n * Mp + j] = v; BM[(size_t)j * Mp + n] = v; });
-  __syncthreads();
+// Fused kernel-gradient pass + Adam on Z.  The thread owning column j accumulates over rows i:
+//   zz: w  = sym(G)[i][j] s E_ij  ->  G_s += sym(G) E,  G_l += w d2,   G_Z[j] += 2 w (Z_j - Z_i)
+//   zx: wx = G_KX[j][n=i] KX_jn   ->  G_s += G_KX E,    G_l += wx d2,  G_Z[j] += wx (Z_j - X_i)
+// (sym(G) o K is symmetric, so the sum over i of column j equals the row sum of the oracle's formula.)
+template <int DMAX>
+__device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const double* Gm, const double* GTm,
+                                                 const double* GKXT, double s, double inv_l2, double step_size,
+                                                 double bc2s, ldsd* red, double* gs_out, double* gl_out) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, M = f.M, D = f.D;
+  const ColMap cm = col_map(Mp);
+  const int j = cm.col;
+  double zj[DMAX], acc[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    zj[d] = (d < D) ? Zt[d * Mp + j] : 0.0;
+    acc[d] = 0.0;
+  }
+  double gs = 0.0, gl = 0.0;
+  if (cm.active && j < M) {
+    for (int i = cm.grp; i < M; i += cm.G) {
+      const size_t o = (size_t)i * Mp + j;
+      double t[DMAX];
+      double d2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) {
+        t[d] = (d < D) ? zj[d] - Zt[d * Mp + i] : 0.0;
+        d2 += t[d] * t[d];
+      }
+      const double e = exp(-0.5 * inv_l2 * d2);
+      const double gsym = 0.5 * (Gm[o] + GTm[o]);
+      const double w = gsym * s * e;
+      gs += gsym * e;
+      gl += w * d2;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) acc[d] += 2.0 * w * t[d];
+      double d2x = 0.0;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) {
+        t[d] = (d < D) ? zj[d] - Xt[d * Mp + i] : 0.0;
+        d2x += t[d] * t[d];
+      }
+      const double ex = exp(-0.5 * inv_l2 * d2x);
+      const double g = GKXT[o];  // G_KX[j][i]
+      const double wx = g * s * ex;
+      gs += g * ex;
+      gl += wx * d2x;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) acc[d] += wx * t[d];
+    }
+  }
+  *gs_out = block_sum(gs);
+  *gl_out = block_sum(gl);
+  // combine the row groups, kRedSlots feature dimensions at a time, then Adam on Z (and its LDS copy)
+  const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
+#pragma unroll
+  for (int dc = 0; dc < DMAX; dc += kRedSlots) {
+    if (dc < D) {
+#pragma unroll
+      for (int e = 0; e < kRedSlots; ++e)
+        if (dc + e < DMAX) red[e * NT + threadIdx.x] = acc[dc + e];
+      __syncthreads();
+      if (threadIdx.x < M) {
+#pragma unroll
+        for (int e = 0; e < kRedSlots; ++e) {
+          const int d = dc + e;
+          if (d < D && d < DMAX) {
+            double sacc = 0.0;
+            for (int g = 0; g < cm.G; ++g) sacc += red[e * NT + g * Mp + threadIdx.x];
+            const double grad = -inv_l2 * sacc;
+            const size_t zi = (size_t)threadIdx.x * D + d;
+            f.gZ[zi] = grad;
+            const double m1 = b1 * f.mZ[zi] + (1.0 - b1) * grad;
+            const double m2 = b2 * f.vZ[zi] + (1.0 - b2) * grad * grad;
+            f.mZ[zi] = m1;
+            f.vZ[zi] = m2;
+            const double znew = f.Z[zi] - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+            f.Z[zi] = znew;
+            Zt[d * Mp + threadIdx.x] = znew;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
 }
 
-#ifdef GAPRO_PROFILE
-constexpr int kProfSlots = 20;
-#endif
-struct Shared {
-  Fit f;
-#ifdef GAPRO_PROFILE
-  unsigned long long prof[kProfSlots];
-  unsigned long long t_last;
-#endif
-  double red[NW];
-  double dblk[16 * 17];
-  double dinv[16 * 17];
-  double part[NT];
-  double c, rho_s, rho_l, s, ell, inv_l2;
-  int status;
-};
-
-template <int TU>
-__device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh, const gapro_fit_desc& desc,
-                         float* __restrict__ o_probs, float* __restrict__ o_probs_new,
+template <int TU, int DMAX>
+__device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* scratch, const gapro_fit_desc& desc, float* __restrict__ o_probs, float* __restrict__ o_probs_new,
                          unsigned char* __restrict__ o_labels, float* __restrict__ o_mu, float* __restrict__ o_var,
                          double* loss_out) {
+  const Fit& f = g_sh.f;
+  Shared& sh = g_sh;
   const int M = f.M, Mp = f.Mp, D = f.D, T = f.T;
   constexpr int TS = 16 * TU;
   const int mt = Mp / TS;
@@ -472,6 +718,8 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
   const double jitter = opt.jitter;
   double* LS = f.mat[B_LS];
   double* LST = f.mat[B_LST];
+  double* MLS = f.mat[B_MLS];
+  double* VLS = f.mat[B_VLS];
   double* GLS = f.mat[B_GLS];
   double* A = f.mat[B_A];
   double* AT = f.mat[B_AT];
@@ -480,10 +728,10 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
   double* GA = f.mat[B_GA];
   double* GKX = f.mat[B_GKX];
   double* GKXT = f.mat[B_GKXT];
-  double* KX = f.mat[B_KX];
   double* vm = f.vec[V_M];
   double* gmu = f.vec[V_GMU];
   double* gv = f.vec[V_GV];
+  ldsd* tile = scratch + (threadIdx.x >> 6) * 16 * 17;  // per-wave transpose tile
   double last_loss = 0.0;
 #ifdef GAPRO_PROFILE
   // diagnostic build only: per-phase wall-clock shares (100 MHz ticks), see tools/bench_fit.py --profile
@@ -510,187 +758,174 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
   };
   auto factorize = [&]() {
     stamp(19);
-    build_kzz(f, sh.s, sh.inv_l2, jitter);
-    __syncthreads();
-    stamp(0);
-    cholesky_blocked(f, sh.dblk, sh.dinv, &sh.status);
+    cholesky_fused(Zt, scratch, sh.s, sh.inv_l2, jitter);
     stamp(1);
-    tri_inverse(f);
+    if (Mp <= 128)
+      tri_inverse<8>(scratch);
+    else
+      tri_inverse<0>(scratch);
     __syncthreads();
     stamp(2);
+  };
+  // A = LI * KX (+ AT) and BMT = A^T LS (+ BM) over ncols columns
+  auto forward_products = [&](int ncols) {
+    const int nt = (ncols + TS - 1) / TS;
+    // A[i][n] = sum_k U[k][i] KX[k][n],  U[k][i] = LI[i][k] = 0 for k > i
+    gemm_tn<TU, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
+                       [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n, tile); });
+    __syncthreads();
+    // BMT[n][j] = sum_i A[i][n] LS[i][j],  LS[i][j] = 0 for i < j
+    gemm_tn<TU, false>(nt, mt, false, A, LS, Mp, nullptr,
+                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                       [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j, tile); });
+    __syncthreads();
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
     refresh_hypers();
     const double s = sh.s, ell = sh.ell, inv_l2 = sh.inv_l2, c = sh.c;
+    const bool last = step == opt.training_iter;
     // ------------------------------- forward -------------------------------
     factorize();
-    build_kx(f, f.X, M, s, inv_l2);
+    build_kx(Zt, Pt, M, s, inv_l2);
     __syncthreads();
     stamp(3);
-    forward_products<TU>(f, M);
+    forward_products(M);
     stamp(4);
-    weighted_colsum(A, vm, Mp, f.vec[V_MU], sh.part);  // mu (without c)
-    column_variance(f, s, jitter, sh.part);
-    // quadrature: E_n, dE/dmu, dE/dvar  (BernoulliLikelihood.expected_log_prob, 20-point Gauss-Hermite)
-    double e_part = 0.0, gmu_part = 0.0, gv_part = 0.0;
-    for (int n = threadIdx.x; n < Mp; n += NT) {
-      double g1 = 0.0, g2 = 0.0;
-      if (n < M) {
-        const double mu = f.vec[V_MU][n] + c;
-        const double vraw = f.vec[V_VAR][n];
-        const bool clamped = vraw < opt.min_variance;
-        const double var = clamped ? opt.min_variance : vraw;
-        const double sd = sqrt(2.0 * var);
-        const double y = f.vec[V_Y][n];
-        double E = 0.0, dmu = 0.0, dvar = 0.0;
-        for (int q = 0; q < NGH / 2; ++q) {
-          const double t = c_gh_t[q], w = c_gh_w[q];
-          double lp, r;
-          log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
-          E += w * lp; dmu += w * r; dvar -= w * t * r;
-          log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
-          E += w * lp; dmu += w * r; dvar += w * t * r;
+    mean_var(s, jitter, scratch);
+    double g_c, gv_sum;
+    const double e_sum = quadrature(c, opt.min_variance, Nd, last, scratch, &g_c, &gv_sum);
+    if (last) {  // the ELBO value is only reported, never used by the optimiser
+      double kl_part = 0.0;
+      for (int idx = threadIdx.x; idx < M * M; idx += NT) {
+        const int i = idx / M, j = idx - i * M;
+        if (j <= i) {
+          const double v = LS[(size_t)i * Mp + j];
+          kl_part += v * v;
+          if (i == j) kl_part -= log(v * v);
         }
-        const double ipi = 0.56418958354775628695;  // 1/sqrt(pi)
-        e_part += ipi * E;
-        g1 = -(ipi * dmu * y) / Nd;
-        g2 = clamped ? 0.0 : -(ipi * dvar * y / sd) / Nd;
       }
-      gmu[n] = g1;
-      gv[n] = g2;
-      gmu_part += g1;
-      gv_part += g2;
+      for (int i = threadIdx.x; i < M; i += NT) kl_part += vm[i] * vm[i];
+      const double kl = 0.5 * (block_sum(kl_part) - Nd);
+      last_loss = -(e_sum / Nd - kl / Nd);
     }
-    const double e_sum = block_sum(e_part, sh.red);
-    const double g_c = block_sum(gmu_part, sh.red);
-    const double gv_sum = block_sum(gv_part, sh.red);
-    // KL(q(u) || N(0, I)) = 0.5 (|LS|_F^2 + |m|^2 - M - sum log LS_jj^2)
-    double kl_part = 0.0;
-    for (int idx = threadIdx.x; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      if (j <= i) {
-        const double v = LS[(size_t)i * Mp + j];
-        kl_part += v * v;
-        if (i == j) kl_part -= log(v * v);
-      }
-    }
-    for (int i = threadIdx.x; i < M; i += NT) kl_part += vm[i] * vm[i];
-    const double kl = 0.5 * (block_sum(kl_part, sh.red) - Nd);
-    last_loss = -(e_sum / Nd - kl / Nd);
     stamp(6);
 
     // ------------------------------- backward ------------------------------
-    // G_m = A g_mu + m / N  (through AT, coalesced)
-    weighted_colsum(AT, gmu, Mp, f.vec[V_GM], sh.part);
-    for (int i = threadIdx.x; i < M; i += NT) f.vec[V_GM][i] += vm[i] / Nd;
-    __syncthreads();
+    const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
+    const double step_size = opt.lr / bc1;
+    // G_m = A g_mu (+ m / N, added with the Adam update below); through AT, coalesced
+    weighted_colsum(AT, gmu, Mp, f.vec[V_GM], scratch);
     // G_A[i][n] = 2 g_v[n] sum_j LS[i][j] BM[j][n] + m[i] g_mu[n] - 2 A[i][n] g_v[n]
-    gemm_tn<TU>(mt, mt, false, LST, BM, Mp, [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
-                NoScale(), [=](int i, int n, double v) {
-                  GA[(size_t)i * Mp + n] = 2.0 * gv[n] * v + vm[i] * gmu[n] - 2.0 * A[(size_t)i * Mp + n] * gv[n];
-                });
+    gemm_tn<TU, false>(mt, mt, false, LST, BM, Mp, nullptr,
+                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
+                       [=](int i0, int n0, const d4& v) {
+                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+                         const int n = n0 + lr;
+                         const double gvn = gv[n], gmn = gmu[n];
+#pragma unroll
+                         for (int r = 0; r < 4; ++r) {
+                           const int i = i0 + lq + 4 * r;
+                           GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * A[(size_t)i * Mp + n] * gvn;
+                         }
+                       });
+    __syncthreads();
     stamp(7);
-    // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL' ; n runs over the M train columns
-    gemm_tn<TU>(mt, mt, true, AT, BMT, Mp, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
-                [=](int k) { return 2.0 * gv[k]; },
-                [=](int i, int j, double v) {
-                  double g = 0.0;
-                  if (j <= i && i < M) {
-                    const double l = LS[(size_t)i * Mp + j];
-                    g = v + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
-                  }
-                  GLS[(size_t)i * Mp + j] = g;
-                });
+    // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL', Adam on LS fused in the epilogue
+    gemm_tn<TU, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+                      [=](int i0, int j0, const d4& v) {
+                        const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+                        const int j = j0 + lr;
+                        d4 newv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                          const int i = i0 + lq + 4 * r;
+                          const size_t o = (size_t)i * Mp + j;
+                          double lnew = 0.0;
+                          if (j <= i && i < M) {
+                            const double l = LS[o];
+                            const double g = 2.0 * v[r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+                            GLS[o] = g;
+                            const double m1 = b1 * MLS[o] + (1.0 - b1) * g;
+                            const double m2 = b2 * VLS[o] + (1.0 - b2) * g * g;
+                            MLS[o] = m1;
+                            VLS[o] = m2;
+                            lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+                            LS[o] = lnew;
+                          }
+                          newv[r] = lnew;
+                        }
+                        store_tile(newv, nullptr, LST, Mp, i0, j0, tile);  // LST[j][i]; zeros above the diagonal
+                      });
     __syncthreads();
     stamp(8);
     // G_KX = LI^T G_A   (P = LI[k][i], non-zero for k >= i)
-    gemm_tn<TU>(mt, mt, false, f.mat[B_LI], GA, Mp, [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                NoScale(), [=](int i, int n, double v) { GKX[(size_t)i * Mp + n] = v; GKXT[(size_t)n * Mp + i] = v; });
+    gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
+                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                       [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n, tile); });
     __syncthreads();
     stamp(9);
     // G_L = -tril(G_KX A^T)  -> BM buffer (lower tiles; strict upper of diagonal tiles zeroed)
     double* GL = BM;
-    gemm_tn<TU>(mt, mt, true, GKXT, AT, Mp, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; }, NoScale(),
-                [=](int i, int j, double v) { GL[(size_t)i * Mp + j] = (j <= i) ? -v : 0.0; });
+    gemm_tn<TU, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+                       [=](int i0, int j0, const d4& v) {
+                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+                         for (int r = 0; r < 4; ++r) {
+                           const int i = i0 + lq + 4 * r, j = j0 + lr;
+                           GL[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
+                         }
+                       });
     __syncthreads();
     stamp(10);
     // Pm = Phi(tril(L^T G_L)) -> GA buffer   (k >= max(i0, j0) = i0 on lower tiles)
     double* Pm = GA;
-    gemm_tn<TU>(mt, mt, true, f.mat[B_L], GL, Mp, [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                NoScale(),
-                [=](int i, int j, double v) { Pm[(size_t)i * Mp + j] = (j < i) ? v : (j == i ? 0.5 * v : 0.0); });
+    gemm_tn<TU, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
+                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                       [=](int i0, int j0, const d4& v) {
+                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+                         for (int r = 0; r < 4; ++r) {
+                           const int i = i0 + lq + 4 * r, j = j0 + lr;
+                           Pm[(size_t)i * Mp + j] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                         }
+                       });
     __syncthreads();
     stamp(11);
     // T1 = LI^T Pm, stored transposed -> BMT buffer   (k >= max(i0, j0))
     double* T1T = BMT;
-    gemm_tn<TU>(mt, mt, false, f.mat[B_LI], Pm, Mp,
-                [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; }, NoScale(),
-                [=](int i, int j, double v) { T1T[(size_t)j * Mp + i] = v; });
+    gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
+                       [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
     __syncthreads();
     stamp(12);
-    // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer   (k >= j0)
+    // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the A buffer   (k >= j0)
     double* G = BM;
-    double* GT = GKXT;
-    gemm_tn<TU>(mt, mt, false, T1T, f.mat[B_LI], Mp, [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
-                NoScale(), [=](int i, int j, double v) { G[(size_t)i * Mp + j] = v; GT[(size_t)j * Mp + i] = v; });
+    double* GT = A;
+    gemm_tn<TU, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j, tile); });
     __syncthreads();
     stamp(13);
-    // kernel weights: Wzz = sym(G) o (s Ezz) -> BM buffer in place, Wzx = G_KX o KX -> GKX in place;
-    // scalar sums for d/ds and d/dl
-    double gs_part = 0.0, gl_part = 0.0;
-    for (int idx = threadIdx.x; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      const size_t o = (size_t)i * Mp + j;
-      const double d2 = sqdist(f.Z + (size_t)i * D, f.Z + (size_t)j * D, D);
-      const double e = exp(-0.5 * inv_l2 * d2);
-      const double gsym = 0.5 * (G[o] + GT[o]);
-      const double w = gsym * s * e;
-      gs_part += gsym * e;
-      gl_part += w * d2;
-      G[o] = w;
-      const double d2x = sqdist(f.Z + (size_t)i * D, f.X + (size_t)j * D, D);
-      const double kx = KX[o];
-      const double wx = GKX[o] * kx;
-      gs_part += GKX[o] * kx / s;
-      gl_part += wx * d2x;
-      GKX[o] = wx;
-    }
-    const double g_s = block_sum(gs_part, sh.red) + gv_sum;
-    const double g_l = block_sum(gl_part, sh.red) / (ell * ell * ell);
+    // kernel gradients + Adam on Z
+    double g_s, g_l;
+    kernel_grads_adam_z<DMAX>(Zt, Pt, G, GT, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
+    g_s += gv_sum;
+    g_l /= (ell * ell * ell);
     stamp(14);
-    // G_Z[i][d] = -(1/l^2) ( sum_j 2 Wzz[i][j] (Z_i - Z_j)[d] + sum_n Wzx[i][n] (Z_i - X_n)[d] )
-    for (int idx = threadIdx.x; idx < M * D; idx += NT) {
-      const int i = idx / D, d = idx - i * D;
-      const double zi = f.Z[(size_t)i * D + d];
-      const double* wz = G + (size_t)i * Mp;
-      const double* wx = GKX + (size_t)i * Mp;
-      double acc = 0.0;
-      for (int j = 0; j < M; ++j)
-        acc += 2.0 * wz[j] * (zi - f.Z[(size_t)j * D + d]) + wx[j] * (zi - f.X[(size_t)j * D + d]);
-      f.gZ[idx] = -inv_l2 * acc;
-    }
-    __syncthreads();
-    stamp(15);
 
-    // ------------------------------- Adam ----------------------------------
-    const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
-    const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
-    const double step_size = opt.lr / bc1;
+    // ------------------------------- Adam (m, scalars) ----------------------
     auto adam = [&](double& p, double& m1, double& m2, double g) {
       m1 = b1 * m1 + (1.0 - b1) * g;
       m2 = b2 * m2 + (1.0 - b2) * g * g;
       p -= step_size * m1 / (sqrt(m2) / bc2s + aeps);
     };
-    for (int idx = threadIdx.x; idx < M * D; idx += NT) adam(f.Z[idx], f.mZ[idx], f.vZ[idx], f.gZ[idx]);
-    for (int i = threadIdx.x; i < M; i += NT) adam(vm[i], f.vec[V_MM][i], f.vec[V_VM][i], f.vec[V_GM][i]);
-    for (int idx = threadIdx.x; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      if (j <= i) {
-        const size_t o = (size_t)i * Mp + j;
-        adam(LS[o], f.mat[B_MLS][o], f.mat[B_VLS][o], GLS[o]);
-        LST[(size_t)j * Mp + i] = LS[o];
-      }
+    for (int i = threadIdx.x; i < M; i += NT) {
+      const double g = f.vec[V_GM][i] + vm[i] / Nd;
+      f.vec[V_GM][i] = g;
+      adam(vm[i], f.vec[V_MM][i], f.vec[V_VM][i], g);
     }
     if (threadIdx.x == 0) {
       adam(sh.c, f.scal[S_MC], f.scal[S_VC], g_c);
@@ -707,11 +942,13 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
   const double s = sh.s, inv_l2 = sh.inv_l2, c = sh.c;
   for (int t0 = 0; t0 < T; t0 += Mp) {
     const int nc = (T - t0) < Mp ? (T - t0) : Mp;
-    build_kx(f, f.Xt + (size_t)t0 * D, nc, s, inv_l2);
     __syncthreads();
-    forward_products<TU>(f, nc);
-    weighted_colsum(A, vm, Mp, f.vec[V_MU], sh.part);
-    column_variance(f, s, jitter, sh.part);
+    stage_points_t(Pt, f.Xt + (size_t)t0 * D, nc, D, Mp);
+    __syncthreads();
+    build_kx(Zt, Pt, nc, s, inv_l2);
+    __syncthreads();
+    forward_products(nc);
+    mean_var(s, jitter, scratch);
     for (int n = threadIdx.x; n < nc; n += NT) {
       const double mu = f.vec[V_MU][n] + c;
       const double var = fmax(f.vec[V_VAR][n], opt.min_variance);
@@ -749,56 +986,30 @@ __global__ __launch_bounds__(NT) void k_svgp_fit(int n_fits, int D, const float*
                                                  float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
                                                  float* __restrict__ o_mu, float* __restrict__ o_var,
                                                  int* __restrict__ o_status, double* __restrict__ o_loss) {
-  __shared__ Shared sh;
+  Shared& sh = g_sh;
+  extern __shared__ double dyn_lds[];
   const int fit = blockIdx.x;
   if (fit >= n_fits) return;
   const gapro_fit_desc desc = descs[fit];
   Fit& f = sh.f;
+  const Layout lay = make_layout(desc.m1 + desc.m2, desc.t, D);
+  double* base = ws + desc.ws_offset;
   if (threadIdx.x == 0) {
     f.M = desc.m1 + desc.m2;
     f.T = desc.t;
     f.D = D;
-  }
-  const Layout lay = make_layout(desc.m1 + desc.m2, desc.t, D);
-  double* base = ws + desc.ws_offset;
-  if (threadIdx.x == 0) {
-  f.Mp = lay.Mp;
-  for (int b = 0; b < B_COUNT; ++b) f.mat[b] = base + lay.mat + (long long)b * lay.Mp * lay.Mp;
-  for (int v = 0; v < V_COUNT; ++v) f.vec[v] = base + lay.vec + (long long)v * lay.Mp;
-  f.X = base + lay.xz;
-  f.Z = f.X + (long long)lay.Mp * D;
-  f.mZ = f.Z + (long long)lay.Mp * D;
-  f.vZ = f.mZ + (long long)lay.Mp * D;
-  f.gZ = f.vZ + (long long)lay.Mp * D;
-  f.Xt = base + lay.xt;
-  f.dinv = base + lay.dinv;
-  f.dinvT = f.dinv + (long long)lay.Mp * 16;
-  f.scal = base + lay.scal;
-  }
-  __syncthreads();
-
-  // ---- initialisation (gaussian_process_utils.py:386-403; gpytorch parameter inits) ----
-  for (long long i = threadIdx.x; i < lay.total; i += NT) base[i] = 0.0;
-  __syncthreads();
-  const int M = f.M, Mp = f.Mp;
-  const int* my_idx = idx + desc.idx_offset;
-  for (int e = threadIdx.x; e < M * D; e += NT) {
-    const int i = e / D, d = e - i * D;
-    const double v = (double)feats_spp[(size_t)my_idx[i] * D + d];  // train_x = cat(b1_feats, b2_feats)  :395
-    f.X[e] = v;
-    f.Z[e] = v;  // inducing points initialised to train_x  (:14)
-  }
-  for (int e = threadIdx.x; e < f.T * D; e += NT) {
-    const int i = e / D, d = e - i * D;
-    f.Xt[e] = (double)feats_spp[(size_t)my_idx[M + i] * D + d];  // intersect_feats  :386
-  }
-  for (int i = threadIdx.x; i < M; i += NT) {
-    f.vec[V_Y][i] = i < desc.m1 ? -1.0 : 1.0;  // train_y  :396-398
-    f.vec[V_M][i] = init_mean ? init_mean[desc.idx_offset + i] : 0.0;
-    f.mat[B_LS][(size_t)i * Mp + i] = 1.0;  // chol_variational_covar = I
-    f.mat[B_LST][(size_t)i * Mp + i] = 1.0;
-  }
-  if (threadIdx.x == 0) {
+    f.Mp = lay.Mp;
+    for (int b = 0; b < B_COUNT; ++b) f.mat[b] = base + lay.mat + (long long)b * lay.Mp * lay.Mp;
+    for (int v = 0; v < V_COUNT; ++v) f.vec[v] = base + lay.vec + (long long)v * lay.Mp;
+    f.X = base + lay.xz;
+    f.Z = f.X + (long long)lay.Mp * D;
+    f.mZ = f.Z + (long long)lay.Mp * D;
+    f.vZ = f.mZ + (long long)lay.Mp * D;
+    f.gZ = f.vZ + (long long)lay.Mp * D;
+    f.Xt = base + lay.xt;
+    f.dinv = base + lay.dinv;
+    f.dinvT = f.dinv + (long long)lay.Mp * 16;
+    f.scal = base + lay.scal;
     sh.c = 0.0;
     sh.rho_s = 0.0;
     sh.rho_l = 0.0;
@@ -808,16 +1019,53 @@ __global__ __launch_bounds__(NT) void k_svgp_fit(int n_fits, int D, const float*
     sh.t_last = wall_clock64();
 #endif
   }
+  const int M = desc.m1 + desc.m2, Mp = lay.Mp;
+  ldsd* Zt = (ldsd*)dyn_lds;
+  ldsd* Pt = Zt + D * Mp;
+  ldsd* scratch = Pt + D * Mp;
+
+  // ---- initialisation (gaussian_process_utils.py:386-403; gpytorch parameter inits) ----
+  // zero everything the kernel reads before writing: parameters/Adam state, padded operand tails
+  for (long long i = threadIdx.x; i < lay.total; i += NT) base[i] = 0.0;
   __syncthreads();
-  if (Mp >= 128)
-    fit_body<2>(f, opt, sh, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[fit]);
-  else
-    fit_body<1>(f, opt, sh, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[fit]);
+  const int* my_idx = idx + desc.idx_offset;
+  for (int e = threadIdx.x; e < M * D; e += NT) {
+    const int i = e / D, d = e - i * D;
+    const double v = (double)feats_spp[(size_t)my_idx[i] * D + d];  // train_x = cat(b1_feats, b2_feats)  :395
+    f.X[e] = v;
+    f.Z[e] = v;  // inducing points initialised to train_x  (:14)
+  }
+  for (int e = threadIdx.x; e < desc.t * D; e += NT) {
+    const int i = e / D, d = e - i * D;
+    f.Xt[e] = (double)feats_spp[(size_t)my_idx[M + i] * D + d];  // intersect_feats  :386
+  }
+  for (int i = threadIdx.x; i < M; i += NT) {
+    f.vec[V_Y][i] = i < desc.m1 ? -1.0 : 1.0;  // train_y  :396-398
+    f.vec[V_M][i] = init_mean ? init_mean[desc.idx_offset + i] : 0.0;
+    f.mat[B_LS][(size_t)i * Mp + i] = 1.0;  // chol_variational_covar = I
+    f.mat[B_LST][(size_t)i * Mp + i] = 1.0;
+  }
+  __syncthreads();
+  stage_points_t(Zt, f.Z, M, D, Mp);
+  stage_points_t(Pt, f.X, M, D, Mp);
+  __syncthreads();
+  double* loss_slot = &o_loss[desc.slot];
+  if (D <= 8) {
+    if (Mp >= 128)
+      fit_body<2, 8>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+    else
+      fit_body<1, 8>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+  } else {
+    if (Mp >= 128)
+      fit_body<2, 32>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+    else
+      fit_body<1, 32>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     int st = sh.status;
-    if (st == GAPRO_OK && !isfinite(o_loss[fit]) && opt.training_iter > 0) st = GAPRO_ERR_NOT_FINITE;
-    o_status[fit] = st;
+    if (st == GAPRO_OK && !isfinite(*loss_slot) && opt.training_iter > 0) st = GAPRO_ERR_NOT_FINITE;
+    o_status[desc.slot] = st;
     f.scal[S_STATUS] = (double)st;
   }
 }
@@ -852,8 +1100,6 @@ int64_t gapro_fit_plan_workspace(gapro_fit_desc* h_descs, int32_t n_fits, int32_
   return off * (int64_t)sizeof(double);
 }
 
-// Offsets (in doubles, relative to a fit's ws_offset) of the named buffers, for tests that inspect
-// intermediate state: out[0]=Mp, then mat base, vec base, xz, xt, dinv, scal, total.
 int gapro_fit_workspace_layout(int32_t m, int32_t t, int32_t feat_dim, int64_t* out8) {
   if (!out8 || m <= 0 || feat_dim <= 0) return GAPRO_ERR_BAD_ARG;
   const Layout L = make_layout(m, t, feat_dim);
@@ -863,20 +1109,60 @@ int gapro_fit_workspace_layout(int32_t m, int32_t t, int32_t feat_dim, int64_t* 
 }
 
 int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t feat_dim, const float* d_feats_spp,
-                         const int32_t* d_idx, const gapro_fit_desc* d_descs, const double* d_init_mean,
-                         const gapro_fit_options* opt, double* d_workspace, size_t workspace_bytes, float* d_probs,
-                         float* d_probs_new, uint8_t* d_labels, float* d_mu, float* d_var, int32_t* d_fit_status,
-                         double* d_fit_loss) {
+                         const int32_t* d_idx, const gapro_fit_desc* h_descs, gapro_fit_desc* d_descs,
+                         const double* d_init_mean, const gapro_fit_options* opt, double* d_workspace,
+                         size_t workspace_bytes, float* d_probs, float* d_probs_new, uint8_t* d_labels, float* d_mu,
+                         float* d_var, int32_t* d_fit_status, double* d_fit_loss) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
   if (n_fits == 0) return GAPRO_OK;
-  if (n_fits < 0 || feat_dim <= 0 || !d_feats_spp || !d_idx || !d_descs || !opt || !d_workspace || !d_probs ||
-      !d_probs_new || !d_labels || !d_mu || !d_var || !d_fit_status || !d_fit_loss || workspace_bytes == 0)
+  if (n_fits < 0 || feat_dim <= 0 || !d_feats_spp || !d_idx || !h_descs || !d_descs || !opt || !d_workspace ||
+      !d_probs || !d_probs_new || !d_labels || !d_mu || !d_var || !d_fit_status || !d_fit_loss || workspace_bytes == 0)
     return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: bad argument");
   if (opt->training_iter < 0 || !(opt->lr > 0.0) || !(opt->jitter >= 0.0))
     return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: bad options");
-  hipLaunchKernelGGL(k_svgp_fit, dim3(n_fits), dim3(NT), 0, (hipStream_t)stream_, (int)n_fits, (int)feat_dim,
-                     d_feats_spp, d_idx, d_descs, d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu,
-                     d_var, d_fit_status, d_fit_loss);
+  hipStream_t stream = (hipStream_t)stream_;
+  // Launch order = longest processing time first (cost ~ M^3): workgroups are dispatched in block
+  // order, so the expensive fits start first and the tail of the launch stays short.  Fits whose
+  // working set does not fit the LDS-staged kernel go to the generic kernel.
+  std::vector<gapro_fit_desc> staged, large;
+  staged.reserve(n_fits);
+  long long need = 0, max_lds = 0;
+  for (int i = 0; i < n_fits; ++i) {
+    gapro_fit_desc d = h_descs[i];
+    const int m = d.m1 + d.m2;
+    if (d.m1 <= 0 || d.m2 <= 0 || d.t < 0)
+      return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: fit %d has an empty side", i);
+    d.slot = i;
+    need = std::max<long long>(need, (d.ws_offset + gapro_fit_workspace_doubles(m, d.t, feat_dim)) * 8LL);
+    if (staged_ok(m, feat_dim)) {
+      staged.push_back(d);
+      max_lds = std::max(max_lds, staged_lds_bytes(m, feat_dim));
+    } else {
+      large.push_back(d);
+    }
+  }
+  if ((size_t)need > workspace_bytes)
+    return gapro_fail(ctx, GAPRO_ERR_WORKSPACE, "gapro_svgp_fit_batch: workspace too small (%lld > %zu)", need,
+                      workspace_bytes);
+  auto by_cost = [](const gapro_fit_desc& a, const gapro_fit_desc& b) { return a.m1 + a.m2 > b.m1 + b.m2; };
+  std::stable_sort(staged.begin(), staged.end(), by_cost);
+  std::stable_sort(large.begin(), large.end(), by_cost);
+  std::vector<gapro_fit_desc> all(large);
+  all.insert(all.end(), staged.begin(), staged.end());
+  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_descs, all.data(), all.size() * sizeof(gapro_fit_desc), hipMemcpyHostToDevice,
+                                      stream));
+  GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));  // `all` is pageable host memory that dies with this call
+  if (!large.empty())
+    gapro_launch_fit_large(stream, (int)large.size(), feat_dim, d_feats_spp, d_idx, d_descs, d_init_mean, *opt,
+                           d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+  if (!staged.empty()) {
+    if (max_lds > 48 * 1024)
+      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_svgp_fit, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)max_lds));
+    hipLaunchKernelGGL(k_svgp_fit, dim3((int)staged.size()), dim3(NT), (size_t)max_lds, stream, (int)staged.size(),
+                       (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size(), d_init_mean, *opt, d_workspace,
+                       d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+  }
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
 }

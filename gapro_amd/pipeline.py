@@ -238,11 +238,7 @@ class Pipeline:
             oo += job.counts.n_fit_out
         res = None
         if n_fits:
-            # longest-processing-time-first: workgroups are dispatched in block order, so launching the
-            # expensive fits (cost ~ M^3) first keeps the tail of the launch short
-            order = sorted(range(n_fits), key=lambda i: -(descs[i].m1 + descs[i].m2))
-            sorted_descs = (FitDesc * n_fits)(*[descs[i] for i in order])
-            res = self.fit_descs(feats_spp_all, sorted_descs, n_fits, h_idx, n_out, keep_debug=keep_debug)
+            res = self.fit_descs(feats_spp_all, descs, n_fits, h_idx, n_out, keep_debug=keep_debug)
 
         # ---- stage E + F
         for job in jobs:
@@ -291,7 +287,7 @@ class Pipeline:
             # gpytorch: variational mean <- 0 + mean_init_std * randn on first call
             rng = np.random.default_rng(self.seed)
             init_mean = self.init_mean_std * rng.standard_normal(len(h_idx))
-        d_descs = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(devc)
+        d_descs = torch.empty(n_fits * C.sizeof(FitDesc), dtype=torch.uint8, device=devc)
         d_idx = torch.from_numpy(h_idx).to(devc)
         d_init = torch.from_numpy(np.ascontiguousarray(init_mean, dtype=np.float64)).to(devc) \
             if init_mean is not None else None
@@ -308,7 +304,8 @@ class Pipeline:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(devc))
         ctx.check(lib.gapro_svgp_fit_batch(
-            ctx.handle, _stream_handle(devc), n_fits, D, _ptr(feats_spp), _ptr(d_idx), _ptr(d_descs), _ptr(d_init),
+            ctx.handle, _stream_handle(devc), n_fits, D, _ptr(feats_spp), _ptr(d_idx), C.cast(descs, C.c_void_p),
+            _ptr(d_descs), _ptr(d_init),
             C.byref(self.opt), _ptr(ws), ws_bytes, _ptr(probs), _ptr(probs_new), _ptr(labels), _ptr(mu), _ptr(var),
             _ptr(status), _ptr(loss)))
         if self.profile_fit:

@@ -121,6 +121,8 @@ typedef struct {
   int32_t m1, m2, t;
   int32_t b1, b2;        /* the two boxes (informational) */
   int32_t scene;         /* caller tag (informational) */
+  int32_t slot;          /* row of d_fit_status / d_fit_loss this fit reports to (set by the library) */
+  int32_t reserved;
   int64_t idx_offset;    /* into the index array */
   int64_t out_offset;    /* into the per-test-superpoint outputs */
   int64_t ws_offset;     /* into the workspace, in doubles (filled by gapro_fit_plan_workspace) */
@@ -175,15 +177,20 @@ int64_t gapro_fit_workspace_doubles(int32_t m, int32_t t, int32_t feat_dim);
 /* Fill ws_offset of every desc; returns the total workspace size in BYTES. */
 int64_t gapro_fit_plan_workspace(gapro_fit_desc* h_descs, int32_t n_fits, int32_t feat_dim);
 
-/* d_feats_spp f32[rows,D]; d_idx i32; d_descs gapro_fit_desc[n_fits] (device copies);
+/* d_feats_spp f32[rows,D]; d_idx i32; h_descs gapro_fit_desc[n_fits] on the HOST (the library orders
+ * the launch longest-fit-first and picks the kernel variant per fit) and d_descs, a device buffer of
+ * n_fits descriptors the library fills (the call synchronises the stream once for that copy, then
+ * only enqueues);
  * d_init_mean f64 (optional, may be NULL = zeros): initial variational mean of fit i at
  *   d_init_mean[idx_offset ... + m] (gpytorch adds 1e-3*randn here; zeros make runs reproducible);
  * outputs per test superpoint at out_offset: d_probs f32, d_probs_new f32, d_labels u8,
  *   d_mu f32, d_var f32  (pred_probs, pred_probs_new, pred_labels, pred_mu, pred_variance);
- * d_fit_status i32[n_fits] (gapro_status per fit), d_fit_loss f64[n_fits] (last ELBO loss). */
+ * d_fit_status i32[n_fits] (gapro_status per fit, in h_descs order), d_fit_loss f64[n_fits] (last
+ *   ELBO loss, in h_descs order). */
 int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t feat_dim,
-                         const float* d_feats_spp, const int32_t* d_idx, const gapro_fit_desc* d_descs,
-                         const double* d_init_mean, const gapro_fit_options* opt, double* d_workspace,
+                         const float* d_feats_spp, const int32_t* d_idx, const gapro_fit_desc* h_descs,
+                         gapro_fit_desc* d_descs, const double* d_init_mean, const gapro_fit_options* opt,
+                         double* d_workspace,
                          size_t workspace_bytes, float* d_probs, float* d_probs_new, uint8_t* d_labels,
                          float* d_mu, float* d_var, int32_t* d_fit_status, double* d_fit_loss);
 

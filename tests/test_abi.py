@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     # sizes follow the C declarations (natural alignment)
     assert C.sizeof(_lib.SceneHeader) == 3 * 8 + 3 * 8 + 8 + 8 + 4 + 4 + 4 + 4
-    assert C.sizeof(_lib.FitDesc) == 6 * 4 + 3 * 8
+    assert C.sizeof(_lib.FitDesc) == 8 * 4 + 3 * 8
     assert C.sizeof(_lib.FitOptions) == 40
     assert C.sizeof(_lib.ScheduleCounts) == 4 + 4 + 8 + 8 + 8 + 4 + 4
 
