@@ -190,10 +190,9 @@ def main():
         pipe.run(make_jobs())
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from gapro_amd.dist_utils import barrier_and_max
+
+    elapsed = barrier_and_max(elapsed, dev)  # MAX over ranks
 
     fit_ms = [e0.elapsed_time(e1) for e0, e1, _ in pipe.fit_events]
     fit_fl = [fl for _, _, fl in pipe.fit_events]

@@ -47,11 +47,18 @@ constexpr int NW = NT / 64;   // waves per fit
 constexpr int kMaxMpLds = 512;          // largest padded M the LDS-staged kernel takes
 constexpr int kMaxDynLds = 150 * 1024;  // dynamic LDS budget (160 KiB per CU minus the static part)
 constexpr int kRedSlots = 8;            // values reduced across row groups per pass
+#ifndef GAPRO_WAVES_PER_SIMD
+#define GAPRO_WAVES_PER_SIMD 4           // 2 workgroups of 8 waves per CU -> 128 VGPRs per lane
+#endif
+constexpr int kWavesPerSimd = GAPRO_WAVES_PER_SIMD;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 // LDS pointers carry their address space explicitly: ds_read/ds_write instead of flat accesses, and no
 // generic->local casts for the optimiser to trip over.
 typedef __attribute__((address_space(3))) double ldsd;
+// Workspace pointers are typed as global memory: global_load/global_store with counted vmcnt waits (a
+// generic pointer compiles to flat_* accesses, whose completion is unordered and forces vmcnt(0)).
+typedef __attribute__((address_space(1))) double gd;
 
 // numpy.polynomial.hermite.hermgauss(20): positive nodes (ascending) and their weights; the rule is
 // symmetric.  Printed with repr() from NumPy 2.2.
@@ -113,9 +120,9 @@ enum ScalId { S_C = 0, S_RS, S_RL, S_MC, S_MRS, S_MRL, S_VC, S_VRS, S_VRL, S_LOS
 
 struct Fit {
   int M, T, D, Mp;
-  double* mat[B_COUNT];
-  double* vec[V_COUNT];
-  double *X, *Z, *mZ, *vZ, *gZ, *Xt, *dinv, *dinvT, *scal;
+  gd* mat[B_COUNT];
+  gd* vec[V_COUNT];
+  gd *X, *Z, *mZ, *vZ, *gZ, *Xt, *dinv, *dinvT, *scal;
 };
 
 #ifdef GAPRO_PROFILE
@@ -153,6 +160,24 @@ __device__ inline void log_ndtr_ratio(double z, double* lp, double* r) {
   }
 }
 
+// value of `v` in lane `lane` (wave-uniform, compile-time after unrolling): v_readlane, no LDS crossbar
+__device__ inline double lane_bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Function arguments of non-kernel functions arrive in VGPRs; these make wave-uniform values scalar again
+// so that loop control and address arithmetic run on the scalar unit.
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ inline T* uni_ptr(T* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ inline double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -180,7 +205,7 @@ __device__ inline double sqdist_t(const ldsd* At, int i, const ldsd* Bt, int j, 
 }
 
 // stage n points [n][D] (global, row-major) transposed into LDS dst[D][Mp]; columns >= n are zeroed
-__device__ inline void stage_points_t(ldsd* dst, const double* src, int n, int D, int Mp) {
+__device__ inline void stage_points_t(ldsd* dst, const gd* src, int n, int D, int Mp) {
   for (int e = threadIdx.x; e < D * Mp; e += NT) {
     const int d = e / Mp, i = e - d * Mp;
     dst[e] = i < n ? src[(size_t)i * D + d] : 0.0;
@@ -192,17 +217,25 @@ __device__ inline void stage_points_t(ldsd* dst, const double* src, int n, int D
 // Each wave owns (16 TU) x (16 TU) output tiles, round-robin; `lower_only` enumerates tiles ti >= tj.
 // kr(i0, j0, &klo, &khi) restricts the contraction (multiples of 16) to where triangular operands are
 // non-zero.  epi(i0, j0, tile) consumes one 16x16 result tile in MFMA C layout.  Fragments of the next
-// 16-deep block are loaded before the MFMAs of the current one are issued.
+// 8-deep block are loaded before the MFMAs of the current one are issued.
 // MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3): A[i = l & 15][k = l >> 4],
 // B[k = l >> 4][j = l & 15], C/D register r -> row (l >> 4) + 4 r, col l & 15.
 template <int TU, bool SCALE, typename KRange, typename Epi>
-__device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const double* __restrict__ P,
-                                     const double* __restrict__ Q, int ld, const double* __restrict__ qscale,
-                                     KRange kr, Epi epi) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
+                                     const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+                                     Epi epi) {
+  mo_tiles = uni(mo_tiles);
+  no_tiles = uni(no_tiles);
+  lower_only = uni((int)lower_only) != 0;
+  ld = uni(ld);
+  P = uni_ptr(P);
+  Q = uni_ptr(Q);
+  qscale = uni_ptr(qscale);
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
   constexpr int TS = 16 * TU;
   const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
+#pragma nounroll
   for (int t = wave; t < ntiles; t += NW) {
     int ti, tj;
     if (lower_only) {
@@ -216,47 +249,52 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
     const int i0 = ti * TS, j0 = tj * TS;
     int klo, khi;
     kr(i0, j0, &klo, &khi);
+    klo = uni(klo);
+    khi = uni(khi);
     d4 acc[TU][TU];
 #pragma unroll
     for (int u = 0; u < TU; ++u)
 #pragma unroll
       for (int v = 0; v < TU; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
-    const double* pbase = P + (size_t)lq * ld + i0 + lr;
-    const double* qbase = Q + (size_t)lq * ld + j0 + lr;
-    double a0[4][TU], b0[4][TU], a1[4][TU], b1[4][TU];
-    auto load_block = [&](int k, double (&a)[4][TU], double (&b)[4][TU]) {
+    const gd* pbase = P + (size_t)lq * ld + i0 + lr;
+    const gd* qbase = Q + (size_t)lq * ld + j0 + lr;
+    constexpr int KS = 2;  // k-steps (of 4) per register block; two blocks alternate (one in flight)
+    constexpr int KB = 4 * KS;
+    double a0[KS][TU], b0[KS][TU], a1[KS][TU], b1[KS][TU];
+    auto load_block = [&](int k, double (&a)[KS][TU], double (&b)[KS][TU]) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const double* pr = pbase + (size_t)(k + 4 * s) * ld;
-        const double* qr = qbase + (size_t)(k + 4 * s) * ld;
-        const double sc = SCALE ? qscale[k + 4 * s + lq] : 1.0;
+      for (int s = 0; s < KS; ++s) {
+        const gd* pr = pbase + (size_t)(k + 4 * s) * ld;
+        const gd* qr = qbase + (size_t)(k + 4 * s) * ld;
 #pragma unroll
         for (int u = 0; u < TU; ++u) a[s][u] = pr[16 * u];
+        if (SCALE) {
+          const double sc = qscale[k + 4 * s + lq];
 #pragma unroll
-        for (int v = 0; v < TU; ++v) b[s][v] = SCALE ? qr[16 * v] * sc : qr[16 * v];
+          for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v] * sc;
+        } else {
+#pragma unroll
+          for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v];
+        }
       }
     };
-    auto mma_block = [&](double (&a)[4][TU], double (&b)[4][TU]) {
+    auto mma_block = [&](double (&a)[KS][TU], double (&b)[KS][TU]) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int u = 0; u < TU; ++u)
 #pragma unroll
           for (int v = 0; v < TU; ++v)
             acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], b[s][v], acc[u][v], 0, 0, 0);
     };
-    if (klo < khi) {
-      load_block(klo, a0, b0);
-      int k = klo;
-      while (true) {
-        if (k + 16 < khi) load_block(k + 16, a1, b1);
-        mma_block(a0, b0);
-        k += 16;
-        if (k >= khi) break;
-        if (k + 16 < khi) load_block(k + 16, a0, b0);
+    if (klo < khi) load_block(klo, a0, b0);
+#pragma nounroll
+    for (int k = klo; k < khi; k += 2 * KB) {
+      if (k + KB < khi) load_block(k + KB, a1, b1);
+      mma_block(a0, b0);
+      if (k + KB < khi) {
+        if (k + 2 * KB < khi) load_block(k + 2 * KB, a0, b0);
         mma_block(a1, b1);
-        k += 16;
-        if (k >= khi) break;
       }
     }
 #pragma unroll
@@ -268,7 +306,7 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 
 // Store a 16x16 accumulator tile (C layout) row-major at Cm[i0.., j0..] and/or transposed at CT[j0.., i0..].
 // The transposed copy goes through a per-wave LDS tile so that its global stores are 128-byte rows too.
-__device__ inline void store_tile(const d4& v, double* __restrict__ Cm, double* __restrict__ CT, int ld, int i0, int j0,
+__device__ inline void store_tile(const d4& v, gd* __restrict__ Cm, gd* __restrict__ CT, int ld, int i0, int j0,
                                   ldsd* tile /* per-wave 16x17 */) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   if (Cm) {
@@ -299,9 +337,9 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
   const Fit& f = g_sh.f;
   Shared& sh = g_sh;
   const int Mp = f.Mp, M = f.M, D = f.D, nb = Mp / 16;
-  double* L = f.mat[B_L];
-  double* LT = f.mat[B_LT];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  gd* L = f.mat[B_L];
+  gd* LT = f.mat[B_LT];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
   for (int kb = 0; kb < nb; ++kb) {
     // (1)
@@ -320,8 +358,8 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
         }
         acc[r] = v;
       }
-      const double* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
-      const double* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
+      const gd* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
+      const gd* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
 #pragma unroll 4
       for (int q = 0; q < 16 * kb; q += 4)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[(size_t)q * Mp], pb[(size_t)q * Mp], acc, 0, 0, 0);
@@ -337,19 +375,21 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = panel[r * 17 + c];
       bool bad = false;
+      double rdiag[16];  // 1 / L[j][j] (wave-uniform)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double d = __shfl(a[j], j, 64);
+        double d = lane_bcast(a[j], j);
         if (!(d > 0.0)) {  // not positive definite (or NaN): flag it, keep going with a tiny pivot
           bad = true;
           d = 1e-30;
         }
-        const double sd = sqrt(d);
-        const double lj = (r == j) ? sd : a[j] / sd;  // column j of L: rows >= j are meaningful
+        const double rs = rsqrt(d);
+        rdiag[j] = rs;
+        const double lj = (r == j) ? d * rs : a[j] * rs;  // column j of L: rows >= j are meaningful
         a[j] = lj;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
-          const double lc = __shfl(lj, c, 64);  // L[c][j]
+          const double lc = lane_bcast(lj, c);  // L[c][j]
           a[c] -= lj * lc;                      // only rows r >= c are used later
         }
       }
@@ -362,11 +402,10 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
         double acc = (rr == r) ? 1.0 : 0.0;
 #pragma unroll
         for (int q = 0; q < rr; ++q) {
-          const double lrq = __shfl(a[q], rr, 64);
+          const double lrq = lane_bcast(a[q], rr);
           acc -= (q >= r) ? lrq * x[q] : 0.0;
         }
-        const double lrr = __shfl(a[rr], rr, 64);
-        x[rr] = (rr >= r) ? acc / lrr : 0.0;
+        x[rr] = (rr >= r) ? acc * rdiag[rr] : 0.0;
       }
       if (lane < 16) {
 #pragma unroll
@@ -423,10 +462,10 @@ template <int NBR>
 __device__ __noinline__ void tri_inverse(ldsd* tiles) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, nb = Mp / 16;
-  const double* LT = f.mat[B_LT];
-  double* LI = f.mat[B_LI];
-  double* U = f.mat[B_U];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const gd* LT = f.mat[B_LT];
+  gd* LI = f.mat[B_LI];
+  gd* U = f.mat[B_U];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
   ldsd* tile = tiles + wave * 16 * 17;
   for (int k = wave; k < nb; k += NW) {
@@ -442,7 +481,7 @@ __device__ __noinline__ void tri_inverse(ldsd* tiles) {
 #pragma unroll
         for (int jj = 0; jj < NBR; ++jj) {
           if (jj < i - k) {
-            const double* pa = LT + (size_t)(16 * (k + jj) + lq) * Mp + 16 * i + lr;  // L[16i+lr][16(k+jj)+4s+lq]
+            const gd* pa = LT + (size_t)(16 * (k + jj) + lq) * Mp + 16 * i + lr;  // L[16i+lr][16(k+jj)+4s+lq]
 #pragma unroll
             for (int sstep = 0; sstep < 4; ++sstep)
               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)(4 * sstep) * Mp], blk[jj][sstep], acc, 0, 0, 0);
@@ -496,7 +535,7 @@ __device__ inline ColMap col_map(int Mp) {
 __device__ __noinline__ void build_kx(const ldsd* Zt, const ldsd* Pt, int ncols, double s, double inv_l2) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
-  double* KX = f.mat[B_KX];
+  gd* KX = f.mat[B_KX];
   const ColMap cm = col_map(Mp);
   if (!cm.active) return;
   const int n = cm.col;
@@ -511,9 +550,9 @@ __device__ __noinline__ void build_kx(const ldsd* Zt, const ldsd* Pt, int ncols,
 __device__ __noinline__ void mean_var(double s, double jitter, ldsd* red) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp;
-  const double* A = f.mat[B_A];
-  const double* BM = f.mat[B_BM];
-  const double* m = f.vec[V_M];
+  const gd* A = f.mat[B_A];
+  const gd* BM = f.mat[B_BM];
+  const gd* m = f.vec[V_M];
   const ColMap cm = col_map(Mp);
   double pm = 0.0, pv = 0.0;
   if (cm.active) {
@@ -539,7 +578,7 @@ __device__ __noinline__ void mean_var(double s, double jitter, ldsd* red) {
 }
 
 // out[c] = sum_r w[r] Mtx[r][c]
-__device__ __noinline__ void weighted_colsum(const double* Mtx, const double* w, int Mp, double* out, ldsd* red) {
+__device__ __noinline__ void weighted_colsum(const gd* Mtx, const gd* w, int Mp, gd* out, ldsd* red) {
   const ColMap cm = col_map(Mp);
   double p = 0.0;
   if (cm.active)
@@ -561,8 +600,8 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
                                           double* g_c, double* gv_sum) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M;
-  double* gmu = f.vec[V_GMU];
-  double* gv = f.vec[V_GV];
+  gd* gmu = f.vec[V_GMU];
+  gd* gv = f.vec[V_GV];
   double e_tot = 0.0, gc_part = 0.0, gvs_part = 0.0;
   constexpr int PPR = NT / 10;  // points per round
   const int q = threadIdx.x % 10, nl = threadIdx.x / 10;
@@ -623,8 +662,8 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
 //   zx: wx = G_KX[j][n=i] KX_jn   ->  G_s += G_KX E,    G_l += wx d2,  G_Z[j] += wx (Z_j - X_i)
 // (sym(G) o K is symmetric, so the sum over i of column j equals the row sum of the oracle's formula.)
 template <int DMAX>
-__device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const double* Gm, const double* GTm,
-                                                 const double* GKXT, double s, double inv_l2, double step_size,
+__device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const gd* Gm, const gd* GTm,
+                                                 const gd* GKXT, double s, double inv_l2, double step_size,
                                                  double bc2s, ldsd* red, double* gs_out, double* gl_out) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
@@ -716,21 +755,21 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   const int mt = Mp / TS;
   const double Nd = (double)M;  // num_data = train_y.numel() (gaussian_process_utils.py:414)
   const double jitter = opt.jitter;
-  double* LS = f.mat[B_LS];
-  double* LST = f.mat[B_LST];
-  double* MLS = f.mat[B_MLS];
-  double* VLS = f.mat[B_VLS];
-  double* GLS = f.mat[B_GLS];
-  double* A = f.mat[B_A];
-  double* AT = f.mat[B_AT];
-  double* BM = f.mat[B_BM];
-  double* BMT = f.mat[B_BMT];
-  double* GA = f.mat[B_GA];
-  double* GKX = f.mat[B_GKX];
-  double* GKXT = f.mat[B_GKXT];
-  double* vm = f.vec[V_M];
-  double* gmu = f.vec[V_GMU];
-  double* gv = f.vec[V_GV];
+  gd* LS = f.mat[B_LS];
+  gd* LST = f.mat[B_LST];
+  gd* MLS = f.mat[B_MLS];
+  gd* VLS = f.mat[B_VLS];
+  gd* GLS = f.mat[B_GLS];
+  gd* A = f.mat[B_A];
+  gd* AT = f.mat[B_AT];
+  gd* BM = f.mat[B_BM];
+  gd* BMT = f.mat[B_BMT];
+  gd* GA = f.mat[B_GA];
+  gd* GKX = f.mat[B_GKX];
+  gd* GKXT = f.mat[B_GKXT];
+  gd* vm = f.vec[V_M];
+  gd* gmu = f.vec[V_GMU];
+  gd* gv = f.vec[V_GV];
   ldsd* tile = scratch + (threadIdx.x >> 6) * 16 * 17;  // per-wave transpose tile
   double last_loss = 0.0;
 #ifdef GAPRO_PROFILE
@@ -868,7 +907,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(9);
     // G_L = -tril(G_KX A^T)  -> BM buffer (lower tiles; strict upper of diagonal tiles zeroed)
-    double* GL = BM;
+    gd* GL = BM;
     gemm_tn<TU, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                        [=](int i0, int j0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -881,7 +920,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(10);
     // Pm = Phi(tril(L^T G_L)) -> GA buffer   (k >= max(i0, j0) = i0 on lower tiles)
-    double* Pm = GA;
+    gd* Pm = GA;
     gemm_tn<TU, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                        [=](int i0, int j0, const d4& v) {
@@ -895,15 +934,15 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(11);
     // T1 = LI^T Pm, stored transposed -> BMT buffer   (k >= max(i0, j0))
-    double* T1T = BMT;
+    gd* T1T = BMT;
     gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                        [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                        [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
     __syncthreads();
     stamp(12);
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the A buffer   (k >= j0)
-    double* G = BM;
-    double* GT = A;
+    gd* G = BM;
+    gd* GT = A;
     gemm_tn<TU, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                        [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j, tile); });
@@ -917,20 +956,30 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     stamp(14);
 
     // ------------------------------- Adam (m, scalars) ----------------------
-    auto adam = [&](double& p, double& m1, double& m2, double g) {
+    auto adam_upd = [&](double p, double& m1, double& m2, double g) {
       m1 = b1 * m1 + (1.0 - b1) * g;
       m2 = b2 * m2 + (1.0 - b2) * g * g;
-      p -= step_size * m1 / (sqrt(m2) / bc2s + aeps);
+      return p - step_size * m1 / (sqrt(m2) / bc2s + aeps);
     };
     for (int i = threadIdx.x; i < M; i += NT) {
       const double g = f.vec[V_GM][i] + vm[i] / Nd;
       f.vec[V_GM][i] = g;
-      adam(vm[i], f.vec[V_MM][i], f.vec[V_VM][i], g);
+      double m1 = f.vec[V_MM][i], m2 = f.vec[V_VM][i];
+      vm[i] = adam_upd(vm[i], m1, m2, g);
+      f.vec[V_MM][i] = m1;
+      f.vec[V_VM][i] = m2;
     }
     if (threadIdx.x == 0) {
-      adam(sh.c, f.scal[S_MC], f.scal[S_VC], g_c);
-      adam(sh.rho_s, f.scal[S_MRS], f.scal[S_VRS], g_s * sigmoid(sh.rho_s));
-      adam(sh.rho_l, f.scal[S_MRL], f.scal[S_VRL], g_l * sigmoid(sh.rho_l));
+      double m1, m2;
+      m1 = f.scal[S_MC]; m2 = f.scal[S_VC];
+      sh.c = adam_upd(sh.c, m1, m2, g_c);
+      f.scal[S_MC] = m1; f.scal[S_VC] = m2;
+      m1 = f.scal[S_MRS]; m2 = f.scal[S_VRS];
+      sh.rho_s = adam_upd(sh.rho_s, m1, m2, g_s * sigmoid(sh.rho_s));
+      f.scal[S_MRS] = m1; f.scal[S_VRS] = m2;
+      m1 = f.scal[S_MRL]; m2 = f.scal[S_VRL];
+      sh.rho_l = adam_upd(sh.rho_l, m1, m2, g_l * sigmoid(sh.rho_l));
+      f.scal[S_MRL] = m1; f.scal[S_VRL] = m2;
     }
     __syncthreads();
     stamp(16);
@@ -979,7 +1028,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   }
 }
 
-__global__ __launch_bounds__(NT) void k_svgp_fit(int n_fits, int D, const float* __restrict__ feats_spp,
+__global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int D, const float* __restrict__ feats_spp,
                                                  const int* __restrict__ idx, const gapro_fit_desc* __restrict__ descs,
                                                  const double* __restrict__ init_mean, gapro_fit_options opt,
                                                  double* __restrict__ ws, float* __restrict__ o_probs,
@@ -993,7 +1042,7 @@ __global__ __launch_bounds__(NT) void k_svgp_fit(int n_fits, int D, const float*
   const gapro_fit_desc desc = descs[fit];
   Fit& f = sh.f;
   const Layout lay = make_layout(desc.m1 + desc.m2, desc.t, D);
-  double* base = ws + desc.ws_offset;
+  gd* base = (gd*)(ws + desc.ws_offset);
   if (threadIdx.x == 0) {
     f.M = desc.m1 + desc.m2;
     f.T = desc.t;

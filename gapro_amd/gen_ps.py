@@ -33,6 +33,7 @@ from glob import glob
 import numpy as np
 import torch
 
+from .dist_utils import pending_scenes, shard_scenes
 from .gen_ps_utils import getInstanceInfo
 from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
@@ -83,8 +84,7 @@ def run_worker(filenames, args, device_index):
     dev = pipe.device
     done = failed = 0
     t0 = time.time()
-    pending = [f for f in filenames
-               if not osp.exists(osp.join(args.save_folder, f.split("/")[-1][:12] + ".pth"))]  # :39-41
+    pending = pending_scenes(filenames, args.save_folder)  # :39-41
     for i in range(0, len(pending), args.batch_scenes):
         scenes = []
         for fn in pending[i:i + args.batch_scenes]:
@@ -150,7 +150,7 @@ def main(argv=None):
     devices = [int(d) for d in args.devices.split(",") if d != ""]
     if args.worker_rank >= 0 or len(devices) == 1:
         r = max(args.worker_rank, 0)
-        mine = filenames[r::len(devices)]  # independent scenes: round-robin shard, no collective
+        mine = shard_scenes(filenames, r, len(devices))  # independent scenes: round-robin shard, no collective
         run_worker(mine, args, devices[r])
     else:
         import subprocess

@@ -304,3 +304,38 @@ def make_gp_problem(seed: int, m1: int, m2: int, t: int, d: int = 6, sep: float 
     b2 = np.arange(m1, m1 + m2, dtype=np.int64)
     it = np.arange(m1 + m2, m1 + m2 + t, dtype=np.int64)
     return feats, b1, b2, it
+
+
+def write_scannet_layout(scene: Scene, data_root: str, split: str = "train", deepfeat_dir: Optional[str] = None):
+    """Write one scene in the on-disk layout reference gapro/gen_ps.py reads:
+
+      <root>/<split>/<scan>_inst_nostuff.pth   tuple(xyz f64, rgb f64, sem f64, inst f64)
+      <root>/superpoints/<scan>.pth            int64[N]
+      <root>/scans_transform/<scan>/<scan>.txt "axisAlignment = 16 floats"
+      <root>/scannet_planes/<scan>.json        optional wall quads
+    """
+    import json
+    import os
+
+    import torch
+
+    os.makedirs(os.path.join(data_root, split), exist_ok=True)
+    os.makedirs(os.path.join(data_root, "superpoints"), exist_ok=True)
+    os.makedirs(os.path.join(data_root, "scans_transform", scene.scan_name), exist_ok=True)
+    torch.save((scene.xyz, scene.rgb, scene.sem, scene.inst),
+               os.path.join(data_root, split, scene.scan_name + "_inst_nostuff.pth"))
+    torch.save(scene.spp, os.path.join(data_root, "superpoints", scene.scan_name + ".pth"))
+    with open(os.path.join(data_root, "scans_transform", scene.scan_name, scene.scan_name + ".txt"), "w") as f:
+        f.write("colorHeight = 968\n")
+        f.write("axisAlignment = " + " ".join(repr(float(v)) for v in scene.axis_align.reshape(-1)) + "\n")
+        f.write("numDepthFrames = 1\n")
+    if scene.quads is not None:
+        os.makedirs(os.path.join(data_root, "scannet_planes"), exist_ok=True)
+        with open(os.path.join(data_root, "scannet_planes", scene.scan_name + ".json"), "w") as f:
+            json.dump(scene.quads, f)
+    if deepfeat_dir is not None:
+        os.makedirs(deepfeat_dir, exist_ok=True)
+        rng = np.random.default_rng(scene.meta.get("seed", 0) + 99)
+        proj = rng.standard_normal((6, 32)) / np.sqrt(6.0)
+        torch.save((scene.default_feats() @ proj * 0.5).astype(np.float32),
+                   os.path.join(deepfeat_dir, scene.scan_name + ".pth"))

@@ -1,0 +1,78 @@
+"""The gen_ps driver: on-disk contract on CPU, end-to-end CLI on the GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _dataset(tmp_path, n=2):
+    from gapro_amd.synth import make_scene, write_scannet_layout
+
+    root = str(tmp_path / "dataset" / "scannetv2")
+    scenes = []
+    for i in range(n):
+        sc = make_scene(seed=30 + i, n_points=4000, n_objects=8, with_walls_json=(i == 0), obj_patch=25,
+                        plane_patch=80, scan_name="scene%04d_00" % (700 + i))
+        write_scannet_layout(sc, root, deepfeat_dir=str(tmp_path / "deep"))
+        scenes.append(sc)
+    return root, scenes
+
+
+def test_load_scene_follows_reference_preprocessing(tmp_path):
+    from gapro_amd.gen_ps import load_scene
+    from gapro_amd.gen_ps_utils import getInstanceInfo
+
+    root, scenes = _dataset(tmp_path, 1)
+    sc = scenes[0]
+    s = load_scene(os.path.join(root, "train", sc.scan_name + "_inst_nostuff.pth"), root)
+    np.testing.assert_array_equal(s["coords_float"], sc.aligned_xyz())  # gen_ps.py:65-69
+    # features come from the UN-aligned xyz (gen_ps.py:55 runs before the alignment)
+    np.testing.assert_array_equal(s["mask_feats"], np.concatenate([sc.xyz, sc.rgb], -1).astype(np.float32))
+    _, cls, box, vol, _ = getInstanceInfo(sc.aligned_xyz(), sc.inst, sc.sem)
+    np.testing.assert_array_equal(s["instance_box"], box.astype(np.float32))
+    assert s["instance_cls"].dtype == np.int64 and s["spp"].dtype == np.int64
+    assert len(s["wall_box"]) > 0 and s["wall_box"].dtype == np.float32
+    d = load_scene(os.path.join(root, "train", sc.scan_name + "_inst_nostuff.pth"), root, True, str(tmp_path / "deep"))
+    assert d["mask_feats"].shape == (sc.n_points, 32)
+
+
+def test_save_scene_writes_the_reference_tuple_atomically(tmp_path):
+    from gapro_amd.gen_ps import save_scene
+
+    n, s = 50, 7
+    outs = (torch.arange(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32), torch.ones(n),
+            torch.full((s,), -100.0), torch.full((s,), -100.0))
+    path = str(tmp_path / "scene0000_00.pth")
+    save_scene(path, outs)
+    assert os.listdir(tmp_path) == ["scene0000_00.pth"]  # no temp file left behind
+    tup = torch.load(path, weights_only=False)  # what ISBNet/SPFormer datasets do (scannetv2.py:46-48)
+    assert len(tup) == 5 and all(isinstance(a, np.ndarray) for a in tup)
+    assert [a.dtype for a in tup] == [np.int32, np.int32, np.float32, np.float32, np.float32]
+    assert [len(a) for a in tup] == [n, n, n, s, s]
+    inv = torch.arange(n) % s
+    save_scene(path, outs, spp_inv=inv, broadcast_mu_var=True)
+    assert [len(a) for a in torch.load(path, weights_only=False)] == [n] * 5
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_and_resume(tmp_path, capsys):
+    from gapro_amd import gen_ps
+
+    root, scenes = _dataset(tmp_path, 3)
+    save = str(tmp_path / "labels")
+    argv = ["--save_folder", save, "--data_root", root, "--batch_scenes", "2", "--eval_pslabel"]
+    gen_ps.main(argv)
+    files = sorted(os.listdir(save))
+    assert files == [s.scan_name + ".pth" for s in scenes]
+    for s in scenes:
+        sem, ins, prob, mu, var = torch.load(os.path.join(save, s.scan_name + ".pth"), weights_only=False)
+        assert sem.dtype == np.int32 and prob.dtype == np.float32 and len(sem) == s.n_points
+        assert len(mu) == len(np.unique(s.spp)) and set(np.unique(sem)) <= set(range(-100, 19))
+        assert ((prob >= 0.5) & (prob <= 1.0)).all()
+    stamp = {f: os.path.getmtime(os.path.join(save, f)) for f in files}
+    os.remove(os.path.join(save, files[1]))
+    gen_ps.main(argv)  # resume: only the missing scene is regenerated
+    assert sorted(os.listdir(save)) == files
+    assert os.path.getmtime(os.path.join(save, files[0])) == stamp[files[0]]
+    assert "Finish" in capsys.readouterr().out

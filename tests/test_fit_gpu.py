@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-VAR_RTOL = 1e-6  # << the 1e-4 of BASELINE.json's north_star
+VAR_RTOL = 1e-5  # << the 1e-4 of BASELINE.json's north_star (typical agreement: 5e-8 = float32 output rounding)
 MU_ATOL = 1e-7
 
 
