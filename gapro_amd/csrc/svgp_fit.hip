@@ -101,10 +101,13 @@ inline __host__ __device__ Layout make_layout(int m, int t, int d) {
 }
 
 // dynamic LDS of the staged kernel: Zt[D][Mp] | Pt[D][Mp] | scratch
+constexpr int kTileDoubles = NW * 16 * 17;  // per-wave transpose tiles at the start of the scratch
+constexpr int kFuseMaxMp = 128;            // up to this size column sums are fused into GEMM epilogues
+inline __host__ __device__ int part_doubles(int Mp) { return Mp <= kFuseMaxMp ? 3 * (Mp / 16) * Mp : 0; }
 inline __host__ __device__ int scratch_doubles(int Mp) {
-  const int a = kRedSlots * NT;     // cross-group reductions / quadrature partials
-  const int b = Mp * 17 + 64 * 17;  // Cholesky block column (row stride 17) + slack
-  const int c = NW * 16 * 17;       // per-wave transpose tiles
+  const int a = kRedSlots * NT;                   // cross-group reductions / quadrature partials
+  const int b = Mp * 17 + 64 * 17;                // Cholesky block column (row stride 17) + slack
+  const int c = kTileDoubles + part_doubles(Mp);  // transpose tiles + per-tile-row column sums
   int m = a > b ? a : b;
   return m > c ? m : c;
 }
@@ -141,6 +144,19 @@ struct Shared {
   int status;
 };
 __shared__ Shared g_sh;  // one fit per workgroup
+
+#ifdef GAPRO_PROFILE
+__device__ inline void prof_stamp(int id) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = wall_clock64();
+    g_sh.prof[id] += t - g_sh.t_last;
+    g_sh.t_last = t;
+  }
+}
+#else
+__device__ inline void prof_stamp(int) {}
+#endif
 
 // ---- small helpers ---------------------------------------------------------------------------------
 __device__ inline double softplus(double x) { return log1p(exp(-fabs(x))) + fmax(x, 0.0); }
@@ -368,6 +384,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
       for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
     }
     __syncthreads();
+    prof_stamp(0);
     // (2)
     if (wave == 0) {
       double a[16];
@@ -427,6 +444,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
       }
     }
     __syncthreads();
+    prof_stamp(5);
     // (3) rows below the diagonal block, in LDS: P[i][c] <- sum_{q <= c} S[i][q] Dinv[c][q]
     const int rows_below = Mp - 16 * (kb + 1);
     ldsd* pb = panel + 16 * 17;
@@ -450,6 +468,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
         LT[(size_t)(16 * kb + c) * Mp + 16 * (kb + 1) + i] = pb[i * 17 + c];
       }
     __syncthreads();
+    prof_stamp(18);
   }
 }
 
@@ -759,7 +778,6 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   gd* LST = f.mat[B_LST];
   gd* MLS = f.mat[B_MLS];
   gd* VLS = f.mat[B_VLS];
-  gd* GLS = f.mat[B_GLS];
   gd* A = f.mat[B_A];
   gd* AT = f.mat[B_AT];
   gd* BM = f.mat[B_BM];
@@ -806,19 +824,73 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(2);
   };
-  // A = LI * KX (+ AT) and BMT = A^T LS (+ BM) over ncols columns
-  auto forward_products = [&](int ncols) {
+  // Column sums fused into the GEMM epilogues (Mp <= kFuseMaxMp): every 16x16 result tile leaves the
+  // partial sum of its 16 rows per column in part_x[tile_row][column]; summed later in tile order.
+  const bool fuse = Mp <= kFuseMaxMp;
+  ldsd* part_m = scratch + kTileDoubles;       // sum_i m[i] A[i][n]   (later reused for G_m partials)
+  ldsd* part_a = part_m + (Mp / 16) * Mp;      // sum_i A[i][n]^2
+  ldsd* part_b = part_a + (Mp / 16) * Mp;      // sum_j B[j][n]^2
+  // A = LI * KX (+ AT) and BMT = A^T LS (+ BM) over ncols columns; then mu (without c) and var
+  auto forward_products = [&](int ncols, double s_, double jitter_) {
     const int nt = (ncols + TS - 1) / TS;
     // A[i][n] = sum_k U[k][i] KX[k][n],  U[k][i] = LI[i][k] = 0 for k > i
     gemm_tn<TU, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
-                       [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n, tile); });
+                       [=](int i, int n, const d4& v) {
+                         store_tile(v, A, AT, Mp, i, n, tile);
+                         if (fuse) {
+                           const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+                           double pm = 0.0, pa = 0.0;
+#pragma unroll
+                           for (int r = 0; r < 4; ++r) {
+                             pm += vm[i + lq + 4 * r] * v[r];
+                             pa += v[r] * v[r];
+                           }
+                           pm += __shfl_xor(pm, 16, 64);
+                           pa += __shfl_xor(pa, 16, 64);
+                           pm += __shfl_xor(pm, 32, 64);
+                           pa += __shfl_xor(pa, 32, 64);
+                           if (lq == 0) {
+                             part_m[(i >> 4) * Mp + n + lr] = pm;
+                             part_a[(i >> 4) * Mp + n + lr] = pa;
+                           }
+                         }
+                       });
     __syncthreads();
     // BMT[n][j] = sum_i A[i][n] LS[i][j],  LS[i][j] = 0 for i < j
     gemm_tn<TU, false>(nt, mt, false, A, LS, Mp, nullptr,
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
-                       [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j, tile); });
+                       [=](int n, int j, const d4& v) {
+                         store_tile(v, BMT, BM, Mp, n, j, tile);
+                         if (fuse) {
+                           const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+                           for (int r = 0; r < 4; ++r) {
+                             double pb = v[r] * v[r];
+                             pb += __shfl_xor(pb, 1, 64);
+                             pb += __shfl_xor(pb, 2, 64);
+                             pb += __shfl_xor(pb, 4, 64);
+                             pb += __shfl_xor(pb, 8, 64);
+                             if (lr == 0) part_b[(j >> 4) * Mp + n + lq + 4 * r] = pb;
+                           }
+                         }
+                       });
     __syncthreads();
+    if (fuse) {
+      for (int n = threadIdx.x; n < nt * TS; n += NT) {
+        double sm = 0.0, sa = 0.0, sb = 0.0;
+        for (int tq = 0; tq < Mp / 16; ++tq) {
+          sm += part_m[tq * Mp + n];
+          sa += part_a[tq * Mp + n];
+          sb += part_b[tq * Mp + n];
+        }
+        f.vec[V_MU][n] = sm;
+        f.vec[V_VAR][n] = s_ + jitter_ + (sb - sa);
+      }
+      __syncthreads();
+    } else {
+      mean_var(s_, jitter_, scratch);
+    }
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
@@ -830,9 +902,8 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     build_kx(Zt, Pt, M, s, inv_l2);
     __syncthreads();
     stamp(3);
-    forward_products(M);
+    forward_products(M, s, jitter);
     stamp(4);
-    mean_var(s, jitter, scratch);
     double g_c, gv_sum;
     const double e_sum = quadrature(c, opt.min_variance, Nd, last, scratch, &g_c, &gv_sum);
     if (last) {  // the ELBO value is only reported, never used by the optimiser
@@ -855,8 +926,8 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
     const double step_size = opt.lr / bc1;
-    // G_m = A g_mu (+ m / N, added with the Adam update below); through AT, coalesced
-    weighted_colsum(AT, gmu, Mp, f.vec[V_GM], scratch);
+    // G_m = A g_mu (+ m / N, added with the Adam update below): fused into the G_A epilogue, or through AT
+    if (!fuse) weighted_colsum(AT, gmu, Mp, f.vec[V_GM], scratch);
     // G_A[i][n] = 2 g_v[n] sum_j LS[i][j] BM[j][n] + m[i] g_mu[n] - 2 A[i][n] g_v[n]
     gemm_tn<TU, false>(mt, mt, false, LST, BM, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
@@ -867,10 +938,27 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
 #pragma unroll
                          for (int r = 0; r < 4; ++r) {
                            const int i = i0 + lq + 4 * r;
-                           GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * A[(size_t)i * Mp + n] * gvn;
+                           const double a = A[(size_t)i * Mp + n];
+                           GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
+                           if (fuse) {
+                             double pg = a * gmn;
+                             pg += __shfl_xor(pg, 1, 64);
+                             pg += __shfl_xor(pg, 2, 64);
+                             pg += __shfl_xor(pg, 4, 64);
+                             pg += __shfl_xor(pg, 8, 64);
+                             if (lr == 0) part_m[(n0 >> 4) * Mp + i] = pg;
+                           }
                          }
                        });
     __syncthreads();
+    if (fuse) {
+      for (int i = threadIdx.x; i < Mp; i += NT) {
+        double sg = 0.0;
+        for (int tq = 0; tq < Mp / 16; ++tq) sg += part_m[tq * Mp + i];
+        f.vec[V_GM][i] = sg;
+      }
+      __syncthreads();
+    }
     stamp(7);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL', Adam on LS fused in the epilogue
     gemm_tn<TU, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
@@ -886,7 +974,6 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                           if (j <= i && i < M) {
                             const double l = LS[o];
                             const double g = 2.0 * v[r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
-                            GLS[o] = g;
                             const double m1 = b1 * MLS[o] + (1.0 - b1) * g;
                             const double m2 = b2 * VLS[o] + (1.0 - b2) * g * g;
                             MLS[o] = m1;
@@ -996,8 +1083,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     build_kx(Zt, Pt, nc, s, inv_l2);
     __syncthreads();
-    forward_products(nc);
-    mean_var(s, jitter, scratch);
+    forward_products(nc, s, jitter);
     for (int n = threadIdx.x; n < nc; n += NT) {
       const double mu = f.vec[V_MU][n] + c;
       const double var = fmax(f.vec[V_VAR][n], opt.min_variance);

@@ -34,8 +34,8 @@ def _oracle(feats, b1, b2, it, iters, init_mean=None):
     X = np.concatenate([feats[b1], feats[b2]]).astype(np.float64)
     y = np.r_[-np.ones(len(b1)), np.ones(len(b2))]
     Xt = feats[it].astype(np.float64)
-    if len(b1) + len(b2) <= 64:
-        return so.svgp_fit_predict_manual(X, y, Xt, iters, init_mean=init_mean)
+    # torch autograd float64 is the reference (gradients right by construction); on tiny problems the
+    # NumPy restatement itself drifts ~1e-6 from it while the kernel stays at float32 output rounding
     return so.svgp_fit_predict_autograd(X, y, Xt, iters, "f64", init_mean=init_mean)
 
 

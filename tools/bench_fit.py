@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch  # noqa: E402
 
 from gapro_amd._lib import FitDesc  # noqa: E402
@@ -80,8 +80,9 @@ def main():
             scal, total = int(lay[6]), int(lay[7])
             ws = res["workspace"].cpu().numpy()
             prof = np.stack([ws[i * total + scal + 24: i * total + scal + 44] for i in range(min(n, 64))]).mean(0)
-            names = ["kzz", "chol", "inv", "kx", "A+BMT", "-", "meanvar/quad/kl", "Gm+GA", "GLS", "GKX", "GL", "Pm",
-                     "T1", "G", "kweights", "GZ", "adam", "predict", "-", "misc"]
+            names = ["chol:update", "chol:rest", "inv", "kx", "A+BMT+meanvar", "chol:diag", "quad/kl", "Gm+GA",
+                     "GLS+adam", "GKX", "GL", "Pm", "T1", "G", "kgrads+adamZ", "-", "adam", "predict", "chol:panel",
+                     "misc"]
             tot = prof.sum()
             print("    phases (us per fit, share): " + "  ".join(
                 "%s %.0f (%.0f%%)" % (nm, v / 100.0, 100 * v / tot) for nm, v in zip(names, prof) if v > 0), flush=True)

@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch  # noqa: E402
 
 from gapro_amd import _lib  # noqa: E402
@@ -79,7 +79,7 @@ def main():
     w = grab(res, M, t, d)
     loss, G = so.svgp_loss_and_grads(X, y, X.copy(), np.zeros(M), np.eye(M), 0.0, 0.0, 0.0)
     print("-- iter 1 (gradients at the initial point); loss hip %.12f oracle %.12f" % (res["loss"][0], loss))
-    err("G_LS", w["GLS"][:M, :M], G["LS"])
+    err("G_LS", w["MLS"][:M, :M] / 0.1, G["LS"])  # Adam first moment after one step = 0.1 g
     err("G_Z", w["gZ"][:M], G["Z"])
     err("G_m", w["GM"][:M], G["m"])
     sc = w["scal"]
