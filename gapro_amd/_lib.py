@@ -56,6 +56,8 @@ SIGNATURES = {
     "gapro_partition_prepare_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "gapro_partition_prepare": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P, C.c_size_t, _P,
                                           C.POINTER(SceneHeader)]),
+    "gapro_partition_prepare_async": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, C.c_int64, _P, C.c_size_t,
+                                                _P, _P]),
     "gapro_partition_pool": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_broadcast_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),

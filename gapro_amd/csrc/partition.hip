@@ -347,13 +347,13 @@ size_t gapro_partition_prepare_workspace_bytes(int64_t n_points, int64_t spp_ran
   return bytes;
 }
 
-int gapro_partition_prepare(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_t feat_dim,
-                            const double* d_coords, const float* d_feats, const int64_t* d_spp,
-                            int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
-                            int32_t* d_spp_inv, gapro_scene_header* h_header) {
+int gapro_partition_prepare_async(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_t feat_dim,
+                                  const double* d_coords, const float* d_feats, const int64_t* d_spp,
+                                  int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
+                                  int32_t* d_spp_inv, gapro_scene_header* h_header_pinned) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
-  if (n_points <= 0 || feat_dim <= 0 || !d_coords || !d_feats || !d_spp || !d_workspace || !d_spp_inv || !h_header ||
-      spp_range_cap < 1)
+  if (n_points <= 0 || feat_dim <= 0 || !d_coords || !d_feats || !d_spp || !d_workspace || !d_spp_inv ||
+      !h_header_pinned || spp_range_cap < 1)
     return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_prepare: bad argument");
   if (workspace_bytes < gapro_partition_prepare_workspace_bytes(n_points, spp_range_cap))
     return gapro_fail(ctx, GAPRO_ERR_WORKSPACE, "gapro_partition_prepare: workspace too small");
@@ -379,9 +379,21 @@ int gapro_partition_prepare(gapro_ctx* ctx, void* stream_, int64_t n_points, int
   hipLaunchKernelGGL(k_rank_lookup, dim3(g_pts), dim3(kThreads), 0, stream, (long long)n_points,
                      (const long long*)d_spp, ws, flags, d_spp_inv);
   GAPRO_LAUNCH_CHECK(ctx);
-  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_header_pinned, &ws->header, sizeof(gapro_scene_header),
-                                      hipMemcpyDeviceToHost, stream));
-  GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));
+  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(h_header_pinned, &ws->header, sizeof(gapro_scene_header), hipMemcpyDeviceToHost,
+                                      stream));
+  return GAPRO_OK;
+}
+
+int gapro_partition_prepare(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_t feat_dim,
+                            const double* d_coords, const float* d_feats, const int64_t* d_spp,
+                            int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
+                            int32_t* d_spp_inv, gapro_scene_header* h_header) {
+  if (!ctx || !h_header) return GAPRO_ERR_BAD_ARG;
+  const int rc = gapro_partition_prepare_async(ctx, stream_, n_points, feat_dim, d_coords, d_feats, d_spp,
+                                               spp_range_cap, d_workspace, workspace_bytes, d_spp_inv,
+                                               ctx->h_header_pinned);
+  if (rc != GAPRO_OK) return rc;
+  GAPRO_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream_));
   *h_header = *ctx->h_header_pinned;
   if (h_header->status != GAPRO_OK)
     return gapro_fail(ctx, h_header->status,

@@ -140,18 +140,26 @@ class Pipeline:
         self.fit_events = []
 
     # ------------------------------------------------------------------ stage A
-    def _prepare(self, job: SceneJob):
+    def _prepare_launch(self, job: SceneJob, hdr_ptr: int):
+        """Enqueue the scene statistics + dense ranks; the header lands in pinned memory at hdr_ptr."""
         n = job.n_points
         cap = int(self.spp_range_cap) if self.spp_range_cap else max(4 * n, 1 << 20)
         nbytes = self.lib.gapro_partition_prepare_workspace_bytes(n, cap)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        job.dev["prep_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         job.spp_inv = torch.empty(n, dtype=torch.int32, device=self.device)
-        hdr = SceneHeader()
-        self.ctx.check(self.lib.gapro_partition_prepare(
+        self.ctx.check(self.lib.gapro_partition_prepare_async(
             self.ctx.handle, _stream_handle(self.device), n, int(job.feats.shape[1]), _ptr(job.coords),
-            _ptr(job.feats), _ptr(job.spp), cap, _ptr(ws), nbytes, _ptr(job.spp_inv), C.byref(hdr)))
+            _ptr(job.feats), _ptr(job.spp), cap, _ptr(job.dev["prep_ws"]), nbytes, _ptr(job.spp_inv),
+            C.c_void_p(hdr_ptr)))
+        job.host["range_cap"] = cap
+
+    def _prepare_finish(self, job: SceneJob, hdr: SceneHeader):
+        if hdr.status != 0:
+            raise _lib.GaproError(int(hdr.status), "superpoint id range [%d, %d] exceeds the rank table (%d slots)"
+                                  % (hdr.spp_min, hdr.spp_max, job.host["range_cap"]))
         job.header = hdr
         job.n_spps = int(hdr.n_spps)
+        job.dev.pop("prep_ws", None)
         # boxes = cat(instance, wall, floor) with torch's dtype promotion (gen_ps_utils.py:317-345)
         mn = np.array(list(hdr.coord_min), dtype=np.float64)
         mx = np.array(list(hdr.coord_max), dtype=np.float64)
@@ -164,6 +172,20 @@ class Pipeline:
             [job.instance_cls, np.full(nw + 1, job.instance_classes, dtype=np.int64)]))
         job.boxes_volume = np.ascontiguousarray(np.concatenate(
             [job.instance_box_volume.astype(np.float64), job.wall_box_volume.astype(np.float64), floor_vol]))
+
+    def _prepare(self, job: SceneJob):
+        """Single-scene, blocking form (tests)."""
+        self._prepare_all([job])
+
+    def _prepare_all(self, jobs: Sequence[SceneJob]):
+        hsz = C.sizeof(SceneHeader)
+        pinned = torch.empty(len(jobs) * hsz, dtype=torch.uint8, pin_memory=True)
+        for i, job in enumerate(jobs):
+            self._prepare_launch(job, pinned.data_ptr() + i * hsz)
+        torch.cuda.current_stream(self.device).synchronize()  # one sync for the whole batch
+        raw = pinned.numpy()
+        for i, job in enumerate(jobs):
+            self._prepare_finish(job, SceneHeader.from_buffer_copy(raw[i * hsz:(i + 1) * hsz].tobytes()))
 
     # ------------------------------------------------------------------ stage B
     def _pool(self, job: SceneJob, feats_spp_all: torch.Tensor):
@@ -182,12 +204,18 @@ class Pipeline:
             C.c_float(job.thresh_spp_occu), _ptr(job.coords), _ptr(job.feats), _ptr(job.spp_inv), _ptr(d["boxes"]),
             _ptr(d["feat_sum"]), _ptr(d["occ_count"]), _ptr(d["point_count"]), _ptr(d["feats_spp"]),
             _ptr(d["occ_bits"]), _ptr(d["n_bbs"])))
+        # stage the two small tables the host scheduler needs into pinned memory (no sync here)
+        h = job.host
+        h["occ_bits_pin"] = torch.empty((S, W), dtype=torch.int64, pin_memory=True)
+        h["n_bbs_pin"] = torch.empty(S, dtype=torch.int32, pin_memory=True)
+        h["occ_bits_pin"].copy_(d["occ_bits"], non_blocking=True)
+        h["n_bbs_pin"].copy_(d["n_bbs"], non_blocking=True)
 
     # ------------------------------------------------------------------ stage C
     def _schedule(self, job: SceneJob):
         h = job.host
-        h["occ_bits"] = np.ascontiguousarray(job.dev["occ_bits"].cpu().numpy().view(np.uint64))
-        h["n_bbs"] = np.ascontiguousarray(job.dev["n_bbs"].cpu().numpy())
+        h["occ_bits"] = np.ascontiguousarray(h["occ_bits_pin"].numpy().view(np.uint64))
+        h["n_bbs"] = np.ascontiguousarray(h["n_bbs_pin"].numpy())
         sched = C.c_void_p()
         rc = self.lib.gapro_schedule_build(job.n_spps, job.n_boxes, _ptr(job.boxes), _ptr(h["occ_bits"]),
                                            _ptr(h["n_bbs"]), C.byref(sched))
@@ -203,8 +231,7 @@ class Pipeline:
         """Process a batch of scenes; fills job.outputs = (sem i32[N], inst i32[N], prob f32[N], mu f32[S],
         var f32[S]) as device tensors (same lengths as the reference returns)."""
         lib, ctx, devc = self.lib, self.ctx, self.device
-        for job in jobs:
-            self._prepare(job)
+        self._prepare_all(jobs)
         D = int(jobs[0].feats.shape[1])
         base = 0
         for job in jobs:
@@ -215,7 +242,8 @@ class Pipeline:
         feats_spp_all = torch.empty((base, D), dtype=torch.float32, device=devc)
         for job in jobs:
             self._pool(job, feats_spp_all)
-        for job in jobs:  # .cpu() synchronises
+        torch.cuda.current_stream(devc).synchronize()  # one sync: pooled tables of every scene are on the host
+        for job in jobs:
             self._schedule(job)
 
         # ---- stage D: one launch for every fit of every scene

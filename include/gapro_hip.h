@@ -77,6 +77,14 @@ int gapro_partition_prepare(gapro_ctx* ctx, void* stream, int64_t n_points, int3
                             int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
                             int32_t* d_spp_inv, gapro_scene_header* h_header);
 
+/* Same, enqueue only: the header lands in `h_header_pinned` (page-locked host memory) once the stream
+ * reaches that point; the caller synchronises and checks header->status itself.  Lets a batch of
+ * scenes share one synchronisation. */
+int gapro_partition_prepare_async(gapro_ctx* ctx, void* stream, int64_t n_points, int32_t feat_dim,
+                                  const double* d_coords, const float* d_feats, const int64_t* d_spp,
+                                  int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
+                                  int32_t* d_spp_inv, gapro_scene_header* h_header_pinned);
+
 /* Fused point-in-box membership + superpoint pooling (gen_ps_utils.py:349-363) in one pass over
  * the points.  Box corners are the float64 `boxes` of gen_ps_utils.py:329-341 (float32-rounded
  * instance/wall corners held in float64, then the float64 floor box); the +-0.005 margin is

@@ -14,7 +14,7 @@ def _run_partition(kw, thresh=0.999, spp_range_cap=None):
     pipe = Pipeline(device=0, training_iter=0, spp_range_cap=spp_range_cap)
     job = make_job(kw["coords_float"], kw["mask_feats"], kw["spp"], kw["instance_cls"], kw["instance_box"],
                    kw["instance_box_volume"], kw["wall_box"], kw["wall_box_volume"], 18, 0.1, thresh)
-    pipe._prepare(job)
+    pipe._prepare(job)  # launches gapro_partition_prepare_async, one sync, checks the header status
     feats_spp = torch.empty((job.n_spps, job.feats.shape[1]), dtype=torch.float32, device=pipe.device)
     pipe._pool(job, feats_spp)
     torch.cuda.synchronize()
