@@ -132,10 +132,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scenes-per-step", type=int, default=16)
+    ap.add_argument("--scenes-per-step", type=int, default=64)
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--feat-dim", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-times", action="store_true", help="print per-stage wall clock to stderr (adds syncs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +185,7 @@ def main():
         pipe.run(make_jobs())
     pipe.profile_fit = True
     pipe.fit_events = []
+    pipe.profile_stages = args.stage_times
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,6 +199,9 @@ def main():
     fit_ms = [e0.elapsed_time(e1) for e0, e1, _ in pipe.fit_events]
     fit_fl = [fl for _, _, fl in pipe.fit_events]
     stats = pipe.last_stats
+    if rank == 0 and args.stage_times:
+        print("stage times per step (ms): " + ", ".join("%s %.2f" % (k, 1e3 * v / args.steps)
+                                                         for k, v in pipe.stage_times.items()), file=sys.stderr)
     if rank == 0:
         avg_ms = float(np.mean(fit_ms)) if fit_ms else 0.0
         achieved = (float(np.mean(fit_fl)) / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0

@@ -341,6 +341,74 @@ __device__ inline void store_tile(const d4& v, gd* __restrict__ Cm, gd* __restri
   }
 }
 
+// Factor the 16x16 diagonal block S (LDS panel rows 0..15, row stride 17) = L_kk L_kk^T and invert L_kk.
+// One wave: lane r (mod 16) holds row r in registers; column pivots and multipliers travel by
+// v_readlane broadcasts, so the 16 dependent elimination steps never wait on LDS.  The inverse is a
+// forward substitution, one column per lane, reading L_kk as LDS broadcasts.  Results: L_kk and
+// Dinv = L_kk^-1 in g_sh.dblk / g_sh.dinv, and in global memory (L, L^T diagonal blocks, Dinv, Dinv^T).
+__device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp;
+  kb = uni(kb);
+  gd* L = f.mat[B_L];
+  gd* LT = f.mat[B_LT];
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  double rdiag[16];  // 1 / L[j][j] (wave-uniform)
+  {
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = panel[r * 17 + c];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double d = lane_bcast(a[j], j);
+      if (!(d > 0.0)) {  // not positive definite (or NaN): flag it, keep going with a tiny pivot
+        bad = true;
+        d = 1e-30;
+      }
+      const double rs = rsqrt(d);
+      rdiag[j] = rs;
+      const double lj = (r == j) ? d * rs : a[j] * rs;  // column j of L: rows >= j are meaningful
+      a[j] = lj;
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) a[c] -= lj * lane_bcast(lj, c);  // only rows r >= c are used later
+    }
+    if (bad && lane == 0) g_sh.status = GAPRO_ERR_CHOLESKY;
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) g_sh.dblk[r * 17 + c] = (c <= r) ? a[c] : 0.0;  // L_kk
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  {
+    // column r of Dinv: x[rr] = (delta - sum_{q=r}^{rr-1} L[rr][q] x[q]) / L[rr][rr]
+    double x[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      double acc = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+      for (int q = 0; q < rr; ++q) acc -= (q >= r) ? g_sh.dblk[rr * 17 + q] * x[q] : 0.0;
+      x[rr] = (rr >= r) ? acc * rdiag[rr] : 0.0;
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) g_sh.dinv[c * 17 + r] = x[c];  // Dinv[c][r]: lane r holds column r
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = lane + 64 * e;
+    const int rr = idx >> 4, cc = idx & 15;
+    L[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = g_sh.dblk[rr * 17 + cc];
+    LT[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = g_sh.dblk[cc * 17 + rr];
+    f.dinv[(size_t)kb * 256 + idx] = g_sh.dinv[rr * 17 + cc];
+    f.dinvT[(size_t)kb * 256 + idx] = g_sh.dinv[cc * 17 + rr];
+  }
+}
+
 // ---- Cholesky of Kzz + jitter I, fused with the kernel evaluation -----------------------------------
 // Left-looking, 16-wide block columns.  Block column kb:
 //   (1) S = Kzz[:, kb] - L[:, <kb] L[kb, <kb]^T : the Kzz tile is evaluated from the staged inducing
@@ -386,63 +454,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
     __syncthreads();
     prof_stamp(0);
     // (2)
-    if (wave == 0) {
-      double a[16];
-      const int r = lane & 15;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = panel[r * 17 + c];
-      bool bad = false;
-      double rdiag[16];  // 1 / L[j][j] (wave-uniform)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double d = lane_bcast(a[j], j);
-        if (!(d > 0.0)) {  // not positive definite (or NaN): flag it, keep going with a tiny pivot
-          bad = true;
-          d = 1e-30;
-        }
-        const double rs = rsqrt(d);
-        rdiag[j] = rs;
-        const double lj = (r == j) ? d * rs : a[j] * rs;  // column j of L: rows >= j are meaningful
-        a[j] = lj;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-          const double lc = lane_bcast(lj, c);  // L[c][j]
-          a[c] -= lj * lc;                      // only rows r >= c are used later
-        }
-      }
-      if (bad && lane == 0) sh.status = GAPRO_ERR_CHOLESKY;
-      // inverse of the lower-triangular block: lane c computes column c by forward substitution;
-      // L[rr][q] is broadcast from lane rr's registers
-      double x[16];
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        double acc = (rr == r) ? 1.0 : 0.0;
-#pragma unroll
-        for (int q = 0; q < rr; ++q) {
-          const double lrq = lane_bcast(a[q], rr);
-          acc -= (q >= r) ? lrq * x[q] : 0.0;
-        }
-        x[rr] = (rr >= r) ? acc * rdiag[rr] : 0.0;
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          sh.dblk[r * 17 + c] = (c <= r) ? a[c] : 0.0;  // L_kk
-          sh.dinv[c * 17 + r] = x[c];                   // Dinv[c][r]: lane r holds column r
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int idx = lane + 64 * e;
-        const int rr = idx >> 4, cc = idx & 15;
-        L[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = sh.dblk[rr * 17 + cc];
-        LT[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = sh.dblk[cc * 17 + rr];
-        f.dinv[(size_t)kb * 256 + idx] = sh.dinv[rr * 17 + cc];
-        f.dinvT[(size_t)kb * 256 + idx] = sh.dinv[cc * 17 + rr];
-      }
-    }
+    if (wave == 0) diag_factor_invert(panel, kb);
     __syncthreads();
     prof_stamp(5);
     // (3) rows below the diagonal block, in LDS: P[i][c] <- sum_{q <= c} S[i][q] Dinv[c][q]
@@ -494,19 +506,33 @@ __device__ __noinline__ void tri_inverse(ldsd* tiles) {
     for (int r = 0; r < 4; ++r) dk[r] = f.dinv[(size_t)k * 256 + (lq + 4 * r) * 16 + lr];
     store_tile(dk, LI, U, Mp, 16 * k, 16 * k, tile);
     if (NBR > 0) blk[0] = dk;
-    for (int i = k + 1; i < nb; ++i) {
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      if (NBR > 0) {
+    if (NBR > 0) {
+      // relative row index ii = i - k is a compile-time constant: every register index is static
 #pragma unroll
-        for (int jj = 0; jj < NBR; ++jj) {
-          if (jj < i - k) {
+      for (int ii = 1; ii < NBR; ++ii) {
+        const int i = k + ii;
+        if (i < nb) {
+          d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int jj = 0; jj < ii; ++jj) {
             const gd* pa = LT + (size_t)(16 * (k + jj) + lq) * Mp + 16 * i + lr;  // L[16i+lr][16(k+jj)+4s+lq]
 #pragma unroll
             for (int sstep = 0; sstep < 4; ++sstep)
               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)(4 * sstep) * Mp], blk[jj][sstep], acc, 0, 0, 0);
           }
+          d4 out = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int sstep = 0; sstep < 4; ++sstep) {
+            const double a = -f.dinvT[(size_t)i * 256 + (4 * sstep + lq) * 16 + lr];  // -Dinv_i[lr][4s + lq]
+            out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[sstep], out, 0, 0, 0);
+          }
+          store_tile(out, LI, U, Mp, 16 * i, 16 * k, tile);
+          blk[ii] = out;
         }
-      } else {
+      }
+    } else {
+      for (int i = k + 1; i < nb; ++i) {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         for (int j = k; j < i; ++j) {
 #pragma unroll
@@ -516,18 +542,13 @@ __device__ __noinline__ void tri_inverse(ldsd* tiles) {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
           }
         }
-      }
-      d4 out = (d4){0.0, 0.0, 0.0, 0.0};
+        d4 out = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int sstep = 0; sstep < 4; ++sstep) {
-        const double a = -f.dinvT[(size_t)i * 256 + (4 * sstep + lq) * 16 + lr];  // -Dinv_i[lr][4s + lq]
-        out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[sstep], out, 0, 0, 0);
-      }
-      store_tile(out, LI, U, Mp, 16 * i, 16 * k, tile);
-      if (NBR > 0) {
-#pragma unroll
-        for (int jj = 1; jj < NBR; ++jj)
-          if (jj == i - k) blk[jj] = out;
+        for (int sstep = 0; sstep < 4; ++sstep) {
+          const double a = -f.dinvT[(size_t)i * 256 + (4 * sstep + lq) * 16 + lr];  // -Dinv_i[lr][4s + lq]
+          out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[sstep], out, 0, 0, 0);
+        }
+        store_tile(out, LI, U, Mp, 16 * i, 16 * k, tile);
       }
     }
   }
@@ -783,7 +804,6 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   gd* BM = f.mat[B_BM];
   gd* BMT = f.mat[B_BMT];
   gd* GA = f.mat[B_GA];
-  gd* GKX = f.mat[B_GKX];
   gd* GKXT = f.mat[B_GKXT];
   gd* vm = f.vec[V_M];
   gd* gmu = f.vec[V_GMU];
@@ -990,7 +1010,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     // G_KX = LI^T G_A   (P = LI[k][i], non-zero for k >= i)
     gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                       [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n, tile); });
+                       [=](int i, int n, const d4& v) { store_tile(v, nullptr, GKXT, Mp, i, n, tile); });
     __syncthreads();
     stamp(9);
     // G_L = -tril(G_KX A^T)  -> BM buffer (lower tiles; strict upper of diagonal tiles zeroed)

@@ -138,6 +138,8 @@ class Pipeline:
         # optional HIP-event timing of the fit launches (bench.py): list of (start_event, end_event, flops)
         self.profile_fit = False
         self.fit_events = []
+        self.profile_stages = False  # bench.py --stage-times: synchronising per-stage wall clock
+        self.stage_times = {}
 
     # ------------------------------------------------------------------ stage A
     def _prepare_launch(self, job: SceneJob, hdr_ptr: int):
@@ -231,7 +233,18 @@ class Pipeline:
         """Process a batch of scenes; fills job.outputs = (sem i32[N], inst i32[N], prob f32[N], mu f32[S],
         var f32[S]) as device tensors (same lengths as the reference returns)."""
         lib, ctx, devc = self.lib, self.ctx, self.device
+        import time as _time
+        _t = [_time.perf_counter()]
+
+        def _mark(name):
+            if self.profile_stages:
+                torch.cuda.synchronize(devc)
+                now = _time.perf_counter()
+                self.stage_times[name] = self.stage_times.get(name, 0.0) + (now - _t[0])
+                _t[0] = now
+
         self._prepare_all(jobs)
+        _mark("A prepare")
         D = int(jobs[0].feats.shape[1])
         base = 0
         for job in jobs:
@@ -243,8 +256,10 @@ class Pipeline:
         for job in jobs:
             self._pool(job, feats_spp_all)
         torch.cuda.current_stream(devc).synchronize()  # one sync: pooled tables of every scene are on the host
+        _mark("B pool")
         for job in jobs:
             self._schedule(job)
+        _mark("C schedule")
 
         # ---- stage D: one launch for every fit of every scene
         n_fits = sum(j.counts.n_fits for j in jobs)
@@ -265,8 +280,10 @@ class Pipeline:
             io += job.counts.n_fit_idx
             oo += job.counts.n_fit_out
         res = None
+        _mark("C export")
         if n_fits:
             res = self.fit_descs(feats_spp_all, descs, n_fits, h_idx, n_out, keep_debug=keep_debug)
+        _mark("D fit")
 
         # ---- stage E + F
         for job in jobs:
@@ -302,6 +319,7 @@ class Pipeline:
             if not keep_debug:
                 lib.gapro_schedule_free(job.schedule)
                 job.schedule = None
+        _mark("E+F merge/broadcast")
         self.last_stats = dict(n_fits=n_fits, n_fit_out=n_out, fit=res)
         return [j.outputs for j in jobs]
 
