@@ -181,15 +181,18 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        pipe.run(make_jobs())
+    if args.warmup:
+        pipe.run_pipelined([make_jobs() for _ in range(args.warmup)])
     pipe.profile_fit = True
     pipe.fit_events = []
     pipe.profile_stages = args.stage_times
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.run(make_jobs())
+    if args.stage_times:
+        for _ in range(args.steps):
+            pipe.run(make_jobs())
+    else:  # K steps back to back; the host work of step i+1 overlaps the fit launch of step i
+        pipe.run_pipelined([make_jobs() for _ in range(args.steps)])
     barrier()
     elapsed = time.perf_counter() - t0
     from gapro_amd.dist_utils import barrier_and_max

@@ -245,8 +245,12 @@ __global__ __launch_bounds__(kThreads) void k_rank_lookup(long long n, const lon
 }
 
 // ---- K4: fused membership + pooling ------------------------------------------------------------
-// One thread per point.  Box corners (with the +-0.005 margin applied in float64, as
-// gen_ps_utils.py:350 does) sit in LDS; every lane reads the same corner -> LDS broadcast.
+// Eight lanes per point.  Lane k of a point adds features k, k+8, ... (so one atomic wave-instruction
+// covers 8 points x one contiguous 8*D-byte run of the per-superpoint row instead of 64 scattered
+// words: scattered atomics are ~17x slower on gfx950, MI355X_MICROARCH.md "Global float atomics"), lane
+// D%8 adds the point count, and lane k tests boxes k, k+8, ...  Box corners (with the +-0.005 margin
+// applied in float64, as gen_ps_utils.py:350 does) sit in LDS.
+constexpr int kLanesPerPoint = 8;
 __global__ __launch_bounds__(kThreads) void k_pool(long long n, int d, int nb, int shift,
                                                    const double* __restrict__ coords,
                                                    const float* __restrict__ feats,
@@ -260,18 +264,20 @@ __global__ __launch_bounds__(kThreads) void k_pool(long long n, int d, int nb, i
     sh_box[j] = c < 3 ? boxes[j] - 0.005 : boxes[j] + 0.005;
   }
   __syncthreads();
-  const long long stride = (long long)gridDim.x * kThreads;
-  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+  const int k = threadIdx.x & (kLanesPerPoint - 1);
+  const long long ppb = kThreads / kLanesPerPoint;  // points per block per iteration
+  const long long stride = (long long)gridDim.x * ppb;
+  for (long long i = (long long)blockIdx.x * ppb + (threadIdx.x / kLanesPerPoint); i < n; i += stride) {
     const double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
     const int r = spp_inv[i];
-    atomicAdd(&point_count[r], 1);
+    if (k == (d & (kLanesPerPoint - 1))) atomicAdd(&point_count[r], 1);
     const float* f = feats + i * d;
-    for (int k = 0; k < d; ++k) {
-      const long long q = __double2ll_rn(ldexp((double)f[k], shift));
-      atomicAdd(&feat_sum[(long long)r * d + k], (unsigned long long)q);
+    for (int c = k; c < d; c += kLanesPerPoint) {
+      const long long q = __double2ll_rn(ldexp((double)f[c], shift));
+      atomicAdd(&feat_sum[(long long)r * d + c], (unsigned long long)q);
     }
     int* occ_row = occ_count + (long long)r * nb;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = k; b < nb; b += kLanesPerPoint) {
       const double* bx = sh_box + 6 * b;
       const bool in = (x >= bx[0]) & (y >= bx[1]) & (z >= bx[2]) & (x <= bx[3]) & (y <= bx[4]) & (z <= bx[5]);
       if (in) atomicAdd(&occ_row[b], 1);
@@ -417,7 +423,7 @@ int gapro_partition_pool(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_
   GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_feat_sum, 0, (size_t)n_spps * feat_dim * sizeof(int64_t), stream));
   GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_occ_count, 0, (size_t)n_spps * n_boxes * sizeof(int32_t), stream));
   GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_point_count, 0, (size_t)n_spps * sizeof(int32_t), stream));
-  hipLaunchKernelGGL(k_pool, dim3(grid_for(n_points)), dim3(kThreads), lds, stream, (long long)n_points, (int)feat_dim,
+  hipLaunchKernelGGL(k_pool, dim3(grid_for(n_points * kLanesPerPoint, 4096)), dim3(kThreads), lds, stream, (long long)n_points, (int)feat_dim,
                      (int)n_boxes, (int)fixed_shift, d_coords, d_feats, d_spp_inv, d_boxes,
                      (unsigned long long*)d_feat_sum, d_occ_count, d_point_count);
   hipLaunchKernelGGL(k_pool_finalize, dim3((n_spps + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, (int)n_spps,

@@ -140,6 +140,7 @@ class Pipeline:
         self.fit_events = []
         self.profile_stages = False  # bench.py --stage-times: synchronising per-stage wall clock
         self.stage_times = {}
+        self._pin_cache = {}
 
     # ------------------------------------------------------------------ stage A
     def _prepare_launch(self, job: SceneJob, hdr_ptr: int):
@@ -190,7 +191,7 @@ class Pipeline:
             self._prepare_finish(job, SceneHeader.from_buffer_copy(raw[i * hsz:(i + 1) * hsz].tobytes()))
 
     # ------------------------------------------------------------------ stage B
-    def _pool(self, job: SceneJob, feats_spp_all: torch.Tensor):
+    def _pool(self, job: SceneJob, feats_spp_all: torch.Tensor, stage: Optional[torch.Tensor] = None, off: int = 0):
         S, B, D = job.n_spps, job.n_boxes, int(job.feats.shape[1])
         W = (B + 63) // 64
         d = job.dev
@@ -208,10 +209,14 @@ class Pipeline:
             _ptr(d["occ_bits"]), _ptr(d["n_bbs"])))
         # stage the two small tables the host scheduler needs into pinned memory (no sync here)
         h = job.host
-        h["occ_bits_pin"] = torch.empty((S, W), dtype=torch.int64, pin_memory=True)
-        h["n_bbs_pin"] = torch.empty(S, dtype=torch.int32, pin_memory=True)
+        if stage is None:
+            stage, off = torch.empty(S * (W * 8 + 4) + 16, dtype=torch.uint8, pin_memory=True), 0
+        nb1, nb2 = S * W * 8, S * 4
+        h["occ_bits_pin"] = stage[off:off + nb1].view(torch.int64).view(S, W)
+        h["n_bbs_pin"] = stage[off + nb1:off + nb1 + nb2].view(torch.int32)
         h["occ_bits_pin"].copy_(d["occ_bits"], non_blocking=True)
         h["n_bbs_pin"].copy_(d["n_bbs"], non_blocking=True)
+        return off + ((nb1 + nb2 + 15) // 16) * 16
 
     # ------------------------------------------------------------------ stage C
     def _schedule(self, job: SceneJob):
@@ -232,7 +237,42 @@ class Pipeline:
     def run(self, jobs: Sequence[SceneJob], keep_debug: bool = False):
         """Process a batch of scenes; fills job.outputs = (sem i32[N], inst i32[N], prob f32[N], mu f32[S],
         var f32[S]) as device tensors (same lengths as the reference returns)."""
-        lib, ctx, devc = self.lib, self.ctx, self.device
+        return self._finish(self._start(jobs, keep_debug))
+
+    def run_pipelined(self, batches: Sequence[Sequence[SceneJob]]):
+        """Several batches back to back, software-pipelined over two HIP streams: while the fit launch of
+        batch i occupies the GPU, the host enumerates the schedule of batch i+1 (and its partition
+        kernels slot in between fit workgroups).  Same results as run() batch by batch."""
+        if not hasattr(self, "_streams"):
+            self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+        outs, prev = [], None
+        for i, jobs in enumerate(batches):
+            stream = self._streams[i % 2]
+            stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(stream):
+                cur = self._start(jobs, False)
+            if prev is not None:
+                with torch.cuda.stream(prev["stream"]):
+                    outs.append(self._finish(prev))
+            prev = cur
+        if prev is not None:
+            with torch.cuda.stream(prev["stream"]):
+                outs.append(self._finish(prev))
+        for st in self._streams:
+            torch.cuda.current_stream(self.device).wait_stream(st)
+        return outs
+
+    def _pinned(self, tag: str, nbytes: int) -> torch.Tensor:
+        """Growable page-locked staging buffers, reused across batches (hipHostMalloc is slow)."""
+        buf = self._pin_cache.get(tag)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            self._pin_cache[tag] = buf
+        return buf
+
+    def _start(self, jobs: Sequence[SceneJob], keep_debug: bool = False):
+        """Stages A-D: everything up to and including the (asynchronous) fit launch."""
+        lib, devc = self.lib, self.device
         import time as _time
         _t = [_time.perf_counter()]
 
@@ -243,6 +283,8 @@ class Pipeline:
                 self.stage_times[name] = self.stage_times.get(name, 0.0) + (now - _t[0])
                 _t[0] = now
 
+        stream = torch.cuda.current_stream(devc)
+        slot = "s%x" % int(stream.cuda_stream)
         self._prepare_all(jobs)
         _mark("A prepare")
         D = int(jobs[0].feats.shape[1])
@@ -253,9 +295,13 @@ class Pipeline:
             job.feats_row_base = base
             base += job.n_spps
         feats_spp_all = torch.empty((base, D), dtype=torch.float32, device=devc)
+        # one pinned staging area for the tables the host scheduler needs from every scene
+        need = sum(job.n_spps * (((job.n_boxes + 63) // 64) * 8 + 4) + 16 for job in jobs)
+        stage = self._pinned(slot + "tables", need)
+        off = 0
         for job in jobs:
-            self._pool(job, feats_spp_all)
-        torch.cuda.current_stream(devc).synchronize()  # one sync: pooled tables of every scene are on the host
+            off = self._pool(job, feats_spp_all, stage, off)
+        stream.synchronize()  # one sync: pooled tables of every scene are on the host
         _mark("B pool")
         for job in jobs:
             self._schedule(job)
@@ -279,18 +325,29 @@ class Pipeline:
             fo += job.counts.n_fits
             io += job.counts.n_fit_idx
             oo += job.counts.n_fit_out
-        res = None
         _mark("C export")
+        pending = None
         if n_fits:
-            res = self.fit_descs(feats_spp_all, descs, n_fits, h_idx, n_out, keep_debug=keep_debug)
-        _mark("D fit")
+            pending = self.fit_launch(feats_spp_all, descs, n_fits, h_idx, n_out, keep_debug=keep_debug, slot=slot)
+        return dict(jobs=jobs, n_fits=n_fits, n_out=n_out, pending=pending, stream=stream, keep_debug=keep_debug,
+                    mark=_mark, feats_spp_all=feats_spp_all, slot=slot)
 
-        # ---- stage E + F
+    def _finish(self, state):
+        """Stages E-F: wait for the fit results, ordered merge on the host, broadcast on the device."""
+        lib, ctx, devc = self.lib, self.ctx, self.device
+        jobs, keep_debug, _mark = state["jobs"], state["keep_debug"], state["mark"]
+        res = self.fit_collect(state["pending"]) if state["pending"] is not None else None
+        _mark("D fit")
+        tot_s = sum(job.n_spps for job in jobs)
+        tables = self._pinned(state["slot"] + "labels", tot_s * 12)
+        d_tables = torch.empty(tot_s * 12, dtype=torch.uint8, device=devc)
+        tab_np = tables.numpy()
+        views, off = [], 0
         for job in jobs:
             S = job.n_spps
-            sem_spp = np.empty(S, np.int32)
-            inst_spp = np.empty(S, np.int32)
-            prob_spp = np.empty(S, np.float32)
+            sem_spp = tab_np[off:off + 4 * S].view(np.int32)
+            inst_spp = tab_np[off + 4 * S:off + 8 * S].view(np.int32)
+            prob_spp = tab_np[off + 8 * S:off + 12 * S].view(np.float32)
             mu_spp = np.empty(S, np.float32)
             var_spp = np.empty(S, np.float32)
             if job.counts.n_fits:
@@ -304,10 +361,15 @@ class Pipeline:
                                           _ptr(mu_spp), _ptr(var_spp))
             if rc != 0:
                 raise _lib.GaproError(rc, "gapro_schedule_merge")
-            n = job.n_points
-            d_sem_spp = torch.from_numpy(sem_spp).to(devc, non_blocking=True)
-            d_inst_spp = torch.from_numpy(inst_spp).to(devc, non_blocking=True)
-            d_prob_spp = torch.from_numpy(prob_spp).to(devc, non_blocking=True)
+            views.append((off, mu_spp, var_spp))
+            job.host.update(sem_spp=sem_spp.copy(), inst_spp=inst_spp.copy(), prob_spp=prob_spp.copy())
+            off += 12 * S
+        d_tables.copy_(tables[:tot_s * 12], non_blocking=True)  # one H2D copy for the whole batch
+        for job, (off, mu_spp, var_spp) in zip(jobs, views):
+            S, n = job.n_spps, job.n_points
+            d_sem_spp = d_tables[off:off + 4 * S].view(torch.int32)
+            d_inst_spp = d_tables[off + 4 * S:off + 8 * S].view(torch.int32)
+            d_prob_spp = d_tables[off + 8 * S:off + 12 * S].view(torch.float32)
             sem = torch.empty(n, dtype=torch.int32, device=devc)
             ins = torch.empty(n, dtype=torch.int32, device=devc)
             prb = torch.empty(n, dtype=torch.float32, device=devc)
@@ -315,17 +377,22 @@ class Pipeline:
                                                  _ptr(d_sem_spp), _ptr(d_inst_spp), _ptr(d_prob_spp), _ptr(sem),
                                                  _ptr(ins), _ptr(prb)))
             job.outputs = (sem, ins, prb, torch.from_numpy(mu_spp).to(devc), torch.from_numpy(var_spp).to(devc))
-            job.host.update(sem_spp=sem_spp, inst_spp=inst_spp, prob_spp=prob_spp)
             if not keep_debug:
                 lib.gapro_schedule_free(job.schedule)
                 job.schedule = None
+        torch.cuda.current_stream(devc).synchronize()  # the pinned label tables are reused by the next batch
         _mark("E+F merge/broadcast")
-        self.last_stats = dict(n_fits=n_fits, n_fit_out=n_out, fit=res)
+        self.last_stats = dict(n_fits=state["n_fits"], n_fit_out=state["n_out"], fit=res)
         return [j.outputs for j in jobs]
 
     # ------------------------------------------------------------------ stage D
     def fit_descs(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
                   init_mean: Optional[np.ndarray] = None, keep_debug: bool = False):
+        """Launch a batch of fits and wait for the results (numpy arrays)."""
+        return self.fit_collect(self.fit_launch(feats_spp, descs, n_fits, h_idx, n_out, init_mean, keep_debug))
+
+    def fit_launch(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
+                   init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, slot: str = "s0"):
         lib, ctx, devc = self.lib, self.ctx, self.device
         D = int(feats_spp.shape[1])
         ws_bytes = int(lib.gapro_fit_plan_workspace(C.cast(descs, C.c_void_p), n_fits, D))
@@ -339,13 +406,16 @@ class Pipeline:
             if init_mean is not None else None
         ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=devc)
         no = max(n_out, 1)
-        probs = torch.empty(no, dtype=torch.float32, device=devc)
-        probs_new = torch.empty(no, dtype=torch.float32, device=devc)
-        labels = torch.empty(no, dtype=torch.uint8, device=devc)
-        mu = torch.empty(no, dtype=torch.float32, device=devc)
-        var = torch.empty(no, dtype=torch.float32, device=devc)
-        status = torch.empty(n_fits, dtype=torch.int32, device=devc)
-        loss = torch.empty(n_fits, dtype=torch.float64, device=devc)
+        # per-test-superpoint outputs in one device block: probs f32 | probs_new f32 | mu f32 | var f32 | labels u8
+        out = torch.empty(no * 17, dtype=torch.uint8, device=devc)
+        probs = out[0:4 * no].view(torch.float32)
+        probs_new = out[4 * no:8 * no].view(torch.float32)
+        mu = out[8 * no:12 * no].view(torch.float32)
+        var = out[12 * no:16 * no].view(torch.float32)
+        labels = out[16 * no:17 * no]
+        stat = torch.empty(n_fits * 12, dtype=torch.uint8, device=devc)  # loss f64[n] | status i32[n]
+        loss = stat[0:8 * n_fits].view(torch.float64)
+        status = stat[8 * n_fits:12 * n_fits].view(torch.int32)
         if self.profile_fit:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(devc))
@@ -357,14 +427,32 @@ class Pipeline:
         if self.profile_fit:
             ev1.record(torch.cuda.current_stream(devc))
             self.fit_events.append((ev0, ev1, fit_flops(descs, n_fits, D, int(self.opt.training_iter))))
-        st = status.cpu().numpy()
+        # results travel to pinned host memory on the same stream; nobody waits here
+        h_out = self._pinned(slot + "fit_out", no * 17)
+        h_stat = self._pinned(slot + "fit_stat", n_fits * 12)
+        h_out[:no * 17].copy_(out, non_blocking=True)
+        h_stat[:n_fits * 12].copy_(stat, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(devc))
+        keep = (d_descs, d_idx, d_init, ws, out, stat, feats_spp)  # alive until the launch has finished
+        return dict(done=done, h_out=h_out, h_stat=h_stat, no=no, n_fits=n_fits, ws_bytes=ws_bytes, keep=keep,
+                    ws=ws if keep_debug else None, descs=descs if keep_debug else None)
+
+    def fit_collect(self, p):
+        p["done"].synchronize()
+        no, n_fits = p["no"], p["n_fits"]
+        raw = p["h_out"].numpy()
+        st_raw = p["h_stat"].numpy()
+        st = st_raw[8 * n_fits:12 * n_fits].view(np.int32).copy()
         if (st != 0).any():
             bad = int(np.nonzero(st)[0][0])
             raise _lib.GaproError(int(st[bad]), "fit %d of %d failed" % (bad, n_fits))
-        res = dict(probs=probs.cpu().numpy(), probs_new=probs_new.cpu().numpy(), labels=labels.cpu().numpy(),
-                   mu=mu.cpu().numpy(), var=var.cpu().numpy(), loss=loss.cpu().numpy(), status=st,
-                   ws_bytes=ws_bytes)
-        if keep_debug:
-            res["workspace"] = ws
-            res["descs"] = descs
+        res = dict(probs=raw[0:4 * no].view(np.float32).copy(), probs_new=raw[4 * no:8 * no].view(np.float32).copy(),
+                   mu=raw[8 * no:12 * no].view(np.float32).copy(), var=raw[12 * no:16 * no].view(np.float32).copy(),
+                   labels=raw[16 * no:17 * no].copy(), loss=st_raw[0:8 * n_fits].view(np.float64).copy(), status=st,
+                   ws_bytes=p["ws_bytes"])
+        if p["ws"] is not None:
+            res["workspace"] = p["ws"]
+            res["descs"] = p["descs"]
+        p["keep"] = None
         return res
