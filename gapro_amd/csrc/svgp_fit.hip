@@ -31,6 +31,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -701,7 +702,7 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
 //   zz: w  = sym(G)[i][j] s E_ij  ->  G_s += sym(G) E,  G_l += w d2,   G_Z[j] += 2 w (Z_j - Z_i)
 //   zx: wx = G_KX[j][n=i] KX_jn   ->  G_s += G_KX E,    G_l += wx d2,  G_Z[j] += wx (Z_j - X_i)
 // (sym(G) o K is symmetric, so the sum over i of column j equals the row sum of the oracle's formula.)
-template <int DMAX>
+template <int DMAX, bool ZX>
 __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const gd* Gm, const gd* GTm,
                                                  const gd* GKXT, double s, double inv_l2, double step_size,
                                                  double bc2s, ldsd* red, double* gs_out, double* gl_out) {
@@ -733,19 +734,21 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
       gl += w * d2;
 #pragma unroll
       for (int d = 0; d < DMAX; ++d) acc[d] += 2.0 * w * t[d];
-      double d2x = 0.0;
+      if (ZX) {
+        double d2x = 0.0;
 #pragma unroll
-      for (int d = 0; d < DMAX; ++d) {
-        t[d] = (d < D) ? zj[d] - Xt[d * Mp + i] : 0.0;
-        d2x += t[d] * t[d];
+        for (int d = 0; d < DMAX; ++d) {
+          t[d] = (d < D) ? zj[d] - Xt[d * Mp + i] : 0.0;
+          d2x += t[d] * t[d];
+        }
+        const double ex = exp(-0.5 * inv_l2 * d2x);
+        const double g = GKXT[o];  // G_KX[j][i]
+        const double wx = g * s * ex;
+        gs += g * ex;
+        gl += wx * d2x;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) acc[d] += wx * t[d];
       }
-      const double ex = exp(-0.5 * inv_l2 * d2x);
-      const double g = GKXT[o];  // G_KX[j][i]
-      const double wx = g * s * ex;
-      gs += g * ex;
-      gl += wx * d2x;
-#pragma unroll
-      for (int d = 0; d < DMAX; ++d) acc[d] += wx * t[d];
     }
   }
   *gs_out = block_sum(gs);
@@ -766,8 +769,9 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
           if (d < D && d < DMAX) {
             double sacc = 0.0;
             for (int g = 0; g < cm.G; ++g) sacc += red[e * NT + g * Mp + threadIdx.x];
-            const double grad = -inv_l2 * sacc;
             const size_t zi = (size_t)threadIdx.x * D + d;
+            if (!ZX) sacc += f.gZ[zi];  // zx part accumulated by the strip loop (raw sums)
+            const double grad = -inv_l2 * sacc;
             f.gZ[zi] = grad;
             const double m1 = b1 * f.mZ[zi] + (1.0 - b1) * grad;
             const double m2 = b2 * f.vZ[zi] + (1.0 - b2) * grad * grad;
@@ -1057,7 +1061,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     stamp(13);
     // kernel gradients + Adam on Z
     double g_s, g_l;
-    kernel_grads_adam_z<DMAX>(Zt, Pt, G, GT, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
+    kernel_grads_adam_z<DMAX, true>(Zt, Pt, G, GT, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
     g_s += gv_sum;
     g_l /= (ell * ell * ell);
     stamp(14);
@@ -1134,18 +1138,12 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   }
 }
 
-__global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int D, const float* __restrict__ feats_spp,
-                                                 const int* __restrict__ idx, const gapro_fit_desc* __restrict__ descs,
-                                                 const double* __restrict__ init_mean, gapro_fit_options opt,
-                                                 double* __restrict__ ws, float* __restrict__ o_probs,
-                                                 float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
-                                                 float* __restrict__ o_mu, float* __restrict__ o_var,
-                                                 int* __restrict__ o_status, double* __restrict__ o_loss) {
+// Common prologue of the fit kernels: workspace pointers, parameter initialisation
+// (gaussian_process_utils.py:386-403 and gpytorch's parameter inits), staging of Z and X into LDS.
+__device__ inline void fit_setup(const gapro_fit_desc& desc, int D, const float* __restrict__ feats_spp,
+                                 const int* __restrict__ idx, const double* __restrict__ init_mean,
+                                 double* __restrict__ ws, ldsd* Zt, ldsd* Pt) {
   Shared& sh = g_sh;
-  extern __shared__ double dyn_lds[];
-  const int fit = blockIdx.x;
-  if (fit >= n_fits) return;
-  const gapro_fit_desc desc = descs[fit];
   Fit& f = sh.f;
   const Layout lay = make_layout(desc.m1 + desc.m2, desc.t, D);
   gd* base = (gd*)(ws + desc.ws_offset);
@@ -1175,11 +1173,6 @@ __global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int 
 #endif
   }
   const int M = desc.m1 + desc.m2, Mp = lay.Mp;
-  ldsd* Zt = (ldsd*)dyn_lds;
-  ldsd* Pt = Zt + D * Mp;
-  ldsd* scratch = Pt + D * Mp;
-
-  // ---- initialisation (gaussian_process_utils.py:386-403; gpytorch parameter inits) ----
   // zero everything the kernel reads before writing: parameters/Adam state, padded operand tails
   for (long long i = threadIdx.x; i < lay.total; i += NT) base[i] = 0.0;
   __syncthreads();
@@ -1204,6 +1197,35 @@ __global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int 
   stage_points_t(Zt, f.Z, M, D, Mp);
   stage_points_t(Pt, f.X, M, D, Mp);
   __syncthreads();
+}
+
+__device__ inline void fit_epilogue(const gapro_fit_desc& desc, const gapro_fit_options& opt, int* o_status,
+                                    double* o_loss) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int st = g_sh.status;
+    if (st == GAPRO_OK && !isfinite(o_loss[desc.slot]) && opt.training_iter > 0) st = GAPRO_ERR_NOT_FINITE;
+    o_status[desc.slot] = st;
+    g_sh.f.scal[S_STATUS] = (double)st;
+  }
+}
+
+__global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int D, const float* __restrict__ feats_spp,
+                                                 const int* __restrict__ idx, const gapro_fit_desc* __restrict__ descs,
+                                                 const double* __restrict__ init_mean, gapro_fit_options opt,
+                                                 double* __restrict__ ws, float* __restrict__ o_probs,
+                                                 float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
+                                                 float* __restrict__ o_mu, float* __restrict__ o_var,
+                                                 int* __restrict__ o_status, double* __restrict__ o_loss) {
+  extern __shared__ double dyn_lds[];
+  const int fit = blockIdx.x;
+  if (fit >= n_fits) return;
+  const gapro_fit_desc desc = descs[fit];
+  const int Mp = round_up(desc.m1 + desc.m2, 32);
+  ldsd* Zt = (ldsd*)dyn_lds;
+  ldsd* Pt = Zt + D * Mp;
+  ldsd* scratch = Pt + D * Mp;
+  fit_setup(desc, D, feats_spp, idx, init_mean, ws, Zt, Pt);
   double* loss_slot = &o_loss[desc.slot];
   if (D <= 8) {
     if (Mp >= 128)
@@ -1216,13 +1238,545 @@ __global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int 
     else
       fit_body<1, 32>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int st = sh.status;
-    if (st == GAPRO_OK && !isfinite(*loss_slot) && opt.training_iter > 0) st = GAPRO_ERR_NOT_FINITE;
-    o_status[desc.slot] = st;
-    f.scal[S_STATUS] = (double)st;
+  fit_epilogue(desc, opt, o_status, o_loss);
+}
+
+// =====================================================================================================
+// Strip-streaming variant (M_p <= 128): the data-dependent intermediates never touch global memory.
+//
+// Everything between the triangular factors and the gradients is column-wise in the data index n:
+//   KX[:,n] -> A[:,n] = LI KX[:,n] -> B[:,n] = LS^T A[:,n] -> mu_n, var_n -> g_mu_n, g_v_n
+//   -> G_A[:,n] = m g_mu_n + LS (2 g_v_n B[:,n]) - 2 g_v_n A[:,n] -> G_KX[:,n] = LI^T G_A[:,n]
+// and the only couplings across n are sums:  G_LS += A[:,n] (2 g_v_n B[:,n])^T,  G_L -= G_KX[:,n] A[:,n]^T,
+// G_m += A[:,n] g_mu_n, and the kernel-gradient sums.  So the training points are streamed in strips of
+// SW = 32 columns held in three LDS buffers (row stride RS = 34: conflict-free for both MFMA operand
+// patterns), the two M x M gradient matrices are accumulated as MFMA tiles that stay in registers for
+// the whole step (each wave owns up to five 16x16 lower tiles of each), and KX, A, A^T, B, B^T, G_A, G_KX^T
+// -- 9 matrix writes and ~13 matrix reads per step in the staged kernel -- disappear from HBM traffic.
+// What still streams from L2/HBM per strip are the fixed operands U, LS, LS^T, LI (triangular halves).
+// =====================================================================================================
+constexpr int SW = 32;  // strip width (data columns)
+constexpr int RS = 34;  // LDS row stride of a strip buffer (doubles)
+constexpr int kStripMaxMp = 128;
+constexpr int kAccTiles = 5;  // lower 16x16 tiles of an 8x8-block matrix: 36 over 8 waves
+
+inline __host__ __device__ int strip_region_doubles(int Mp) {
+  const int a = 3 * Mp * RS, b = scratch_doubles(Mp);
+  return a > b ? a : b;
+}
+inline __host__ __device__ long long strip_lds_bytes(int m, int d) {
+  const int Mp = round_up(m > 0 ? m : 1, 32);
+  return 8LL * (2LL * d * Mp + strip_region_doubles(Mp) + 3 * NT + Mp + 4 * SW + 32);
+}
+inline __host__ __device__ bool strip_ok(int m, int d) {
+  return round_up(m > 0 ? m : 1, 32) <= kStripMaxMp && d <= 32 && strip_lds_bytes(m, d) <= kMaxDynLds;
+}
+
+enum { K_LE = 0, K_GE = 1 };
+// One strip product: out[16 rb .. ][16 ct ..] = sum_k P[k][16 rb + i] * Sin[k][16 ct + n], k restricted to
+// k < 16 (rb+1) (K_LE: P upper-triangular in (k,i)) or k >= 16 rb (K_GE).  2 nbk tiles over 8 waves, dealt
+// so that a wave's two tiles have complementary k-ranges.  A operand from global (TN rows), B from LDS.
+template <int MODE, typename Epi>
+__device__ inline void strip_gemm(const gd* __restrict__ P, int Mp, const ldsd* Sin, int nbk, int wave, int lr, int lq,
+                                  Epi epi) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = wave + NW * q;
+    if (t < 2 * nbk) {
+      const int rb = t < nbk ? t : 2 * nbk - 1 - t, ct = t < nbk ? 0 : 1;
+      const int klo = MODE == K_LE ? 0 : 16 * rb, khi = MODE == K_LE ? 16 * (rb + 1) : Mp;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      const gd* pa = P + (size_t)(klo + lq) * Mp + 16 * rb + lr;
+      const ldsd* pb = Sin + (klo + lq) * RS + 16 * ct + lr;
+#pragma unroll 4
+      for (int k = klo; k < khi; k += 4) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
+        pa += (size_t)4 * Mp;
+        pb += 4 * RS;
+      }
+      epi(rb, ct, acc);
+    }
   }
+}
+
+__device__ inline void lower_tile(int t, int* ti, int* tj) {
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  *ti = i;
+  *tj = t - i * (i + 1) / 2;
+}
+
+template <int DMAX>
+__device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* region,
+                               const gapro_fit_desc& desc, float* __restrict__ o_probs,
+                               float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
+                               float* __restrict__ o_mu, float* __restrict__ o_var, double* loss_out) {
+  const Fit& f = g_sh.f;
+  Shared& sh = g_sh;
+  const int M = f.M, Mp = f.Mp, D = f.D, T = f.T;
+  const int nbk = Mp / 16, nt_acc = nbk * (nbk + 1) / 2;
+  const double Nd = (double)M;
+  const double jitter = opt.jitter;
+  ldsd* As = region;
+  ldsd* Bs = As + Mp * RS;
+  ldsd* Cs = Bs + Mp * RS;
+  ldsd* scratch = region;  // outside the strip loop the same memory serves Cholesky, tiles and reductions
+  ldsd* sred = region + strip_region_doubles(Mp);  // 3 * NT
+  ldsd* m_s = sred + 3 * NT;                       // Mp
+  ldsd* mu_s = m_s + Mp;                           // SW each
+  ldsd* var_s = mu_s + SW;
+  ldsd* gmu_s = var_s + SW;
+  ldsd* gv_s = gmu_s + SW;
+  gd* LS = f.mat[B_LS];
+  gd* LST = f.mat[B_LST];
+  gd* MLS = f.mat[B_MLS];
+  gd* VLS = f.mat[B_VLS];
+  gd* GLb = f.mat[B_BM];    // G_L (lower) for the tail products
+  gd* Pm = f.mat[B_GA];
+  gd* T1T = f.mat[B_BMT];
+  gd* Gb = f.mat[B_A];
+  gd* GTb = f.mat[B_AT];
+  gd* vm = f.vec[V_M];
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  ldsd* tile = scratch + wave * 16 * 17;
+  double last_loss = 0.0;
+#ifdef GAPRO_PROFILE
+  auto stamp = [&](int id) { prof_stamp(id); };
+#else
+  auto stamp = [&](int) {};
+#endif
+  auto refresh_hypers = [&]() {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      sh.s = softplus(sh.rho_s);
+      sh.ell = softplus(sh.rho_l);
+      sh.inv_l2 = 1.0 / (sh.ell * sh.ell);
+    }
+    __syncthreads();
+  };
+  auto factorize = [&]() {
+    stamp(19);
+    cholesky_fused(Zt, scratch, sh.s, sh.inv_l2, jitter);
+    stamp(1);
+    tri_inverse<8>(scratch);
+    __syncthreads();
+    stamp(2);
+  };
+  // forward part of one strip: Cs = KX(:, n0..), As = LI Cs, Bs = LS^T As, mu_s / var_s for the strip columns
+  auto strip_forward = [&](const ldsd* Xpts, int n0, int nc, double s, double inv_l2) {
+    for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
+      const int k = idx / SW, n = idx - k * SW;
+      double v = 0.0;
+      if (k < M && n < nc) v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Xpts, n0 + n, D, Mp));
+      Cs[k * RS + n] = v;
+    }
+    __syncthreads();
+    strip_gemm<K_LE>(f.mat[B_U], Mp, Cs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) As[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
+    });
+    __syncthreads();
+    strip_gemm<K_GE>(LS, Mp, As, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Bs[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
+    });
+    __syncthreads();
+    {
+      const int n = threadIdx.x % SW, p = threadIdx.x / SW;  // NT / SW = 16 row groups
+      double pm = 0.0, pv = 0.0;
+      for (int i = p; i < Mp; i += NT / SW) {
+        const double a = As[i * RS + n], b = Bs[i * RS + n];
+        pm += m_s[i] * a;
+        pv += b * b - a * a;
+      }
+      sred[threadIdx.x] = pm;
+      sred[NT + threadIdx.x] = pv;
+      __syncthreads();
+      if (threadIdx.x < SW) {
+        double sm = 0.0, sv = 0.0;
+        for (int g = 0; g < NT / SW; ++g) {
+          sm += sred[g * SW + threadIdx.x];
+          sv += sred[NT + g * SW + threadIdx.x];
+        }
+        mu_s[threadIdx.x] = sm;
+        var_s[threadIdx.x] = s + jitter + sv;
+      }
+      __syncthreads();
+    }
+  };
+
+  for (int step = 1; step <= opt.training_iter; ++step) {
+    refresh_hypers();
+    const double s = sh.s, ell = sh.ell, inv_l2 = sh.inv_l2, c = sh.c;
+    const bool last = step == opt.training_iter;
+    factorize();
+    for (int i = threadIdx.x; i < Mp; i += NT) m_s[i] = vm[i];
+    d4 gls[kAccTiles], gl[kAccTiles];
+#pragma unroll
+    for (int q = 0; q < kAccTiles; ++q) {
+      gls[q] = (d4){0.0, 0.0, 0.0, 0.0};
+      gl[q] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    double gm_acc = 0.0, e_tot = 0.0, gc_part = 0.0, gvs_part = 0.0, gs_zx = 0.0, gl_zx = 0.0;
+    double acc_zx[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) acc_zx[d] = 0.0;
+    __syncthreads();
+    stamp(3);
+
+    for (int n0 = 0; n0 < M; n0 += SW) {
+      const int nc = (M - n0) < SW ? (M - n0) : SW;
+      strip_forward(Pt, n0, nc, s, inv_l2);
+      // ---- likelihood gradients of the strip columns (ten threads per column)
+      {
+        const int q = threadIdx.x % 10, nl = threadIdx.x / 10;
+        double E = 0.0, dmu = 0.0, dvar = 0.0;
+        const bool on = nl < nc;
+        if (on) {
+          const double mu = mu_s[nl] + c;
+          const double vraw = var_s[nl];
+          const double var = vraw < opt.min_variance ? opt.min_variance : vraw;
+          const double sd = sqrt(2.0 * var);
+          const double y = f.vec[V_Y][n0 + nl];
+          const double t = c_gh_t[q], w = c_gh_w[q];
+          double lp, r;
+          log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
+          E += w * lp; dmu += w * r; dvar -= w * t * r;
+          log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
+          E += w * lp; dmu += w * r; dvar += w * t * r;
+        }
+        sred[threadIdx.x] = E;
+        sred[NT + threadIdx.x] = dmu;
+        sred[2 * NT + threadIdx.x] = dvar;
+        __syncthreads();
+        if (on && q == 0) {
+          double se = 0.0, sm = 0.0, sv = 0.0;
+          for (int qq = 0; qq < 10; ++qq) {
+            se += sred[threadIdx.x + qq];
+            sm += sred[NT + threadIdx.x + qq];
+            sv += sred[2 * NT + threadIdx.x + qq];
+          }
+          const double ipi = 0.56418958354775628695;  // 1/sqrt(pi)
+          const double vraw = var_s[nl];
+          const bool clamped = vraw < opt.min_variance;
+          const double var = clamped ? opt.min_variance : vraw;
+          const double y = f.vec[V_Y][n0 + nl];
+          const double g1 = -(ipi * sm * y) / Nd;
+          const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
+          gmu_s[nl] = g1;
+          gv_s[nl] = g2;
+          e_tot += ipi * se;
+          gc_part += g1;
+          gvs_part += g2;
+        }
+        if (threadIdx.x >= nc && threadIdx.x < SW) {
+          gmu_s[threadIdx.x] = 0.0;
+          gv_s[threadIdx.x] = 0.0;
+        }
+        __syncthreads();
+      }
+      // ---- GB = 2 B diag(g_v), in place
+      for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
+        const int j = idx / SW, n = idx - j * SW;
+        Bs[j * RS + n] *= 2.0 * gv_s[n];
+      }
+      __syncthreads();
+      // ---- G_LS += A GB^T (register tiles), G_m += A g_mu
+#pragma unroll
+      for (int q = 0; q < kAccTiles; ++q) {
+        const int t = wave + NW * q;
+        if (t < nt_acc) {
+          int ti, tj;
+          lower_tile(t, &ti, &tj);
+          const ldsd* pa = As + (16 * ti + lr) * RS + lq;
+          const ldsd* pb = Bs + (16 * tj + lr) * RS + lq;
+#pragma unroll
+          for (int ks = 0; ks < SW / 4; ++ks)
+            gls[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], gls[q], 0, 0, 0);
+        }
+      }
+      if (threadIdx.x < Mp) {
+        const ldsd* pa = As + threadIdx.x * RS;
+        for (int n = 0; n < SW; ++n) gm_acc += pa[n] * gmu_s[n];
+      }
+      // ---- G_A strip -> Cs:  m g_mu^T + LS GB - 2 A diag(g_v)     (LS[i][j] = LST[j][i], j <= i)
+      strip_gemm<K_LE>(LST, Mp, Bs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
+        const int n = 16 * ct + lr;
+        const double gvn = gv_s[n], gmn = gmu_s[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * rb + lq + 4 * r;
+          Cs[i * RS + n] = v[r] + m_s[i] * gmn - 2.0 * As[i * RS + n] * gvn;
+        }
+      });
+      __syncthreads();
+      // ---- G_KX strip -> Bs:  LI^T G_A   (P = LI[k][i], k >= i)
+      strip_gemm<K_GE>(f.mat[B_LI], Mp, Cs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bs[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
+      });
+      __syncthreads();
+      // ---- G_L -= G_KX A^T (register tiles)
+#pragma unroll
+      for (int q = 0; q < kAccTiles; ++q) {
+        const int t = wave + NW * q;
+        if (t < nt_acc) {
+          int ti, tj;
+          lower_tile(t, &ti, &tj);
+          const ldsd* pa = Bs + (16 * ti + lr) * RS + lq;
+          const ldsd* pb = As + (16 * tj + lr) * RS + lq;
+#pragma unroll
+          for (int ks = 0; ks < SW / 4; ++ks)
+            gl[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], gl[q], 0, 0, 0);
+        }
+      }
+      // ---- zx kernel gradients: wx = G_KX[k][n] KX[k][n]; thread (k, part) walks the strip columns
+      {
+        const int G = NT / Mp, k = threadIdx.x % Mp, p = threadIdx.x / Mp;
+        if (p < G && k < M) {
+          for (int n = p; n < nc; n += G) {
+            double t[DMAX];
+            double d2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+              t[d] = (d < D) ? Zt[d * Mp + k] - Pt[d * Mp + n0 + n] : 0.0;
+              d2 += t[d] * t[d];
+            }
+            const double ex = exp(-0.5 * inv_l2 * d2);
+            const double g = Bs[k * RS + n];
+            const double wx = g * s * ex;
+            gs_zx += g * ex;
+            gl_zx += wx * d2;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) acc_zx[d] += wx * t[d];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    stamp(4);
+
+    // ---- after the strips: scalars, G_m, ELBO value (last step only)
+    const double g_c = block_sum(gc_part);
+    const double gv_sum = block_sum(gvs_part);
+    if (threadIdx.x < Mp) f.vec[V_GM][threadIdx.x] = gm_acc;
+    if (last) {
+      const double e_sum = block_sum(e_tot);
+      double kl_part = 0.0;
+      for (int idx = threadIdx.x; idx < M * M; idx += NT) {
+        const int i = idx / M, j = idx - i * M;
+        if (j <= i) {
+          const double v = LS[(size_t)i * Mp + j];
+          kl_part += v * v;
+          if (i == j) kl_part -= log(v * v);
+        }
+      }
+      for (int i = threadIdx.x; i < M; i += NT) kl_part += vm[i] * vm[i];
+      const double kl = 0.5 * (block_sum(kl_part) - Nd);
+      last_loss = -(e_sum / Nd - kl / Nd);
+    }
+    // zx sums of the row groups -> gZ (raw), combined with the zz part in kernel_grads_adam_z
+    {
+      const int G = NT / Mp;
+#pragma unroll
+      for (int dc = 0; dc < DMAX; dc += kRedSlots) {
+        if (dc < D) {
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < kRedSlots; ++e)
+            if (dc + e < DMAX) scratch[e * NT + threadIdx.x] = acc_zx[dc + e];
+          __syncthreads();
+          if (threadIdx.x < M) {
+#pragma unroll
+            for (int e = 0; e < kRedSlots; ++e) {
+              const int d = dc + e;
+              if (d < D && d < DMAX) {
+                double sacc = 0.0;
+                for (int g = 0; g < G; ++g) sacc += scratch[e * NT + g * Mp + threadIdx.x];
+                f.gZ[(size_t)threadIdx.x * D + d] = sacc;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const double gs_zx_tot = block_sum(gs_zx);
+    const double gl_zx_tot = block_sum(gl_zx);
+    stamp(6);
+
+    // ---- Adam on LS straight from the register tiles;  G_L tiles -> global for the tail products
+    const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
+    const double step_size = opt.lr / bc1;
+#pragma unroll
+    for (int q = 0; q < kAccTiles; ++q) {
+      const int t = wave + NW * q;
+      if (t < nt_acc) {
+        int ti, tj;
+        lower_tile(t, &ti, &tj);
+        const int j = 16 * tj + lr;
+        d4 newv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + lq + 4 * r;
+          const size_t o = (size_t)i * Mp + j;
+          double lnew = 0.0;
+          if (j <= i && i < M) {
+            const double l = LS[o];
+            const double g = gls[q][r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+            const double m1 = b1 * MLS[o] + (1.0 - b1) * g;
+            const double m2 = b2 * VLS[o] + (1.0 - b2) * g * g;
+            MLS[o] = m1;
+            VLS[o] = m2;
+            lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+            LS[o] = lnew;
+          }
+          newv[r] = lnew;
+          GLb[o] = (j <= i) ? gl[q][r] : 0.0;
+        }
+        store_tile(newv, nullptr, LST, Mp, 16 * ti, 16 * tj, tile);
+      }
+    }
+    __syncthreads();
+    stamp(8);
+
+    // ---- tail: G_Kzz = LI^T Phi(L^T G_L) LI through global memory (three TN products)
+    auto tail = [&](auto tu_tag) {
+      constexpr int TU = decltype(tu_tag)::value;
+      constexpr int TS = 16 * TU;
+      const int mt = Mp / TS;
+      gemm_tn<TU, false>(mt, mt, true, f.mat[B_L], GLb, Mp, nullptr,
+                         [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                         [=](int i0, int j0, const d4& v) {
+                           const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
+#pragma unroll
+                           for (int r = 0; r < 4; ++r) {
+                             const int i = i0 + g4 + 4 * r, j = j0 + c;
+                             Pm[(size_t)i * Mp + j] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                           }
+                         });
+      __syncthreads();
+      gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+                         [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
+                         [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
+      __syncthreads();
+      gemm_tn<TU, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+                         [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                         [=](int i, int j, const d4& v) { store_tile(v, Gb, GTb, Mp, i, j, tile); });
+      __syncthreads();
+    };
+    if (Mp >= 128)
+      tail(std::integral_constant<int, 2>());
+    else
+      tail(std::integral_constant<int, 1>());
+    stamp(13);
+    double g_s, g_l;
+    kernel_grads_adam_z<DMAX, false>(Zt, Pt, Gb, GTb, nullptr, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
+    g_s += gs_zx_tot + gv_sum;
+    g_l = (g_l + gl_zx_tot) / (ell * ell * ell);
+    stamp(14);
+
+    auto adam_upd = [&](double p, double& m1, double& m2, double g) {
+      m1 = b1 * m1 + (1.0 - b1) * g;
+      m2 = b2 * m2 + (1.0 - b2) * g * g;
+      return p - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+    };
+    for (int i = threadIdx.x; i < M; i += NT) {
+      const double g = f.vec[V_GM][i] + vm[i] / Nd;
+      f.vec[V_GM][i] = g;
+      double m1 = f.vec[V_MM][i], m2 = f.vec[V_VM][i];
+      vm[i] = adam_upd(vm[i], m1, m2, g);
+      f.vec[V_MM][i] = m1;
+      f.vec[V_VM][i] = m2;
+    }
+    if (threadIdx.x == 0) {
+      double m1, m2;
+      m1 = f.scal[S_MC]; m2 = f.scal[S_VC];
+      sh.c = adam_upd(sh.c, m1, m2, g_c);
+      f.scal[S_MC] = m1; f.scal[S_VC] = m2;
+      m1 = f.scal[S_MRS]; m2 = f.scal[S_VRS];
+      sh.rho_s = adam_upd(sh.rho_s, m1, m2, g_s * sigmoid(sh.rho_s));
+      f.scal[S_MRS] = m1; f.scal[S_VRS] = m2;
+      m1 = f.scal[S_MRL]; m2 = f.scal[S_VRL];
+      sh.rho_l = adam_upd(sh.rho_l, m1, m2, g_l * sigmoid(sh.rho_l));
+      f.scal[S_MRL] = m1; f.scal[S_VRL] = m2;
+    }
+    __syncthreads();
+    stamp(16);
+  }
+
+  // ------------------------------- prediction ------------------------------
+  refresh_hypers();
+  if (!(opt.eval_stale_chol && opt.training_iter > 0)) factorize();
+  const double s = sh.s, inv_l2 = sh.inv_l2, c = sh.c;
+  for (int i = threadIdx.x; i < Mp; i += NT) m_s[i] = vm[i];
+  for (int t0 = 0; t0 < T; t0 += Mp) {
+    const int ncx = (T - t0) < Mp ? (T - t0) : Mp;
+    __syncthreads();
+    stage_points_t(Pt, f.Xt + (size_t)t0 * D, ncx, D, Mp);
+    __syncthreads();
+    for (int n0 = 0; n0 < ncx; n0 += SW) {
+      const int nc = (ncx - n0) < SW ? (ncx - n0) : SW;
+      strip_forward(Pt, n0, nc, s, inv_l2);
+      if ((int)threadIdx.x < nc) {
+        const int n = threadIdx.x;
+        const double mu = mu_s[n] + c;
+        const double var = fmax(var_s[n], opt.min_variance);
+        const double p = 0.5 * erfc(-(mu / sqrt(1.0 + var)) * 0.70710678118654752440);
+        const float pf = (float)p;                       // pred_probs            :432
+        const bool lab = pf >= 0.5f;                     // pred_labels           :433
+        const long long o = desc.out_offset + t0 + n0 + n;
+        o_probs[o] = pf;
+        o_probs_new[o] = lab ? pf : 1.0f - pf;           // pred_probs_new        :438
+        o_labels[o] = lab ? 1 : 0;
+        o_mu[o] = (float)mu;                             // pred_mu               :435
+        o_var[o] = (float)var;                           // pred_variance         :436
+        if (!isfinite(mu) || !isfinite(var)) sh.status = GAPRO_ERR_NOT_FINITE;
+      }
+      __syncthreads();
+    }
+  }
+  stamp(17);
+#ifdef GAPRO_PROFILE
+  if (threadIdx.x == 0)
+    for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+#endif
+  if (threadIdx.x == 0) {
+    f.scal[S_C] = sh.c;
+    f.scal[S_RS] = sh.rho_s;
+    f.scal[S_RL] = sh.rho_l;
+    f.scal[S_LOSS] = last_loss;
+    *loss_out = last_loss;
+  }
+}
+
+// one workgroup per CU: the register-resident gradient tiles need the full 256-VGPR budget
+__global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, const float* __restrict__ feats_spp,
+                                                        const int* __restrict__ idx,
+                                                        const gapro_fit_desc* __restrict__ descs,
+                                                        const double* __restrict__ init_mean, gapro_fit_options opt,
+                                                        double* __restrict__ ws, float* __restrict__ o_probs,
+                                                        float* __restrict__ o_probs_new,
+                                                        unsigned char* __restrict__ o_labels, float* __restrict__ o_mu,
+                                                        float* __restrict__ o_var, int* __restrict__ o_status,
+                                                        double* __restrict__ o_loss) {
+  extern __shared__ double dyn_lds[];
+  const int fit = blockIdx.x;
+  if (fit >= n_fits) return;
+  const gapro_fit_desc desc = descs[fit];
+  const int Mp = round_up(desc.m1 + desc.m2, 32);
+  ldsd* Zt = (ldsd*)dyn_lds;
+  ldsd* Pt = Zt + D * Mp;
+  ldsd* region = Pt + D * Mp;
+  fit_setup(desc, D, feats_spp, idx, init_mean, ws, Zt, Pt);
+  double* loss_slot = &o_loss[desc.slot];
+  if (D <= 8)
+    fit_body_strip<8>(opt, Zt, Pt, region, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+  else
+    fit_body_strip<32>(opt, Zt, Pt, region, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+  fit_epilogue(desc, opt, o_status, o_loss);
 }
 
 // ---- MFMA layout self-test (debug entry, used by tests/test_fit_gpu.py) ------------------------------
@@ -1279,9 +1833,11 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // Launch order = longest processing time first (cost ~ M^3): workgroups are dispatched in block
   // order, so the expensive fits start first and the tail of the launch stays short.  Fits whose
   // working set does not fit the LDS-staged kernel go to the generic kernel.
-  std::vector<gapro_fit_desc> staged, large;
+  std::vector<gapro_fit_desc> staged, large, strip;
   staged.reserve(n_fits);
-  long long need = 0, max_lds = 0;
+  strip.reserve(n_fits);
+  long long need = 0, max_lds = 0, max_lds_strip = 0;
+  const bool use_strip = opt->reserved != 1;  // reserved == 1: force the staged kernel (tests, A/B runs)
   for (int i = 0; i < n_fits; ++i) {
     gapro_fit_desc d = h_descs[i];
     const int m = d.m1 + d.m2;
@@ -1289,7 +1845,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: fit %d has an empty side", i);
     d.slot = i;
     need = std::max<long long>(need, (d.ws_offset + gapro_fit_workspace_doubles(m, d.t, feat_dim)) * 8LL);
-    if (staged_ok(m, feat_dim)) {
+    if (use_strip && strip_ok(m, feat_dim)) {
+      strip.push_back(d);
+      max_lds_strip = std::max(max_lds_strip, strip_lds_bytes(m, feat_dim));
+    } else if (staged_ok(m, feat_dim)) {
       staged.push_back(d);
       max_lds = std::max(max_lds, staged_lds_bytes(m, feat_dim));
     } else {
@@ -1302,8 +1861,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   auto by_cost = [](const gapro_fit_desc& a, const gapro_fit_desc& b) { return a.m1 + a.m2 > b.m1 + b.m2; };
   std::stable_sort(staged.begin(), staged.end(), by_cost);
   std::stable_sort(large.begin(), large.end(), by_cost);
+  std::stable_sort(strip.begin(), strip.end(), by_cost);
   std::vector<gapro_fit_desc> all(large);
   all.insert(all.end(), staged.begin(), staged.end());
+  all.insert(all.end(), strip.begin(), strip.end());
   GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_descs, all.data(), all.size() * sizeof(gapro_fit_desc), hipMemcpyHostToDevice,
                                       stream));
   GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));  // `all` is pageable host memory that dies with this call
@@ -1317,6 +1878,15 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     hipLaunchKernelGGL(k_svgp_fit, dim3((int)staged.size()), dim3(NT), (size_t)max_lds, stream, (int)staged.size(),
                        (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size(), d_init_mean, *opt, d_workspace,
                        d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+  }
+  if (!strip.empty()) {
+    if (max_lds_strip > 48 * 1024)
+      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_svgp_fit_strip,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_strip));
+    hipLaunchKernelGGL(k_svgp_fit_strip, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, stream,
+                       (int)strip.size(), (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size() + staged.size(),
+                       d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status,
+                       d_fit_loss);
   }
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;

@@ -138,3 +138,25 @@ def test_fit_rejects_empty_side():
 
     with pytest.raises(ValueError):
         fit_gp_spp_batch(np.zeros((4, 6), np.float32), [(np.array([], np.int64), np.array([1]), np.array([2]))])
+
+
+def test_strip_and_staged_kernels_agree():
+    """M_p <= 128 runs the strip-streaming kernel by default; the LDS-staged kernel (forced) must give the
+    same answers up to float64 summation order."""
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    feats_list, probs = [], []
+    base = 0
+    for i, (m1, m2, t) in enumerate([(5, 9, 3), (33, 20, 17), (64, 64, 70), (50, 40, 1), (20, 90, 200)]):
+        f, b1, b2, it = make_gp_problem(300 + i, m1, m2, t, 6)
+        feats_list.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(feats_list)
+    a = fit_gp_spp_batch(feats, probs, training_iter=50)
+    b = fit_gp_spp_batch(feats, probs, training_iter=50, force_staged=True)
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x[4], y[4], rtol=1e-6)
+        np.testing.assert_allclose(x[3], y[3], rtol=1e-5, atol=1e-7)
+        np.testing.assert_array_equal(x[2], y[2])
