@@ -445,9 +445,16 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
       }
       const gd* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
       const gd* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
-#pragma unroll 4
-      for (int q = 0; q < 16 * kb; q += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[(size_t)q * Mp], pb[(size_t)q * Mp], acc, 0, 0, 0);
+#pragma nounroll
+      for (int q = 0; q < 16 * kb; q += 16) {  // blocks of four k-steps: eight loads in flight, then four MFMAs
+        const size_t o = (size_t)q * Mp, st = (size_t)4 * Mp;
+        const double a0 = pa[o], a1 = pa[o + st], a2 = pa[o + 2 * st], a3 = pa[o + 3 * st];
+        const double b0 = pb[o], b1 = pb[o + st], b2 = pb[o + 2 * st], b3 = pb[o + 3 * st];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc, 0, 0, 0);
+      }
       ldsd* dst = panel + (16 * (ib - kb)) * 17;
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
@@ -1288,11 +1295,26 @@ __device__ inline void strip_gemm(const gd* __restrict__ P, int Mp, const ldsd* 
       d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
       const gd* pa = P + (size_t)(klo + lq) * Mp + 16 * rb + lr;
       const ldsd* pb = Sin + (klo + lq) * RS + 16 * ct + lr;
-#pragma unroll 4
-      for (int k = klo; k < khi; k += 4) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
-        pa += (size_t)4 * Mp;
-        pb += 4 * RS;
+      const size_t sa = (size_t)4 * Mp;
+      // blocks of four k-steps; the global operands of the next block are in flight during the MFMAs
+      double c0 = pa[0], c1 = pa[sa], c2 = pa[2 * sa], c3 = pa[3 * sa];
+#pragma nounroll
+      for (int k = klo; k < khi; k += 16) {
+        pa += 4 * sa;
+        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+        if (k + 16 < khi) {
+          n0 = pa[0];
+          n1 = pa[sa];
+          n2 = pa[2 * sa];
+          n3 = pa[3 * sa];
+        }
+        const double b0 = pb[0], b1 = pb[4 * RS], b2 = pb[8 * RS], b3 = pb[12 * RS];
+        pb += 16 * RS;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c3, b3, acc, 0, 0, 0);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
       }
       epi(rb, ct, acc);
     }
@@ -1753,6 +1775,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
 }
 
 // one workgroup per CU: the register-resident gradient tiles need the full 256-VGPR budget
+template <int DMAX>
 __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, const float* __restrict__ feats_spp,
                                                         const int* __restrict__ idx,
                                                         const gapro_fit_desc* __restrict__ descs,
@@ -1772,10 +1795,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, con
   ldsd* region = Pt + D * Mp;
   fit_setup(desc, D, feats_spp, idx, init_mean, ws, Zt, Pt);
   double* loss_slot = &o_loss[desc.slot];
-  if (D <= 8)
-    fit_body_strip<8>(opt, Zt, Pt, region, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
-  else
-    fit_body_strip<32>(opt, Zt, Pt, region, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+  fit_body_strip<DMAX>(opt, Zt, Pt, region, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
   fit_epilogue(desc, opt, o_status, o_loss);
 }
 
@@ -1880,13 +1900,13 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                        d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   }
   if (!strip.empty()) {
+    auto kern = feat_dim <= 8 ? k_svgp_fit_strip<8> : k_svgp_fit_strip<32>;
     if (max_lds_strip > 48 * 1024)
-      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_svgp_fit_strip,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds_strip));
-    hipLaunchKernelGGL(k_svgp_fit_strip, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, stream,
-                       (int)strip.size(), (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size() + staged.size(),
-                       d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status,
-                       d_fit_loss);
+      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)max_lds_strip));
+    hipLaunchKernelGGL(kern, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, stream, (int)strip.size(),
+                       (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size() + staged.size(), d_init_mean, *opt,
+                       d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   }
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
