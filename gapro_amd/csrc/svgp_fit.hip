@@ -1328,6 +1328,104 @@ __device__ inline void lower_tile(int t, int* ti, int* tj) {
   *tj = t - i * (i + 1) / 2;
 }
 
+// The register-hungry, MFMA-free parts of a strip are separate functions: values that live across a call
+// (the gradient tiles) are kept in callee-saved VGPRs instead of being spilled around inlined libm code.
+__device__ __noinline__ void strip_fill_kx(ldsd* Cs, const ldsd* Zt, const ldsd* Xpts, int n0, int nc, double s,
+                                           double inv_l2) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, M = f.M, D = f.D;
+  for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
+    const int k = idx / SW, n = idx - k * SW;
+    double v = 0.0;
+    if (k < M && n < nc) v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Xpts, n0 + n, D, Mp));
+    Cs[k * RS + n] = v;
+  }
+  __syncthreads();
+}
+
+// mu_s[n] = sum_i m[i] As[i][n],  var_s[n] = s + jitter + sum_i (Bs[i][n]^2 - As[i][n]^2) for the SW strip columns
+__device__ __noinline__ void strip_mean_var(const ldsd* As, const ldsd* Bs, const ldsd* m_s, ldsd* sred, ldsd* mu_s,
+                                            ldsd* var_s, double s, double jitter) {
+  const int Mp = g_sh.f.Mp;
+  const int n = threadIdx.x % SW, p = threadIdx.x / SW;  // NT / SW row groups
+  double pm = 0.0, pv = 0.0;
+  for (int i = p; i < Mp; i += NT / SW) {
+    const double a = As[i * RS + n], b = Bs[i * RS + n];
+    pm += m_s[i] * a;
+    pv += b * b - a * a;
+  }
+  sred[threadIdx.x] = pm;
+  sred[NT + threadIdx.x] = pv;
+  __syncthreads();
+  if (threadIdx.x < SW) {
+    double sm = 0.0, sv = 0.0;
+    for (int g = 0; g < NT / SW; ++g) {
+      sm += sred[g * SW + threadIdx.x];
+      sv += sred[NT + g * SW + threadIdx.x];
+    }
+    mu_s[threadIdx.x] = sm;
+    var_s[threadIdx.x] = s + jitter + sv;
+  }
+  __syncthreads();
+}
+
+// Likelihood gradients of the strip columns (ten threads per column, one per symmetric Gauss-Hermite pair):
+// gmu_s / gv_s for the strip, and this thread's contributions to sum E, sum g_mu, sum g_v in out3[0..2].
+__device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_s, ldsd* gmu_s, ldsd* gv_s, ldsd* sred,
+                                              int n0, int nc, double c, double min_variance, double Nd,
+                                              double* out3) {
+  const Fit& f = g_sh.f;
+  const int q = threadIdx.x % 10, nl = threadIdx.x / 10;
+  double E = 0.0, dmu = 0.0, dvar = 0.0;
+  const bool on = nl < nc;
+  if (on) {
+    const double mu = mu_s[nl] + c;
+    const double vraw = var_s[nl];
+    const double var = vraw < min_variance ? min_variance : vraw;
+    const double sd = sqrt(2.0 * var);
+    const double y = f.vec[V_Y][n0 + nl];
+    const double t = c_gh_t[q], w = c_gh_w[q];
+    double lp, r;
+    log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
+    E += w * lp; dmu += w * r; dvar -= w * t * r;
+    log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
+    E += w * lp; dmu += w * r; dvar += w * t * r;
+  }
+  sred[threadIdx.x] = E;
+  sred[NT + threadIdx.x] = dmu;
+  sred[2 * NT + threadIdx.x] = dvar;
+  __syncthreads();
+  double e_add = 0.0, gc_add = 0.0, gv_add = 0.0;
+  if (on && q == 0) {
+    double se = 0.0, sm = 0.0, sv = 0.0;
+    for (int qq = 0; qq < 10; ++qq) {
+      se += sred[threadIdx.x + qq];
+      sm += sred[NT + threadIdx.x + qq];
+      sv += sred[2 * NT + threadIdx.x + qq];
+    }
+    const double ipi = 0.56418958354775628695;  // 1/sqrt(pi)
+    const double vraw = var_s[nl];
+    const bool clamped = vraw < min_variance;
+    const double var = clamped ? min_variance : vraw;
+    const double y = f.vec[V_Y][n0 + nl];
+    const double g1 = -(ipi * sm * y) / Nd;
+    const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
+    gmu_s[nl] = g1;
+    gv_s[nl] = g2;
+    e_add = ipi * se;
+    gc_add = g1;
+    gv_add = g2;
+  }
+  if ((int)threadIdx.x >= nc && threadIdx.x < SW) {
+    gmu_s[threadIdx.x] = 0.0;
+    gv_s[threadIdx.x] = 0.0;
+  }
+  out3[0] = e_add;
+  out3[1] = gc_add;
+  out3[2] = gv_add;
+  __syncthreads();
+}
+
 template <int DMAX>
 __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* region,
                                const gapro_fit_desc& desc, float* __restrict__ o_probs,
@@ -1358,11 +1456,21 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   gd* T1T = f.mat[B_BMT];
   gd* Gb = f.mat[B_A];
   gd* GTb = f.mat[B_AT];
+  gd* GKXT = f.mat[B_GKXT];
   gd* vm = f.vec[V_M];
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
   ldsd* tile = scratch + wave * 16 * 17;
   double last_loss = 0.0;
+  // LDS offsets of this lane's operand rows for the accumulator tiles the wave owns
+  int offA[kAccTiles], offB[kAccTiles];
+#pragma unroll
+  for (int q = 0; q < kAccTiles; ++q) {
+    int ti = 0, tj = 0;
+    if (wave + NW * q < nt_acc) lower_tile(wave + NW * q, &ti, &tj);
+    offA[q] = (16 * ti + lr) * RS + lq;
+    offB[q] = (16 * tj + lr) * RS + lq;
+  }
 #ifdef GAPRO_PROFILE
   auto stamp = [&](int id) { prof_stamp(id); };
 #else
@@ -1387,13 +1495,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   };
   // forward part of one strip: Cs = KX(:, n0..), As = LI Cs, Bs = LS^T As, mu_s / var_s for the strip columns
   auto strip_forward = [&](const ldsd* Xpts, int n0, int nc, double s, double inv_l2) {
-    for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
-      const int k = idx / SW, n = idx - k * SW;
-      double v = 0.0;
-      if (k < M && n < nc) v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Xpts, n0 + n, D, Mp));
-      Cs[k * RS + n] = v;
-    }
-    __syncthreads();
+    strip_fill_kx(Cs, Zt, Xpts, n0, nc, s, inv_l2);
     strip_gemm<K_LE>(f.mat[B_U], Mp, Cs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) As[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
@@ -1404,28 +1506,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       for (int r = 0; r < 4; ++r) Bs[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
     });
     __syncthreads();
-    {
-      const int n = threadIdx.x % SW, p = threadIdx.x / SW;  // NT / SW = 16 row groups
-      double pm = 0.0, pv = 0.0;
-      for (int i = p; i < Mp; i += NT / SW) {
-        const double a = As[i * RS + n], b = Bs[i * RS + n];
-        pm += m_s[i] * a;
-        pv += b * b - a * a;
-      }
-      sred[threadIdx.x] = pm;
-      sred[NT + threadIdx.x] = pv;
-      __syncthreads();
-      if (threadIdx.x < SW) {
-        double sm = 0.0, sv = 0.0;
-        for (int g = 0; g < NT / SW; ++g) {
-          sm += sred[g * SW + threadIdx.x];
-          sv += sred[NT + g * SW + threadIdx.x];
-        }
-        mu_s[threadIdx.x] = sm;
-        var_s[threadIdx.x] = s + jitter + sv;
-      }
-      __syncthreads();
-    }
+    strip_mean_var(As, Bs, m_s, sred, mu_s, var_s, s, jitter);
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
@@ -1440,63 +1521,20 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       gls[q] = (d4){0.0, 0.0, 0.0, 0.0};
       gl[q] = (d4){0.0, 0.0, 0.0, 0.0};
     }
-    double gm_acc = 0.0, e_tot = 0.0, gc_part = 0.0, gvs_part = 0.0, gs_zx = 0.0, gl_zx = 0.0;
-    double acc_zx[DMAX];
-#pragma unroll
-    for (int d = 0; d < DMAX; ++d) acc_zx[d] = 0.0;
+    double gm_acc = 0.0, e_tot = 0.0, gc_part = 0.0, gvs_part = 0.0;
     __syncthreads();
     stamp(3);
 
     for (int n0 = 0; n0 < M; n0 += SW) {
       const int nc = (M - n0) < SW ? (M - n0) : SW;
       strip_forward(Pt, n0, nc, s, inv_l2);
-      // ---- likelihood gradients of the strip columns (ten threads per column)
+      // ---- likelihood gradients of the strip columns
       {
-        const int q = threadIdx.x % 10, nl = threadIdx.x / 10;
-        double E = 0.0, dmu = 0.0, dvar = 0.0;
-        const bool on = nl < nc;
-        if (on) {
-          const double mu = mu_s[nl] + c;
-          const double vraw = var_s[nl];
-          const double var = vraw < opt.min_variance ? opt.min_variance : vraw;
-          const double sd = sqrt(2.0 * var);
-          const double y = f.vec[V_Y][n0 + nl];
-          const double t = c_gh_t[q], w = c_gh_w[q];
-          double lp, r;
-          log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
-          E += w * lp; dmu += w * r; dvar -= w * t * r;
-          log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
-          E += w * lp; dmu += w * r; dvar += w * t * r;
-        }
-        sred[threadIdx.x] = E;
-        sred[NT + threadIdx.x] = dmu;
-        sred[2 * NT + threadIdx.x] = dvar;
-        __syncthreads();
-        if (on && q == 0) {
-          double se = 0.0, sm = 0.0, sv = 0.0;
-          for (int qq = 0; qq < 10; ++qq) {
-            se += sred[threadIdx.x + qq];
-            sm += sred[NT + threadIdx.x + qq];
-            sv += sred[2 * NT + threadIdx.x + qq];
-          }
-          const double ipi = 0.56418958354775628695;  // 1/sqrt(pi)
-          const double vraw = var_s[nl];
-          const bool clamped = vraw < opt.min_variance;
-          const double var = clamped ? opt.min_variance : vraw;
-          const double y = f.vec[V_Y][n0 + nl];
-          const double g1 = -(ipi * sm * y) / Nd;
-          const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
-          gmu_s[nl] = g1;
-          gv_s[nl] = g2;
-          e_tot += ipi * se;
-          gc_part += g1;
-          gvs_part += g2;
-        }
-        if (threadIdx.x >= nc && threadIdx.x < SW) {
-          gmu_s[threadIdx.x] = 0.0;
-          gv_s[threadIdx.x] = 0.0;
-        }
-        __syncthreads();
+        double part[3];
+        strip_likelihood(mu_s, var_s, gmu_s, gv_s, sred, n0, nc, c, opt.min_variance, Nd, part);
+        e_tot += part[0];
+        gc_part += part[1];
+        gvs_part += part[2];
       }
       // ---- GB = 2 B diag(g_v), in place
       for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
@@ -1509,10 +1547,8 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       for (int q = 0; q < kAccTiles; ++q) {
         const int t = wave + NW * q;
         if (t < nt_acc) {
-          int ti, tj;
-          lower_tile(t, &ti, &tj);
-          const ldsd* pa = As + (16 * ti + lr) * RS + lq;
-          const ldsd* pb = Bs + (16 * tj + lr) * RS + lq;
+          const ldsd* pa = As + offA[q];
+          const ldsd* pb = Bs + offB[q];
 #pragma unroll
           for (int ks = 0; ks < SW / 4; ++ks)
             gls[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], gls[q], 0, 0, 0);
@@ -1544,36 +1580,18 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       for (int q = 0; q < kAccTiles; ++q) {
         const int t = wave + NW * q;
         if (t < nt_acc) {
-          int ti, tj;
-          lower_tile(t, &ti, &tj);
-          const ldsd* pa = Bs + (16 * ti + lr) * RS + lq;
-          const ldsd* pb = As + (16 * tj + lr) * RS + lq;
+          const ldsd* pa = Bs + offA[q];
+          const ldsd* pb = As + offB[q];
 #pragma unroll
           for (int ks = 0; ks < SW / 4; ++ks)
             gl[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], gl[q], 0, 0, 0);
         }
       }
-      // ---- zx kernel gradients: wx = G_KX[k][n] KX[k][n]; thread (k, part) walks the strip columns
-      {
-        const int G = NT / Mp, k = threadIdx.x % Mp, p = threadIdx.x / Mp;
-        if (p < G && k < M) {
-          for (int n = p; n < nc; n += G) {
-            double t[DMAX];
-            double d2 = 0.0;
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) {
-              t[d] = (d < D) ? Zt[d * Mp + k] - Pt[d * Mp + n0 + n] : 0.0;
-              d2 += t[d] * t[d];
-            }
-            const double ex = exp(-0.5 * inv_l2 * d2);
-            const double g = Bs[k * RS + n];
-            const double wx = g * s * ex;
-            gs_zx += g * ex;
-            gl_zx += wx * d2;
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) acc_zx[d] += wx * t[d];
-          }
-        }
+      // ---- G_KX^T rows of the strip -> global (the only intermediate that leaves the chip): the kernel
+      // gradient pass after the loop reads G_KX[k][n] as GKXT[n][k], contiguous in k
+      for (int idx = threadIdx.x; idx < Mp * nc; idx += NT) {
+        const int n = idx / Mp, k = idx - n * Mp;
+        GKXT[(size_t)(n0 + n) * Mp + k] = Bs[k * RS + n];
       }
       __syncthreads();
     }
@@ -1598,34 +1616,6 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       const double kl = 0.5 * (block_sum(kl_part) - Nd);
       last_loss = -(e_sum / Nd - kl / Nd);
     }
-    // zx sums of the row groups -> gZ (raw), combined with the zz part in kernel_grads_adam_z
-    {
-      const int G = NT / Mp;
-#pragma unroll
-      for (int dc = 0; dc < DMAX; dc += kRedSlots) {
-        if (dc < D) {
-          __syncthreads();
-#pragma unroll
-          for (int e = 0; e < kRedSlots; ++e)
-            if (dc + e < DMAX) scratch[e * NT + threadIdx.x] = acc_zx[dc + e];
-          __syncthreads();
-          if (threadIdx.x < M) {
-#pragma unroll
-            for (int e = 0; e < kRedSlots; ++e) {
-              const int d = dc + e;
-              if (d < D && d < DMAX) {
-                double sacc = 0.0;
-                for (int g = 0; g < G; ++g) sacc += scratch[e * NT + g * Mp + threadIdx.x];
-                f.gZ[(size_t)threadIdx.x * D + d] = sacc;
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-    const double gs_zx_tot = block_sum(gs_zx);
-    const double gl_zx_tot = block_sum(gl_zx);
     stamp(6);
 
     // ---- Adam on LS straight from the register tiles;  G_L tiles -> global for the tail products
@@ -1695,9 +1685,9 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       tail(std::integral_constant<int, 1>());
     stamp(13);
     double g_s, g_l;
-    kernel_grads_adam_z<DMAX, false>(Zt, Pt, Gb, GTb, nullptr, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
-    g_s += gs_zx_tot + gv_sum;
-    g_l = (g_l + gl_zx_tot) / (ell * ell * ell);
+    kernel_grads_adam_z<DMAX, true>(Zt, Pt, Gb, GTb, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
+    g_s += gv_sum;
+    g_l /= (ell * ell * ell);
     stamp(14);
 
     auto adam_upd = [&](double p, double& m1, double& m2, double g) {
