@@ -1282,43 +1282,54 @@ inline __host__ __device__ bool strip_ok(int m, int d) {
 enum { K_LE = 0, K_GE = 1 };
 // One strip product: out[16 rb .. ][16 ct ..] = sum_k P[k][16 rb + i] * Sin[k][16 ct + n], k restricted to
 // k < 16 (rb+1) (K_LE: P upper-triangular in (k,i)) or k >= 16 rb (K_GE).  2 nbk tiles over 8 waves, dealt
-// so that a wave's two tiles have complementary k-ranges.  A operand from global (TN rows), B from LDS.
+// so that a wave's two tiles have complementary k-ranges (nbk + 1 <= 9 blocks of 16 in total).  The A
+// operand streams from global memory (TN rows); the fixed operand matrices of 256 concurrent fits do not
+// stay in L2, so a fetch costs ~1 us under load: ALL of the wave's A fragments (<= 36 loads) are issued up
+// front and the MFMAs consume them in order, paying that latency once per product instead of once per
+// k-block.  The B operand comes from the LDS strip buffer.
+constexpr int kStripBlocks = kStripMaxMp / 16 + 1;
 template <int MODE, typename Epi>
 __device__ inline void strip_gemm(const gd* __restrict__ P, int Mp, const ldsd* Sin, int nbk, int wave, int lr, int lq,
                                   Epi epi) {
+  const int t0 = wave, t1 = wave + NW;
+  if (t0 >= 2 * nbk) return;
+  const int rb0 = t0 < nbk ? t0 : 2 * nbk - 1 - t0, ct0 = t0 < nbk ? 0 : 1;
+  const bool two = t1 < 2 * nbk;
+  const int rb1 = two ? (t1 < nbk ? t1 : 2 * nbk - 1 - t1) : 0, ct1 = two ? (t1 < nbk ? 0 : 1) : 0;
+  const int kb0 = MODE == K_LE ? 0 : rb0, n0 = MODE == K_LE ? rb0 + 1 : nbk - rb0;  // first block, block count
+  const int kb1 = MODE == K_LE ? 0 : rb1, n1 = two ? (MODE == K_LE ? rb1 + 1 : nbk - rb1) : 0;
+  const size_t sa = (size_t)4 * Mp;
+  double a[kStripBlocks][4];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int t = wave + NW * q;
-    if (t < 2 * nbk) {
-      const int rb = t < nbk ? t : 2 * nbk - 1 - t, ct = t < nbk ? 0 : 1;
-      const int klo = MODE == K_LE ? 0 : 16 * rb, khi = MODE == K_LE ? 16 * (rb + 1) : Mp;
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-      const gd* pa = P + (size_t)(klo + lq) * Mp + 16 * rb + lr;
-      const ldsd* pb = Sin + (klo + lq) * RS + 16 * ct + lr;
-      const size_t sa = (size_t)4 * Mp;
-      // blocks of four k-steps; the global operands of the next block are in flight during the MFMAs
-      double c0 = pa[0], c1 = pa[sa], c2 = pa[2 * sa], c3 = pa[3 * sa];
-#pragma nounroll
-      for (int k = klo; k < khi; k += 16) {
-        pa += 4 * sa;
-        double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
-        if (k + 16 < khi) {
-          n0 = pa[0];
-          n1 = pa[sa];
-          n2 = pa[2 * sa];
-          n3 = pa[3 * sa];
-        }
-        const double b0 = pb[0], b1 = pb[4 * RS], b2 = pb[8 * RS], b3 = pb[12 * RS];
-        pb += 16 * RS;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c2, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c3, b3, acc, 0, 0, 0);
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-      }
-      epi(rb, ct, acc);
+  for (int blk = 0; blk < kStripBlocks; ++blk) {
+    if (blk < n0 + n1) {
+      const bool first = blk < n0;
+      const int kb = first ? kb0 + blk : kb1 + (blk - n0);
+      const gd* pa = P + (size_t)(16 * kb + lq) * Mp + 16 * (first ? rb0 : rb1) + lr;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[blk][ks] = pa[ks * sa];
     }
   }
+  d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int blk = 0; blk < kStripBlocks; ++blk) {
+    if (blk < n0 + n1) {
+      const bool first = blk < n0;
+      const int kb = first ? kb0 + blk : kb1 + (blk - n0);
+      const ldsd* pb = Sin + (16 * kb + lq) * RS + 16 * (first ? ct0 : ct1) + lr;
+      if (first) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[blk][ks], pb[4 * ks * RS], acc0, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[blk][ks], pb[4 * ks * RS], acc1, 0, 0, 0);
+      }
+    }
+  }
+  epi(rb0, ct0, acc0);
+  if (two) epi(rb1, ct1, acc1);
 }
 
 __device__ inline void lower_tile(int t, int* ti, int* tj) {
