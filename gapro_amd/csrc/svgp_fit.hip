@@ -1507,17 +1507,21 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   // forward part of one strip: Cs = KX(:, n0..), As = LI Cs, Bs = LS^T As, mu_s / var_s for the strip columns
   auto strip_forward = [&](const ldsd* Xpts, int n0, int nc, double s, double inv_l2) {
     strip_fill_kx(Cs, Zt, Xpts, n0, nc, s, inv_l2);
+    stamp(3);
     strip_gemm<K_LE>(f.mat[B_U], Mp, Cs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) As[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
     });
     __syncthreads();
+    stamp(4);
     strip_gemm<K_GE>(LS, Mp, As, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Bs[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
     });
     __syncthreads();
+    stamp(7);
     strip_mean_var(As, Bs, m_s, sred, mu_s, var_s, s, jitter);
+    stamp(9);
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
@@ -1547,6 +1551,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         gc_part += part[1];
         gvs_part += part[2];
       }
+      stamp(10);
       // ---- GB = 2 B diag(g_v), in place
       for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
         const int j = idx / SW, n = idx - j * SW;
@@ -1569,6 +1574,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         const ldsd* pa = As + threadIdx.x * RS;
         for (int n = 0; n < SW; ++n) gm_acc += pa[n] * gmu_s[n];
       }
+      stamp(11);
       // ---- G_A strip -> Cs:  m g_mu^T + LS GB - 2 A diag(g_v)     (LS[i][j] = LST[j][i], j <= i)
       strip_gemm<K_LE>(LST, Mp, Bs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
         const int n = 16 * ct + lr;
@@ -1580,12 +1586,14 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         }
       });
       __syncthreads();
+      stamp(12);
       // ---- G_KX strip -> Bs:  LI^T G_A   (P = LI[k][i], k >= i)
       strip_gemm<K_GE>(f.mat[B_LI], Mp, Cs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) Bs[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
       });
       __syncthreads();
+      stamp(15);
       // ---- G_L -= G_KX A^T (register tiles)
 #pragma unroll
       for (int q = 0; q < kAccTiles; ++q) {
@@ -1605,8 +1613,8 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         GKXT[(size_t)(n0 + n) * Mp + k] = Bs[k * RS + n];
       }
       __syncthreads();
+      stamp(18);
     }
-    stamp(4);
 
     // ---- after the strips: scalars, G_m, ELBO value (last step only)
     const double g_c = block_sum(gc_part);
@@ -1858,7 +1866,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   staged.reserve(n_fits);
   strip.reserve(n_fits);
   long long need = 0, max_lds = 0, max_lds_strip = 0;
-  const bool use_strip = opt->reserved != 1;  // reserved == 1: force the staged kernel (tests, A/B runs)
+  const bool use_strip = opt->reserved == 2;  // opt-in: the strip-streaming kernel (experimental)
   for (int i = 0; i < n_fits; ++i) {
     gapro_fit_desc d = h_descs[i];
     const int m = d.m1 + d.m2;

@@ -26,12 +26,13 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true", help="use libgapro_hip_prof.so and print phase shares")
+    ap.add_argument("--use-strip", action="store_true")
     args = ap.parse_args()
     if args.profile:
         import os
         from gapro_amd import _lib
         _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libgapro_hip_prof.so")
-    pipe = Pipeline(device=0, training_iter=args.iters)
+    pipe = Pipeline(device=0, training_iter=args.iters, use_strip=args.use_strip)
     for m in [int(s) for s in args.sizes.split(",")]:
         m1 = m // 2
         m2 = m - m1
@@ -83,6 +84,10 @@ def main():
             names = ["chol:update", "chol:rest", "inv", "kx", "A+BMT+meanvar", "chol:diag", "quad/kl", "Gm+GA",
                      "GLS+adam", "GKX", "GL", "Pm", "T1", "G", "kgrads+adamZ", "-", "adam", "predict", "chol:panel",
                      "misc"]
+            if args.use_strip:
+                names = ["chol:update", "chol:rest", "inv", "s:fill", "s:A", "chol:diag", "post-strips", "s:B",
+                         "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
+                         "s:GKX", "adam", "predict", "s:GLacc+store", "misc"]
             tot = prof.sum()
             print("    phases (us per fit, share): " + "  ".join(
                 "%s %.0f (%.0f%%)" % (nm, v / 100.0, 100 * v / tot) for nm, v in zip(names, prof) if v > 0), flush=True)
