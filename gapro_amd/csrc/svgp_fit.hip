@@ -1289,8 +1289,14 @@ enum { K_LE = 0, K_GE = 1 };
 // k-block.  The B operand comes from the LDS strip buffer.
 constexpr int kStripBlocks = kStripMaxMp / 16 + 1;
 template <int MODE, typename Epi>
-__device__ inline void strip_gemm(const gd* __restrict__ P, int Mp, const ldsd* Sin, int nbk, int wave, int lr, int lq,
-                                  Epi epi) {
+__device__ __noinline__ void strip_gemm(const gd* __restrict__ P, int Mp, const ldsd* Sin, int nbk, Epi epi) {
+  // its own function on purpose: the caller keeps 80 accumulator registers alive across it (callee-saved
+  // VGPRs), and in here the 36 operand loads must all be in flight at once without a spill between them
+  P = uni_ptr(P);
+  Mp = uni(Mp);
+  nbk = uni(nbk);
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lr = lane & 15, lq = lane >> 4;
   const int t0 = wave, t1 = wave + NW;
   if (t0 >= 2 * nbk) return;
   const int rb0 = t0 < nbk ? t0 : 2 * nbk - 1 - t0, ct0 = t0 < nbk ? 0 : 1;
@@ -1508,15 +1514,17 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   auto strip_forward = [&](const ldsd* Xpts, int n0, int nc, double s, double inv_l2) {
     strip_fill_kx(Cs, Zt, Xpts, n0, nc, s, inv_l2);
     stamp(3);
-    strip_gemm<K_LE>(f.mat[B_U], Mp, Cs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
+    strip_gemm<K_LE>(f.mat[B_U], Mp, Cs, nbk, [=](int rb, int ct, const d4& v) {
+      const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) As[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
+      for (int r = 0; r < 4; ++r) As[(16 * rb + g4 + 4 * r) * RS + 16 * ct + c] = v[r];
     });
     __syncthreads();
     stamp(4);
-    strip_gemm<K_GE>(LS, Mp, As, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
+    strip_gemm<K_GE>(LS, Mp, As, nbk, [=](int rb, int ct, const d4& v) {
+      const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Bs[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
+      for (int r = 0; r < 4; ++r) Bs[(16 * rb + g4 + 4 * r) * RS + 16 * ct + c] = v[r];
     });
     __syncthreads();
     stamp(7);
@@ -1576,21 +1584,23 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       }
       stamp(11);
       // ---- G_A strip -> Cs:  m g_mu^T + LS GB - 2 A diag(g_v)     (LS[i][j] = LST[j][i], j <= i)
-      strip_gemm<K_LE>(LST, Mp, Bs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
-        const int n = 16 * ct + lr;
+      strip_gemm<K_LE>(LST, Mp, Bs, nbk, [=](int rb, int ct, const d4& v) {
+        const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
+        const int n = 16 * ct + c;
         const double gvn = gv_s[n], gmn = gmu_s[n];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 16 * rb + lq + 4 * r;
+          const int i = 16 * rb + g4 + 4 * r;
           Cs[i * RS + n] = v[r] + m_s[i] * gmn - 2.0 * As[i * RS + n] * gvn;
         }
       });
       __syncthreads();
       stamp(12);
       // ---- G_KX strip -> Bs:  LI^T G_A   (P = LI[k][i], k >= i)
-      strip_gemm<K_GE>(f.mat[B_LI], Mp, Cs, nbk, wave, lr, lq, [&](int rb, int ct, const d4& v) {
+      strip_gemm<K_GE>(f.mat[B_LI], Mp, Cs, nbk, [=](int rb, int ct, const d4& v) {
+        const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Bs[(16 * rb + lq + 4 * r) * RS + 16 * ct + lr] = v[r];
+        for (int r = 0; r < 4; ++r) Bs[(16 * rb + g4 + 4 * r) * RS + 16 * ct + c] = v[r];
       });
       __syncthreads();
       stamp(15);
