@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--feat-dim", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--use-strip", action="store_true", help="opt in to the experimental strip-streaming fit kernel")
+    ap.add_argument("--force-staged", action="store_true", help="never use the strip-streaming fit kernel (A/B)")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage wall clock to stderr (adds syncs)")
     args = ap.parse_args()
 
@@ -170,7 +170,7 @@ def main():
         resident.append(dict(kw, coords_float=torch.from_numpy(kw["coords_float"]).to(dev),
                              mask_feats=torch.from_numpy(kw["mask_feats"]).to(dev),
                              spp=torch.from_numpy(kw["spp"]).to(dev)))
-    pipe = Pipeline(device=local_rank, training_iter=50, use_strip=args.use_strip)
+    pipe = Pipeline(device=local_rank, training_iter=50, force_staged=args.force_staged)
 
     def make_jobs():
         return [make_job(r["coords_float"], r["mask_feats"], r["spp"], r["instance_cls"], r["instance_box"],

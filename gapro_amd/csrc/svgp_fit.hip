@@ -1876,7 +1876,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   staged.reserve(n_fits);
   strip.reserve(n_fits);
   long long need = 0, max_lds = 0, max_lds_strip = 0;
-  const bool use_strip = opt->reserved == 2;  // opt-in: the strip-streaming kernel (experimental)
+  const bool use_strip = opt->reserved != 1;  // reserved == 1: never use the strip-streaming kernel (A/B runs)
   for (int i = 0; i < n_fits; ++i) {
     gapro_fit_desc d = h_descs[i];
     const int m = d.m1 + d.m2;

@@ -121,7 +121,7 @@ def fit_flops(descs, n_fits: int, feat_dim: int, training_iter: int) -> float:
 
 class Pipeline:
     def __init__(self, device=0, training_iter=50, init_mean_std=0.0, seed=0, eval_stale_chol=False,
-                 spp_range_cap=None, force_staged=False, use_strip=False):
+                 spp_range_cap=None, force_staged=False):
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
         if not torch.cuda.is_available():
             raise RuntimeError("gapro_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -131,9 +131,9 @@ class Pipeline:
         self.lib = self.ctx.lib
         self.opt = _lib.default_fit_options(training_iter)
         self.opt.eval_stale_chol = 1 if eval_stale_chol else 0
-        # reserved: 0 default dispatch (LDS-staged kernel, generic kernel beyond its limits); 2 opts in to the
-        # experimental strip-streaming kernel for M_p <= 128 (kept for A/B runs, currently slower)
-        self.opt.reserved = 2 if (use_strip and not force_staged) else 0
+        # reserved: 0 default dispatch (strip-streaming kernel for M_p <= 128, LDS-staged kernel up to 512, generic
+        # kernel beyond); 1 = never the strip kernel (A/B runs, tests)
+        self.opt.reserved = 1 if force_staged else 0
         self.init_mean_std = float(init_mean_std)
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap

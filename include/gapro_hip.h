@@ -175,7 +175,7 @@ typedef struct {
   double min_variance;       /* 1e-6 gpytorch settings.min_variance */
   int32_t eval_stale_chol;   /* 0 = refactor K_ZZ with the trained parameters for prediction (default);
                                 1 = reuse the factor of the last training step */
-  int32_t reserved;          /* 0; 2 = opt in to the experimental strip-streaming kernel for M <= 128 */
+  int32_t reserved;          /* 0; 1 = debug: never route a fit to the strip-streaming kernel */
 } gapro_fit_options;
 
 void gapro_fit_options_default(gapro_fit_options* opt);

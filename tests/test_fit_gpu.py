@@ -141,8 +141,8 @@ def test_fit_rejects_empty_side():
 
 
 def test_strip_and_staged_kernels_agree():
-    """The opt-in strip-streaming kernel (M_p <= 128) and the default LDS-staged kernel must give the same
-    answers up to float64 summation order."""
+    """M_p <= 128 runs the strip-streaming kernel by default; the LDS-staged kernel (forced) must give the
+    same answers up to float64 summation order."""
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
     from gapro_amd.synth import make_gp_problem
 
@@ -154,8 +154,8 @@ def test_strip_and_staged_kernels_agree():
         probs.append((b1 + base, b2 + base, it + base))
         base += len(f)
     feats = np.concatenate(feats_list)
-    a = fit_gp_spp_batch(feats, probs, training_iter=50, use_strip=True)
-    b = fit_gp_spp_batch(feats, probs, training_iter=50)
+    a = fit_gp_spp_batch(feats, probs, training_iter=50)
+    b = fit_gp_spp_batch(feats, probs, training_iter=50, force_staged=True)
     for x, y in zip(a, b):
         np.testing.assert_allclose(x[4], y[4], rtol=1e-6)
         np.testing.assert_allclose(x[3], y[3], rtol=1e-5, atol=1e-7)

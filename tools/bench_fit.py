@@ -26,13 +26,13 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true", help="use libgapro_hip_prof.so and print phase shares")
-    ap.add_argument("--use-strip", action="store_true")
+    ap.add_argument("--force-staged", action="store_true")
     args = ap.parse_args()
     if args.profile:
         import os
         from gapro_amd import _lib
         _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libgapro_hip_prof.so")
-    pipe = Pipeline(device=0, training_iter=args.iters, use_strip=args.use_strip)
+    pipe = Pipeline(device=0, training_iter=args.iters, force_staged=args.force_staged)
     for m in [int(s) for s in args.sizes.split(",")]:
         m1 = m // 2
         m2 = m - m1
@@ -84,7 +84,7 @@ def main():
             names = ["chol:update", "chol:rest", "inv", "kx", "A+BMT+meanvar", "chol:diag", "quad/kl", "Gm+GA",
                      "GLS+adam", "GKX", "GL", "Pm", "T1", "G", "kgrads+adamZ", "-", "adam", "predict", "chol:panel",
                      "misc"]
-            if args.use_strip:
+            if not args.force_staged and m <= 128:
                 names = ["chol:update", "chol:rest", "inv", "s:fill", "s:A", "chol:diag", "post-strips", "s:B",
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
                          "s:GKX", "adam", "predict", "s:GLacc+store", "misc"]
