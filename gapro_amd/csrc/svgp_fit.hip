@@ -1560,22 +1560,20 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         gvs_part += part[2];
       }
       stamp(10);
-      // ---- GB = 2 B diag(g_v), in place
-      for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
-        const int j = idx / SW, n = idx - j * SW;
-        Bs[j * RS + n] *= 2.0 * gv_s[n];
-      }
-      __syncthreads();
       // ---- G_LS += A GB^T (register tiles), G_m += A g_mu
+      double sc2[SW / 4];
+#pragma unroll
+      for (int ks = 0; ks < SW / 4; ++ks) sc2[ks] = 2.0 * gv_s[4 * ks + lq];
 #pragma unroll
       for (int q = 0; q < kAccTiles; ++q) {
         const int t = wave + NW * q;
         if (t < nt_acc) {
           const ldsd* pa = As + offA[q];
           const ldsd* pb = Bs + offB[q];
+          // GB = 2 B diag(g_v) is never materialised: the factor rides on the A operand (k index = n)
 #pragma unroll
           for (int ks = 0; ks < SW / 4; ++ks)
-            gls[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], gls[q], 0, 0, 0);
+            gls[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks] * sc2[ks], pb[4 * ks], gls[q], 0, 0, 0);
         }
       }
       if (threadIdx.x < Mp) {
@@ -1591,7 +1589,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * rb + g4 + 4 * r;
-          Cs[i * RS + n] = v[r] + m_s[i] * gmn - 2.0 * As[i * RS + n] * gvn;
+          Cs[i * RS + n] = 2.0 * gvn * v[r] + m_s[i] * gmn - 2.0 * As[i * RS + n] * gvn;
         }
       });
       __syncthreads();
@@ -1651,33 +1649,62 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
     const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
     const double step_size = opt.lr / bc1;
+    {
+      // software-pipelined over the wave's tiles: the loads of tile q+1 are in flight while tile q is updated
+      double lsv[4], m1v[4], m2v[4], lsn[4], m1n[4], m2n[4];
+      auto load_tile = [&](int q, double (&l)[4], double (&a1)[4], double (&a2)[4]) {
+        const int t = wave + NW * q;
+        if (t < nt_acc) {
+          int ti, tj;
+          lower_tile(t, &ti, &tj);
+          const int j = 16 * tj + lr;
 #pragma unroll
-    for (int q = 0; q < kAccTiles; ++q) {
-      const int t = wave + NW * q;
-      if (t < nt_acc) {
-        int ti, tj;
-        lower_tile(t, &ti, &tj);
-        const int j = 16 * tj + lr;
-        d4 newv;
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + lq + 4 * r;
+            const size_t o = (size_t)i * Mp + j;
+            const bool act = j <= i && i < M;
+            l[r] = act ? LS[o] : 1.0;
+            a1[r] = act ? MLS[o] : 0.0;
+            a2[r] = act ? VLS[o] : 0.0;
+          }
+        }
+      };
+      load_tile(0, lsv, m1v, m2v);
+#pragma unroll
+      for (int q = 0; q < kAccTiles; ++q) {
+        const int t = wave + NW * q;
+        if (q + 1 < kAccTiles) load_tile(q + 1, lsn, m1n, m2n);
+        if (t < nt_acc) {
+          int ti, tj;
+          lower_tile(t, &ti, &tj);
+          const int j = 16 * tj + lr;
+          d4 newv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * ti + lq + 4 * r;
+            const size_t o = (size_t)i * Mp + j;
+            double lnew = 0.0;
+            if (j <= i && i < M) {
+              const double l = lsv[r];
+              const double g = gls[q][r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+              const double m1 = b1 * m1v[r] + (1.0 - b1) * g;
+              const double m2 = b2 * m2v[r] + (1.0 - b2) * g * g;
+              MLS[o] = m1;
+              VLS[o] = m2;
+              lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+              LS[o] = lnew;
+            }
+            newv[r] = lnew;
+            GLb[o] = (j <= i) ? gl[q][r] : 0.0;
+          }
+          store_tile(newv, nullptr, LST, Mp, 16 * ti, 16 * tj, tile);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 16 * ti + lq + 4 * r;
-          const size_t o = (size_t)i * Mp + j;
-          double lnew = 0.0;
-          if (j <= i && i < M) {
-            const double l = LS[o];
-            const double g = gls[q][r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
-            const double m1 = b1 * MLS[o] + (1.0 - b1) * g;
-            const double m2 = b2 * VLS[o] + (1.0 - b2) * g * g;
-            MLS[o] = m1;
-            VLS[o] = m2;
-            lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
-            LS[o] = lnew;
-          }
-          newv[r] = lnew;
-          GLb[o] = (j <= i) ? gl[q][r] : 0.0;
+          lsv[r] = lsn[r];
+          m1v[r] = m1n[r];
+          m2v[r] = m2n[r];
         }
-        store_tile(newv, nullptr, LST, Mp, 16 * ti, 16 * tj, tile);
       }
     }
     __syncthreads();
