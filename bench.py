@@ -203,6 +203,14 @@ def main():
     fit_ms = [e0.elapsed_time(e1) for e0, e1, _ in pipe.fit_events]
     fit_fl = [fl for _, _, fl in pipe.fit_events]
     stats = pipe.last_stats
+    if rank == 0 and getattr(pipe, "last_fit_m", None) is not None:
+        m = pipe.last_fit_m
+        edges = [0, 32, 64, 96, 128, 192, 256, 512, 1 << 30]
+        hist = np.histogram(m, bins=edges)[0]
+        w = np.histogram(m, bins=edges, weights=m.astype(np.float64) ** 3)[0]
+        print("inducing-set size M per fit (last launch): " + ", ".join(
+            "(%d,%s] n=%d M^3-share=%.0f%%" % (edges[i], edges[i + 1] if i < 7 else "inf", hist[i], 100 * w[i] / w.sum())
+            for i in range(8) if hist[i]) + "; max M %d" % m.max(), file=sys.stderr)
     if rank == 0 and args.stage_times:
         print("stage times per step (ms): " + ", ".join("%s %.2f" % (k, 1e3 * v / args.steps)
                                                          for k, v in pipe.stage_times.items()), file=sys.stderr)
@@ -229,7 +237,7 @@ def main():
                        "scenes_per_step_per_gpu": B, "points_per_scene": args.points, "feat_dim": args.feat_dim,
                        "gp_fits_per_step_per_gpu": int(stats.get("n_fits", 0)),
                        "parallelism": "scene-sharded x%d, no collective" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_svgp_fit (batched SVGP fit, f64 MFMA 16x16x4)",
+            "roofline": {"bound": "mfma", "kernel": "k_svgp_fit_strip<8> + k_svgp_fit (one batched SVGP fit launch = both, by fit size; f64 MFMA 16x16x4)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "avg_launch_ms": avg_ms, "flops_per_launch": float(np.mean(fit_fl)) if fit_fl else 0.0,

@@ -74,6 +74,7 @@ SIGNATURES = {
                                        C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_fit_workspace_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P]),
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
+    "gapro_debug_stream": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
 }
 
 _lib: Optional[C.CDLL] = None

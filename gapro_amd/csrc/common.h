@@ -13,6 +13,8 @@ struct gapro_ctx {
   int n_cu = 0;
   std::string last_error;
   gapro_scene_header* h_header_pinned = nullptr;  // pinned staging for the blocking prepare call
+  hipStream_t side_stream = nullptr;              // fit launches fork their second kernel onto it
+  hipEvent_t ev_join = nullptr;
 };
 
 inline int gapro_fail(gapro_ctx* ctx, int code, const char* fmt, ...) {

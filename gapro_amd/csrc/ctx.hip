@@ -23,6 +23,11 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
     delete ctx;
     return GAPRO_ERR_OOM;
   }
+  if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+    gapro_ctx_destroy(ctx);
+    return GAPRO_ERR_HIP;
+  }
   *out = ctx;
   return GAPRO_OK;
 }
@@ -30,6 +35,8 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
 void gapro_ctx_destroy(gapro_ctx* ctx) {
   if (!ctx) return;
   if (ctx->h_header_pinned) (void)hipHostFree(ctx->h_header_pinned);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   delete ctx;
 }
 

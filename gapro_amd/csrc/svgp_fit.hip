@@ -130,7 +130,7 @@ struct Fit {
 };
 
 #ifdef GAPRO_PROFILE
-constexpr int kProfSlots = 20;
+constexpr int kProfSlots = 28;
 #endif
 struct Shared {
   Fit f;
@@ -418,10 +418,11 @@ __device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
 //       broadcasts, no LDS round trips) and inverts it (column per lane)
 //   (3) panel below = S * Dinv^T, computed in LDS, then written once to L (rows) and L^T (rows)
 // The padded tail (index >= M) is an identity block.  Strict upper triangle of L stays zero.
+template <int DC>
 __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double s, double inv_l2, double jitter) {
   const Fit& f = g_sh.f;
   Shared& sh = g_sh;
-  const int Mp = f.Mp, M = f.M, D = f.D, nb = Mp / 16;
+  const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D, nb = Mp / 16;
   gd* L = f.mat[B_L];
   gd* LT = f.mat[B_LT];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -580,9 +581,10 @@ __device__ inline ColMap col_map(int Mp) {
 }
 
 // KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for k < M, n < ncols, zero elsewhere (Pt: staged points)
+template <int DC>
 __device__ __noinline__ void build_kx(const ldsd* Zt, const ldsd* Pt, int ncols, double s, double inv_l2) {
   const Fit& f = g_sh.f;
-  const int Mp = f.Mp, M = f.M, D = f.D;
+  const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D;
   gd* KX = f.mat[B_KX];
   const ColMap cm = col_map(Mp);
   if (!cm.active) return;
@@ -709,12 +711,17 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
 //   zz: w  = sym(G)[i][j] s E_ij  ->  G_s += sym(G) E,  G_l += w d2,   G_Z[j] += 2 w (Z_j - Z_i)
 //   zx: wx = G_KX[j][n=i] KX_jn   ->  G_s += G_KX E,    G_l += wx d2,  G_Z[j] += wx (Z_j - X_i)
 // (sym(G) o K is symmetric, so the sum over i of column j equals the row sum of the oracle's formula.)
-template <int DMAX, bool ZX>
+#ifdef GAPRO_X_NOEXP
+#define KG_EXP(x) (1.0 + (x))
+#else
+#define KG_EXP(x) exp(x)
+#endif
+template <int DMAX, bool ZX, int U, int DC>
 __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const gd* Gm, const gd* GTm,
                                                  const gd* GKXT, double s, double inv_l2, double step_size,
                                                  double bc2s, ldsd* red, double* gs_out, double* gl_out) {
   const Fit& f = g_sh.f;
-  const int Mp = f.Mp, M = f.M, D = f.D;
+  const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D;
   const ColMap cm = col_map(Mp);
   const int j = cm.col;
   double zj[DMAX], acc[DMAX];
@@ -725,41 +732,61 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
   }
   double gs = 0.0, gl = 0.0;
   if (cm.active && j < M) {
-    for (int i = cm.grp; i < M; i += cm.G) {
-      const size_t o = (size_t)i * Mp + j;
-      double t[DMAX];
-      double d2 = 0.0;
+    // the (up to) 3 U operand loads of U rows are issued before the first exp: one memory round trip per
+    // U rows instead of one per row (U is chosen per calling kernel to fit its register budget; a distinct U
+    // also keeps the two kernels from sharing one instantiation compiled for the tighter budget)
+    for (int i0 = cm.grp; i0 < M; i0 += cm.G * U) {
+      double g1[U], g2[U], g3[U];
 #pragma unroll
-      for (int d = 0; d < DMAX; ++d) {
-        t[d] = (d < D) ? zj[d] - Zt[d * Mp + i] : 0.0;
-        d2 += t[d] * t[d];
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * cm.G;
+        const bool act = i < M;
+        const size_t o = (size_t)(act ? i : 0) * Mp + j;
+        g1[u] = act ? Gm[o] : 0.0;
+        g2[u] = act ? GTm[o] : 0.0;
+        g3[u] = (ZX && act) ? GKXT[o] : 0.0;  // G_KX[j][i]
       }
-      const double e = exp(-0.5 * inv_l2 * d2);
-      const double gsym = 0.5 * (Gm[o] + GTm[o]);
-      const double w = gsym * s * e;
-      gs += gsym * e;
-      gl += w * d2;
 #pragma unroll
-      for (int d = 0; d < DMAX; ++d) acc[d] += 2.0 * w * t[d];
-      if (ZX) {
-        double d2x = 0.0;
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * cm.G;
+        if (u * cm.G >= M) break;  // wave-uniform: no row of this or any later u exists (small M)
+        if (i < M) {
+          double t[DMAX];
+          double d2 = 0.0;
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) {
-          t[d] = (d < D) ? zj[d] - Xt[d * Mp + i] : 0.0;
-          d2x += t[d] * t[d];
+          for (int d = 0; d < DMAX; ++d) {
+            t[d] = (d < D) ? zj[d] - Zt[d * Mp + i] : 0.0;
+            d2 += t[d] * t[d];
+          }
+          const double e = KG_EXP(-0.5 * inv_l2 * d2);
+          const double gsym = 0.5 * (g1[u] + g2[u]);
+          const double w = gsym * s * e;
+          gs += gsym * e;
+          gl += w * d2;
+#pragma unroll
+          for (int d = 0; d < DMAX; ++d) acc[d] += 2.0 * w * t[d];
+          if (ZX) {
+            double d2x = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+              t[d] = (d < D) ? zj[d] - Xt[d * Mp + i] : 0.0;
+              d2x += t[d] * t[d];
+            }
+            const double ex = KG_EXP(-0.5 * inv_l2 * d2x);
+            const double wx = g3[u] * s * ex;
+            gs += g3[u] * ex;
+            gl += wx * d2x;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) acc[d] += wx * t[d];
+          }
         }
-        const double ex = exp(-0.5 * inv_l2 * d2x);
-        const double g = GKXT[o];  // G_KX[j][i]
-        const double wx = g * s * ex;
-        gs += g * ex;
-        gl += wx * d2x;
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d) acc[d] += wx * t[d];
       }
     }
   }
+  prof_stamp(20);
   *gs_out = block_sum(gs);
   *gl_out = block_sum(gl);
+  prof_stamp(21);
   // combine the row groups, kRedSlots feature dimensions at a time, then Adam on Z (and its LDS copy)
   const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
 #pragma unroll
@@ -795,13 +822,13 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
   }
 }
 
-template <int TU, int DMAX>
+template <int TU, int DMAX, int DC>
 __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* scratch, const gapro_fit_desc& desc, float* __restrict__ o_probs, float* __restrict__ o_probs_new,
                          unsigned char* __restrict__ o_labels, float* __restrict__ o_mu, float* __restrict__ o_var,
                          double* loss_out) {
   const Fit& f = g_sh.f;
   Shared& sh = g_sh;
-  const int M = f.M, Mp = f.Mp, D = f.D, T = f.T;
+  const int M = f.M, Mp = f.Mp, D = DC ? DC : f.D, T = f.T;
   constexpr int TS = 16 * TU;
   const int mt = Mp / TS;
   const double Nd = (double)M;  // num_data = train_y.numel() (gaussian_process_utils.py:414)
@@ -846,7 +873,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   };
   auto factorize = [&]() {
     stamp(19);
-    cholesky_fused(Zt, scratch, sh.s, sh.inv_l2, jitter);
+    cholesky_fused<DC>(Zt, scratch, sh.s, sh.inv_l2, jitter);
     stamp(1);
     if (Mp <= 128)
       tri_inverse<8>(scratch);
@@ -930,7 +957,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     const bool last = step == opt.training_iter;
     // ------------------------------- forward -------------------------------
     factorize();
-    build_kx(Zt, Pt, M, s, inv_l2);
+    build_kx<DC>(Zt, Pt, M, s, inv_l2);
     __syncthreads();
     stamp(3);
     forward_products(M, s, jitter);
@@ -1068,7 +1095,8 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     stamp(13);
     // kernel gradients + Adam on Z
     double g_s, g_l;
-    kernel_grads_adam_z<DMAX, true>(Zt, Pt, G, GT, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
+    kernel_grads_adam_z<DMAX, true, (DMAX <= 8 ? 2 : 1), DC>(Zt, Pt, G, GT, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s,
+                                                         &g_l);
     g_s += gv_sum;
     g_l /= (ell * ell * ell);
     stamp(14);
@@ -1112,7 +1140,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stage_points_t(Pt, f.Xt + (size_t)t0 * D, nc, D, Mp);
     __syncthreads();
-    build_kx(Zt, Pt, nc, s, inv_l2);
+    build_kx<DC>(Zt, Pt, nc, s, inv_l2);
     __syncthreads();
     forward_products(nc, s, jitter);
     for (int n = threadIdx.x; n < nc; n += NT) {
@@ -1234,17 +1262,19 @@ __global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int 
   ldsd* scratch = Pt + D * Mp;
   fit_setup(desc, D, feats_spp, idx, init_mean, ws, Zt, Pt);
   double* loss_slot = &o_loss[desc.slot];
-  if (D <= 8) {
-    if (Mp >= 128)
-      fit_body<2, 8>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
-    else
-      fit_body<1, 8>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
-  } else {
-    if (Mp >= 128)
-      fit_body<2, 32>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
-    else
-      fit_body<1, 32>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
-  }
+  // the reference's two feature widths (xyz+rgb = 6, deep features = 32) get a compile-time D: the distance
+  // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
+#define GAPRO_FIT_BODY(DM, DCV)                                                                              \
+  do {                                                                                                       \
+    if (Mp >= 128)                                                                                           \
+      fit_body<2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
+    else                                                                                                     \
+      fit_body<1, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
+  } while (0)
+  if (D == 6) GAPRO_FIT_BODY(6, 6);
+  else if (D == 32) GAPRO_FIT_BODY(32, 32);
+  else GAPRO_FIT_BODY(32, 0);
+#undef GAPRO_FIT_BODY
   fit_epilogue(desc, opt, o_status, o_loss);
 }
 
@@ -1347,10 +1377,11 @@ __device__ inline void lower_tile(int t, int* ti, int* tj) {
 
 // The register-hungry, MFMA-free parts of a strip are separate functions: values that live across a call
 // (the gradient tiles) are kept in callee-saved VGPRs instead of being spilled around inlined libm code.
+template <int DC>
 __device__ __noinline__ void strip_fill_kx(ldsd* Cs, const ldsd* Zt, const ldsd* Xpts, int n0, int nc, double s,
                                            double inv_l2) {
   const Fit& f = g_sh.f;
-  const int Mp = f.Mp, M = f.M, D = f.D;
+  const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D;
   for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
     const int k = idx / SW, n = idx - k * SW;
     double v = 0.0;
@@ -1443,14 +1474,14 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
   __syncthreads();
 }
 
-template <int DMAX>
+template <int DMAX, int DC>
 __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* region,
                                const gapro_fit_desc& desc, float* __restrict__ o_probs,
                                float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
                                float* __restrict__ o_mu, float* __restrict__ o_var, double* loss_out) {
   const Fit& f = g_sh.f;
   Shared& sh = g_sh;
-  const int M = f.M, Mp = f.Mp, D = f.D, T = f.T;
+  const int M = f.M, Mp = f.Mp, D = DC ? DC : f.D, T = f.T;
   const int nbk = Mp / 16, nt_acc = nbk * (nbk + 1) / 2;
   const double Nd = (double)M;
   const double jitter = opt.jitter;
@@ -1504,7 +1535,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   };
   auto factorize = [&]() {
     stamp(19);
-    cholesky_fused(Zt, scratch, sh.s, sh.inv_l2, jitter);
+    cholesky_fused<DC>(Zt, scratch, sh.s, sh.inv_l2, jitter);
     stamp(1);
     tri_inverse<8>(scratch);
     __syncthreads();
@@ -1512,7 +1543,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   };
   // forward part of one strip: Cs = KX(:, n0..), As = LI Cs, Bs = LS^T As, mu_s / var_s for the strip columns
   auto strip_forward = [&](const ldsd* Xpts, int n0, int nc, double s, double inv_l2) {
-    strip_fill_kx(Cs, Zt, Xpts, n0, nc, s, inv_l2);
+    strip_fill_kx<DC>(Cs, Zt, Xpts, n0, nc, s, inv_l2);
     stamp(3);
     strip_gemm<K_LE>(f.mat[B_U], Mp, Cs, nbk, [=](int rb, int ct, const d4& v) {
       const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
@@ -1741,7 +1772,8 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       tail(std::integral_constant<int, 1>());
     stamp(13);
     double g_s, g_l;
-    kernel_grads_adam_z<DMAX, true>(Zt, Pt, Gb, GTb, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l);
+    kernel_grads_adam_z<DMAX, true, (DMAX <= 8 ? 8 : 2), DC>(Zt, Pt, Gb, GTb, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s,
+                                                         &g_l);
     g_s += gv_sum;
     g_l /= (ell * ell * ell);
     stamp(14);
@@ -1821,7 +1853,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
 }
 
 // one workgroup per CU: the register-resident gradient tiles need the full 256-VGPR budget
-template <int DMAX>
+template <int DMAX, int DC>
 __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, const float* __restrict__ feats_spp,
                                                         const int* __restrict__ idx,
                                                         const gapro_fit_desc* __restrict__ descs,
@@ -1841,7 +1873,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, con
   ldsd* region = Pt + D * Mp;
   fit_setup(desc, D, feats_spp, idx, init_mean, ws, Zt, Pt);
   double* loss_slot = &o_loss[desc.slot];
-  fit_body_strip<DMAX>(opt, Zt, Pt, region, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
+  fit_body_strip<DMAX, DC>(opt, Zt, Pt, region, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot);
   fit_epilogue(desc, opt, o_status, o_loss);
 }
 
@@ -1857,6 +1889,20 @@ __global__ void k_mfma_selftest(const double* __restrict__ P, const double* __re
 }
 
 }  // namespace
+
+__global__ void k_stream_calib(long long n, const double* __restrict__ src, double* __restrict__ dst, int mode) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double v = src[i];
+    if (mode == 1) dst[i] = v;
+    else acc += v;
+  }
+  if (mode == 0) {
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&dst[blockIdx.x], acc);
+  }
+}
 
 extern "C" {
 
@@ -1903,7 +1949,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   staged.reserve(n_fits);
   strip.reserve(n_fits);
   long long need = 0, max_lds = 0, max_lds_strip = 0;
-  const bool use_strip = opt->reserved != 1;  // reserved == 1: never use the strip-streaming kernel (A/B runs)
+  const bool use_strip = !(opt->reserved & 1);  // debug bit 0: never use the strip-streaming kernel (A/B runs)
   for (int i = 0; i < n_fits; ++i) {
     gapro_fit_desc d = h_descs[i];
     const int m = d.m1 + d.m2;
@@ -1945,14 +1991,27 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                        (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size(), d_init_mean, *opt, d_workspace,
                        d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   }
+  // The strip kernel runs beside the staged one (the few large fits leave most CUs idle): it goes to the
+  // context's side stream and is joined back into the caller's stream with an event.
+  hipStream_t sstream = stream;
+  const bool fork = !strip.empty() && (!staged.empty() || !large.empty()) && ctx->side_stream &&
+                    !(opt->reserved & 2);  // debug bit 1: keep both kernels on the caller's stream
+  // No fork event: `stream` has just been synchronised above, so everything the kernels read is complete.
+  // (An event recorded here completes together with the NEXT dispatch of `stream` under this runtime, which
+  // would serialise the two kernels again.)
+  if (fork) sstream = ctx->side_stream;
   if (!strip.empty()) {
-    auto kern = feat_dim <= 8 ? k_svgp_fit_strip<8> : k_svgp_fit_strip<32>;
+    auto kern = feat_dim == 6 ? k_svgp_fit_strip<6, 6> : feat_dim == 32 ? k_svgp_fit_strip<32, 32> : k_svgp_fit_strip<32, 0>;
     if (max_lds_strip > 48 * 1024)
       GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)max_lds_strip));
-    hipLaunchKernelGGL(kern, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, stream, (int)strip.size(),
+    hipLaunchKernelGGL(kern, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, sstream, (int)strip.size(),
                        (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size() + staged.size(), d_init_mean, *opt,
                        d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+  }
+  if (fork) {
+    GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, sstream));
+    GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
   }
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
@@ -1962,6 +2021,17 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
 int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream_, const double* d_P, const double* d_Q, double* d_C, int32_t K) {
   if (!ctx || !d_P || !d_Q || !d_C || K <= 0 || (K & 3)) return GAPRO_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream_, d_P, d_Q, d_C, (int)K);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+// Debug: streaming kernels with a known byte count in this library's own access pattern (one double per
+// lane, grid-stride), used to calibrate the FETCH_SIZE / WRITE_SIZE counters.  mode 0: read n doubles and
+// write one partial sum per workgroup; mode 1: copy n doubles.
+int gapro_debug_stream(gapro_ctx* ctx, void* stream_, int64_t n, const double* d_src, double* d_dst, int32_t mode) {
+  if (!ctx || !d_src || !d_dst || n <= 0 || mode < 0 || mode > 1) return GAPRO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_stream_calib, dim3(4096), dim3(256), 0, (hipStream_t)stream_, (long long)n, d_src, d_dst,
+                     (int)mode);
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
 }

@@ -109,14 +109,15 @@ def make_job(coords_float, mask_feats, spp, instance_cls, instance_box, instance
 def fit_flops(descs, n_fits: int, feat_dim: int, training_iter: int) -> float:
     """Algorithmic FLOPs of a fit batch, SURVEY.md section 8(d):
     F_fit = I (8.33 M^3 + 12 D M^2) + (M^3/3 + 2 M^2 T + 2 D (M^2 + M T)),  M = m1 + m2."""
-    total = 0.0
+    if n_fits <= 0:
+        return 0.0
+    raw = np.frombuffer(descs, dtype=np.int32, count=n_fits * (C.sizeof(FitDesc) // 4)).reshape(n_fits, -1)
+    m = (raw[:, 0] + raw[:, 1]).astype(np.float64)
+    t = raw[:, 2].astype(np.float64)
     d = float(feat_dim)
-    for i in range(n_fits):
-        m = float(descs[i].m1 + descs[i].m2)
-        t = float(descs[i].t)
-        total += training_iter * (8.33 * m**3 + 12.0 * d * m * m) + (m**3 / 3.0 + 2.0 * m * m * t
-                                                                     + 2.0 * d * (m * m + m * t))
-    return total
+    per_fit = training_iter * (8.33 * m**3 + 12.0 * d * m * m) + (m**3 / 3.0 + 2.0 * m * m * t
+                                                                  + 2.0 * d * (m * m + m * t))
+    return float(per_fit.sum())
 
 
 class Pipeline:
@@ -430,6 +431,8 @@ class Pipeline:
         if self.profile_fit:
             ev1.record(torch.cuda.current_stream(devc))
             self.fit_events.append((ev0, ev1, fit_flops(descs, n_fits, D, int(self.opt.training_iter))))
+            raw = np.frombuffer(descs, dtype=np.int32, count=n_fits * (C.sizeof(FitDesc) // 4)).reshape(n_fits, -1)
+            self.last_fit_m = (raw[:, 0] + raw[:, 1]).copy()
         # results travel to pinned host memory on the same stream; nobody waits here
         h_out = self._pinned(slot + "fit_out", no * 17)
         h_stat = self._pinned(slot + "fit_stat", n_fits * 12)

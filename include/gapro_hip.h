@@ -175,7 +175,8 @@ typedef struct {
   double min_variance;       /* 1e-6 gpytorch settings.min_variance */
   int32_t eval_stale_chol;   /* 0 = refactor K_ZZ with the trained parameters for prediction (default);
                                 1 = reuse the factor of the last training step */
-  int32_t reserved;          /* 0; 1 = debug: never route a fit to the strip-streaming kernel */
+  int32_t reserved;          /* 0; debug bits: 1 = never route a fit to the strip-streaming kernel,
+                              * 2 = launch both fit kernels on the caller's stream (no side stream) */
 } gapro_fit_options;
 
 void gapro_fit_options_default(gapro_fit_options* opt);
@@ -214,6 +215,11 @@ int gapro_fit_workspace_layout(int32_t m, int32_t t, int32_t feat_dim, int64_t* 
  * v_mfma_f64_16x16x4_f64 lane maps the fit kernel relies on. */
 int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream, const double* d_P, const double* d_Q, double* d_C,
                         int32_t K);
+/* Streaming kernels with a known byte count (one double per lane, grid-stride: the access width of the
+ * fit kernel), to calibrate the FETCH_SIZE / WRITE_SIZE counters.  mode 0: read n doubles, one atomic
+ * partial sum per wave into d_dst[0..4095]; mode 1: copy n doubles. */
+int gapro_debug_stream(gapro_ctx* ctx, void* stream, int64_t n, const double* d_src, double* d_dst,
+                       int32_t mode);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,75 @@ from gapro_amd.pipeline import Pipeline, fit_flops  # noqa: E402
 from gapro_amd.synth import make_gp_problem  # noqa: E402
 
 
+def build_mix(mix, args):
+    groups = [(int(a.split(":")[0]), int(a.split(":")[1])) for a in mix.split(",")]
+    feats_l, sel = [], []
+    base = 0
+    for m, cnt in groups:
+        for i in range(4):
+            f, b1, b2, it = make_gp_problem(i, m // 2, m - m // 2, args.t, args.d)
+            feats_l.append(f)
+            sel.append((m, b1 + base, b2 + base, it + base))
+            base += len(f)
+    feats = torch.from_numpy(np.concatenate(feats_l)).cuda()
+    n = sum(c for _, c in groups)
+    descs = (FitDesc * n)()
+    idx = []
+    io = oo = k = 0
+    for gi, (m, cnt) in enumerate(groups):
+        for i in range(cnt):
+            _, b1, b2, it = sel[4 * gi + i % 4]
+            d = descs[k]
+            d.m1, d.m2, d.t = len(b1), len(b2), len(it)
+            d.idx_offset, d.out_offset = io, oo
+            idx += [b1, b2, it]
+            io += len(b1) + len(b2) + len(it)
+            oo += len(it)
+            k += 1
+    h_idx = np.concatenate(idx).astype(np.int32)
+    return feats, descs, n, h_idx, oo
+
+
+def run_two_streams(pipe, args):
+    """--mix 'A;B': batch A on one torch stream, batch B on another, launched back to back from the host."""
+    import time
+    mixes = args.mix.split(";")
+    batches = [build_mix(m, args) for m in mixes]
+    streams = [torch.cuda.Stream() for _ in batches]
+    for mode in ("serial", "two streams"):
+        for r in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pend = []
+            for i, (b, st) in enumerate(zip(batches, streams)):
+                with torch.cuda.stream(st if mode != "serial" else streams[0]):
+                    pend.append(pipe.fit_launch(*b, slot="s%d" % i))
+            for p in pend:
+                pipe.fit_collect(p)
+            torch.cuda.synchronize()
+            dt = 1e3 * (time.perf_counter() - t0)
+        print("%s: %-12s %.2f ms" % (args.mix, mode, dt))
+
+
+def run_mix(pipe, args):
+    if ";" in args.mix:
+        return run_two_streams(pipe, args)
+    feats, descs, n, h_idx, oo = build_mix(args.mix, args)
+    pipe.profile_fit = True
+    times = []
+    for r in range(args.reps + 1):
+        pipe.fit_events = []
+        with torch.cuda.stream(torch.cuda.Stream() if args.own_stream else torch.cuda.current_stream()):
+            pipe.fit_descs(feats, descs, n, h_idx, oo)
+        torch.cuda.synchronize()
+        e0, e1, fl = pipe.fit_events[0]
+        if r > 0:
+            times.append(e0.elapsed_time(e1))
+    ms = float(np.median(times))
+    print("mix %s fork=%s : %9.2f ms/launch  %9.1f fits/s  %7.3f TFLOP/s" % (args.mix, not args.no_fork, ms,
+                                                                           n / (ms * 1e-3), fl / (ms * 1e-3) / 1e12))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="32,64,96,128,160,256")
@@ -27,12 +96,25 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true", help="use libgapro_hip_prof.so and print phase shares")
     ap.add_argument("--force-staged", action="store_true")
+    ap.add_argument("--lib", default="", help="alternative library file name inside gapro_amd/ (A/B runs)")
+    ap.add_argument("--mix", default="", help="one launch of mixed sizes, e.g. 160:128,96:1024,64:1024 (M:count)")
+    ap.add_argument("--no-fork", action="store_true", help="both fit kernels on one stream")
+    ap.add_argument("--own-stream", action="store_true", help="launch from a non-default torch stream")
     args = ap.parse_args()
     if args.profile:
         import os
         from gapro_amd import _lib
         _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libgapro_hip_prof.so")
+    if args.lib:
+        import os
+        from gapro_amd import _lib
+        _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), args.lib)
     pipe = Pipeline(device=0, training_iter=args.iters, force_staged=args.force_staged)
+    if args.no_fork:
+        pipe.opt.reserved |= 2
+    if args.mix:
+        run_mix(pipe, args)
+        return
     for m in [int(s) for s in args.sizes.split(",")]:
         m1 = m // 2
         m2 = m - m1
@@ -80,14 +162,15 @@ def main():
             _lib.load().gapro_fit_workspace_layout(m, args.t, args.d, C.cast(lay, C.c_void_p))
             scal, total = int(lay[6]), int(lay[7])
             ws = res["workspace"].cpu().numpy()
-            prof = np.stack([ws[i * total + scal + 24: i * total + scal + 44] for i in range(min(n, 64))]).mean(0)
+            prof = np.stack([ws[i * total + scal + 24: i * total + scal + 52] for i in range(min(n, 64))]).mean(0)
             names = ["chol:update", "chol:rest", "inv", "kx", "A+BMT+meanvar", "chol:diag", "quad/kl", "Gm+GA",
                      "GLS+adam", "GKX", "GL", "Pm", "T1", "G", "kgrads+adamZ", "-", "adam", "predict", "chol:panel",
                      "misc"]
             if not args.force_staged and m <= 128:
                 names = ["chol:update", "chol:rest", "inv", "s:fill", "s:A", "chol:diag", "post-strips", "s:B",
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
-                         "s:GKX", "adam", "predict", "s:GLacc+store", "misc"]
+                         "s:GKX", "adam", "predict", "s:GLacc+store", "misc", "kg:loop", "kg:sums", "x22", "x23",
+                         "x24", "x25", "x26", "x27"]
             tot = prof.sum()
             print("    phases (us per fit, share): " + "  ".join(
                 "%s %.0f (%.0f%%)" % (nm, v / 100.0, 100 * v / tot) for nm, v in zip(names, prof) if v > 0), flush=True)
