@@ -14,7 +14,8 @@ wall time).  Rank 0 prints ONE JSON line.
 
 `roofline` is for the dominant kernel, the batched SVGP fit: achieved = algorithmic FLOPs of one
 launch (F_fit = I(8.33 M^3 + 12 D M^2) + M^3/3 + 2 M^2 T + 2 D (M^2 + M T), summed over
-the fits of the launch) / the launch's duration measured with HIP events on the launch stream.
+the fits the kernel processes) / the kernel's duration measured with HIP events that the library
+records on the stream the kernel is launched on (its own CU-masked fit stream).
 `cpu_baseline` times the CPU oracle (torch float64 autograd restatement of the reference algorithm,
 kind "port") on this box's host cores on one scene of the same workload.
 """
@@ -49,6 +50,31 @@ def build_scene_inputs(seed, n_points, feat_dim):
     return dict(coords_float=xyz, mask_feats=feats, spp=sc.spp, instance_cls=cls.astype(np.int64),
                 instance_box=box.astype(np.float32), instance_box_volume=vol.astype(np.float32), wall_box=[],
                 wall_box_volume=[], instance_classes=18, ground_h=0.1, thresh_spp_occu=0.999)
+
+
+def lib_route(m, feat_dim):
+    from gapro_amd import _lib
+
+    return int(_lib.load().gapro_fit_route(m, feat_dim))
+
+
+def pmc_traffic(args, scenes_per_step):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json,
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this same command, corrected as calibrated there); None when
+    the profiled workload is not the one being run."""
+    import glob
+
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            with open(fn) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        w = rec.get("workload", {})
+        if (w.get("scenes_per_step"), w.get("points"), w.get("feat_dim")) == (scenes_per_step, args.points, args.feat_dim):
+            best = rec
+    return None if best is None else float(best["strip_kernel"]["hbm_bytes_per_launch"])
 
 
 def _cpu_worker_init():
@@ -138,6 +164,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-staged", action="store_true", help="never use the strip-streaming fit kernel (A/B)")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage wall clock to stderr (adds syncs)")
+    ap.add_argument("--trace", action="store_true", help="print the host-side stage timeline of the timed steps to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,6 +214,8 @@ def main():
     pipe.profile_fit = True
     pipe.fit_events = []
     pipe.profile_stages = args.stage_times
+    if args.trace:
+        pipe.trace = []
     barrier()
     t0 = time.perf_counter()
     if args.stage_times:
@@ -200,8 +229,11 @@ def main():
 
     elapsed = barrier_and_max(elapsed, dev)  # MAX over ranks
 
-    fit_ms = [e0.elapsed_time(e1) for e0, e1, _ in pipe.fit_events]
-    fit_fl = [fl for _, _, fl in pipe.fit_events]
+    # device-side duration of every fit launch, from HIP events the library records on the streams its kernels
+    # run on: (staged kernel ms, strip kernel ms, first start -> last end ms)
+    fit_ms3 = [ev.read() for ev in pipe.fit_events]
+    fit_ms = [t[2] for t in fit_ms3]
+    fit_fl = [ev.flops for ev in pipe.fit_events]
     stats = pipe.last_stats
     if rank == 0 and getattr(pipe, "last_fit_m", None) is not None:
         m = pipe.last_fit_m
@@ -211,12 +243,25 @@ def main():
         print("inducing-set size M per fit (last launch): " + ", ".join(
             "(%d,%s] n=%d M^3-share=%.0f%%" % (edges[i], edges[i + 1] if i < 7 else "inf", hist[i], 100 * w[i] / w.sum())
             for i in range(8) if hist[i]) + "; max M %d" % m.max(), file=sys.stderr)
+    if rank == 0 and args.trace:
+        t_first = pipe.trace[0][0]
+        ids = {}
+        for t, bid, name in pipe.trace:
+            print("  %9.2f ms  batch %d  %s" % (1e3 * (t - t_first), ids.setdefault(bid, len(ids)), name), file=sys.stderr)
     if rank == 0 and args.stage_times:
         print("stage times per step (ms): " + ", ".join("%s %.2f" % (k, 1e3 * v / args.steps)
                                                          for k, v in pipe.stage_times.items()), file=sys.stderr)
     if rank == 0:
         avg_ms = float(np.mean(fit_ms)) if fit_ms else 0.0
-        achieved = (float(np.mean(fit_fl)) / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0
+        launch_tflops = (float(np.mean(fit_fl)) / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0
+        # dominant kernel: the strip-streaming fit kernel (fits with round_up(M, 32) <= 128)
+        strip_ms = float(np.mean([t[1] for t in fit_ms3])) if fit_ms3 else 0.0
+        strip_fl = float(np.mean([ev.flops_strip for ev in pipe.fit_events])) if fit_ms3 else 0.0
+        staged_ms = float(np.mean([t[0] for t in fit_ms3])) if fit_ms3 else 0.0
+        staged_fl = float(np.mean([ev.flops_staged for ev in pipe.fit_events])) if fit_ms3 else 0.0
+        achieved = (strip_fl / (strip_ms * 1e-3) / 1e12) if strip_ms > 0 else 0.0
+        n_strip = int(sum(1 for ev in pipe.fit_events[-1:] for v in ev.m if lib_route(int(v), args.feat_dim) == 0))
+        traffic = pmc_traffic(args, B)
         descs = stats.get("fit") or {}
         out = {
             "metric": "scenes/sec pseudo-label gen (ScanNetV2-train-shaped synthetic scenes)",
@@ -237,12 +282,19 @@ def main():
                        "scenes_per_step_per_gpu": B, "points_per_scene": args.points, "feat_dim": args.feat_dim,
                        "gp_fits_per_step_per_gpu": int(stats.get("n_fits", 0)),
                        "parallelism": "scene-sharded x%d, no collective" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_svgp_fit_strip<8> + k_svgp_fit (one batched SVGP fit launch = both, by fit size; f64 MFMA 16x16x4)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "k_svgp_fit_strip<%d,%d> (batched SVGP fit, fits with round_up(M,32) <= 128; f64 MFMA "
+                                   "16x16x4)" % ((args.feat_dim, args.feat_dim) if args.feat_dim in (6, 32) else (32, 0)),
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_ms": avg_ms, "flops_per_launch": float(np.mean(fit_fl)) if fit_fl else 0.0,
-                         "fits_per_s": (stats.get("n_fits", 0) / (avg_ms * 1e-3)) if avg_ms > 0 else 0.0,
-                         "fit_share_of_step": (sum(fit_ms) / (1e3 * elapsed)) if elapsed > 0 else None},
+                         "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": strip_ms, "flops_per_launch": strip_fl, "fits_per_launch": n_strip,
+                         "timing": "HIP events recorded by the library on the stream the kernel is launched on"},
+            # the whole fit launch: the strip kernel and the staged kernel (larger fits) run side by side
+            "fit_launch": {"avg_ms_first_start_to_last_end": avg_ms, "flops": float(np.mean(fit_fl)) if fit_fl else 0.0,
+                           "tflops": launch_tflops, "frac_of_fp64_mfma_peak": launch_tflops / FP64_MFMA_PEAK_TFLOPS,
+                           "fits_per_s": (stats.get("n_fits", 0) / (avg_ms * 1e-3)) if avg_ms > 0 else 0.0,
+                           "staged_kernel_avg_ms": staged_ms, "staged_kernel_flops": staged_fl,
+                           "share_of_step": (sum(fit_ms) / (1e3 * elapsed)) if elapsed > 0 else None},
         }
         out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -73,6 +73,11 @@ SIGNATURES = {
     "gapro_svgp_fit_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.POINTER(FitOptions), _P,
                                        C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_fit_workspace_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P]),
+    "gapro_fit_route": (C.c_int, [C.c_int32, C.c_int32]),
+    "gapro_fit_timing_create": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "gapro_fit_timing_destroy": (None, [_P]),
+    "gapro_fit_timing_arm": (C.c_int, [_P, _P]),
+    "gapro_fit_timing_read": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "gapro_debug_stream": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
 }

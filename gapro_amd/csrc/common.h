@@ -13,8 +13,17 @@ struct gapro_ctx {
   int n_cu = 0;
   std::string last_error;
   gapro_scene_header* h_header_pinned = nullptr;  // pinned staging for the blocking prepare call
-  hipStream_t side_stream = nullptr;              // fit launches fork their second kernel onto it
-  hipEvent_t ev_join = nullptr;
+  // The fit kernels run on two library-owned streams ([0] staged / generic kernel, [1] strip kernel), so that
+  // the few large fits of the staged kernel and the strip kernel share the GPU.
+  hipStream_t fit_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_join[2] = {nullptr, nullptr};
+  struct gapro_fit_timing* armed_timing = nullptr;  // consumed by the next gapro_svgp_fit_batch
+};
+
+// HIP events around the kernels of one fit launch, recorded on the streams the kernels run on.
+struct gapro_fit_timing {
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // staged start/end, strip start/end
+  bool used[2] = {false, false};
 };
 
 inline int gapro_fail(gapro_ctx* ctx, int code, const char* fmt, ...) {

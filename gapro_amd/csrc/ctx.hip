@@ -1,6 +1,7 @@
 // Context management of libgapro_hip.so.
 #include "common.h"
 
+
 extern "C" {
 
 int gapro_version(void) { return GAPRO_VERSION; }
@@ -23,11 +24,12 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
     delete ctx;
     return GAPRO_ERR_OOM;
   }
-  if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
-    gapro_ctx_destroy(ctx);
-    return GAPRO_ERR_HIP;
-  }
+  for (int k = 0; k < 2; ++k)
+    if (hipStreamCreateWithFlags(&ctx->fit_stream[k], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) != hipSuccess) {
+      gapro_ctx_destroy(ctx);
+      return GAPRO_ERR_HIP;
+    }
   *out = ctx;
   return GAPRO_OK;
 }
@@ -35,8 +37,10 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
 void gapro_ctx_destroy(gapro_ctx* ctx) {
   if (!ctx) return;
   if (ctx->h_header_pinned) (void)hipHostFree(ctx->h_header_pinned);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+    if (ctx->fit_stream[k]) (void)hipStreamDestroy(ctx->fit_stream[k]);
+  }
   delete ctx;
 }
 

@@ -1245,7 +1245,10 @@ __device__ inline void fit_epilogue(const gapro_fit_desc& desc, const gapro_fit_
   }
 }
 
-__global__ __launch_bounds__(NT, kWavesPerSimd) void k_svgp_fit(int n_fits, int D, const float* __restrict__ feats_spp,
+// WPS = waves per SIMD the register budget is sized for: kWavesPerSimd (two workgroups per CU) for a full
+// launch, 2 (one workgroup per CU, 256 VGPRs, no spills in the body) when the launch has fewer fits than CUs
+template <int WPS>
+__global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const float* __restrict__ feats_spp,
                                                  const int* __restrict__ idx, const gapro_fit_desc* __restrict__ descs,
                                                  const double* __restrict__ init_mean, gapro_fit_options opt,
                                                  double* __restrict__ ws, float* __restrict__ o_probs,
@@ -1904,6 +1907,13 @@ __global__ void k_stream_calib(long long n, const double* __restrict__ src, doub
   }
 }
 
+// 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel.  flags: gapro_fit_options.reserved
+// debug bits (bit 0: never the strip kernel).
+static int fit_route(int m, int feat_dim, int flags) {
+  if (!(flags & 1) && strip_ok(m, feat_dim)) return 0;
+  return staged_ok(m, feat_dim) ? 1 : 2;
+}
+
 extern "C" {
 
 int64_t gapro_fit_workspace_doubles(int32_t m, int32_t t, int32_t feat_dim) {
@@ -1942,14 +1952,13 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   if (opt->training_iter < 0 || !(opt->lr > 0.0) || !(opt->jitter >= 0.0))
     return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: bad options");
   hipStream_t stream = (hipStream_t)stream_;
-  // Launch order = longest processing time first (cost ~ M^3): workgroups are dispatched in block
-  // order, so the expensive fits start first and the tail of the launch stays short.  Fits whose
-  // working set does not fit the LDS-staged kernel go to the generic kernel.
-  std::vector<gapro_fit_desc> staged, large, strip;
-  staged.reserve(n_fits);
+  // Routing (gapro_fit_route): strip-streaming kernel, LDS-staged kernel, generic kernel (working set beyond
+  // LDS).  Every group is sorted longest processing time first (cost ~ M^3): workgroups are dispatched in
+  // block order, so the expensive fits start first and the tail of a launch stays short.
+  std::vector<gapro_fit_desc> strip, staged, large;
   strip.reserve(n_fits);
   long long need = 0, max_lds = 0, max_lds_strip = 0;
-  const bool use_strip = !(opt->reserved & 1);  // debug bit 0: never use the strip-streaming kernel (A/B runs)
+  const int route_flags = opt->reserved;
   for (int i = 0; i < n_fits; ++i) {
     gapro_fit_desc d = h_descs[i];
     const int m = d.m1 + d.m2;
@@ -1957,10 +1966,11 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: fit %d has an empty side", i);
     d.slot = i;
     need = std::max<long long>(need, (d.ws_offset + gapro_fit_workspace_doubles(m, d.t, feat_dim)) * 8LL);
-    if (use_strip && strip_ok(m, feat_dim)) {
+    const int route = fit_route(m, feat_dim, route_flags);
+    if (route == 0) {
       strip.push_back(d);
       max_lds_strip = std::max(max_lds_strip, strip_lds_bytes(m, feat_dim));
-    } else if (staged_ok(m, feat_dim)) {
+    } else if (route == 1) {
       staged.push_back(d);
       max_lds = std::max(max_lds, staged_lds_bytes(m, feat_dim));
     } else {
@@ -1971,49 +1981,115 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     return gapro_fail(ctx, GAPRO_ERR_WORKSPACE, "gapro_svgp_fit_batch: workspace too small (%lld > %zu)", need,
                       workspace_bytes);
   auto by_cost = [](const gapro_fit_desc& a, const gapro_fit_desc& b) { return a.m1 + a.m2 > b.m1 + b.m2; };
+  std::stable_sort(strip.begin(), strip.end(), by_cost);
   std::stable_sort(staged.begin(), staged.end(), by_cost);
   std::stable_sort(large.begin(), large.end(), by_cost);
-  std::stable_sort(strip.begin(), strip.end(), by_cost);
   std::vector<gapro_fit_desc> all(large);
   all.insert(all.end(), staged.begin(), staged.end());
   all.insert(all.end(), strip.begin(), strip.end());
   GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_descs, all.data(), all.size() * sizeof(gapro_fit_desc), hipMemcpyHostToDevice,
                                       stream));
   GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));  // `all` is pageable host memory that dies with this call
+  // The kernels go to the context's two fit streams so that the staged kernel (a few large fits, which leave
+  // most CUs idle) and the strip kernel run side by side.  No fork event is needed: `stream` has just been
+  // synchronised, so everything the kernels read is complete (and an event recorded here completes together
+  // with the NEXT dispatch of `stream` under this runtime, which would serialise the kernels again).  Both
+  // are joined back into `stream` with events.
+  const bool own = !(route_flags & 2) && ctx->fit_stream[0] && ctx->fit_stream[1];  // debug bit 1: caller's stream
+  hipStream_t s_staged = own ? ctx->fit_stream[0] : stream;
+  hipStream_t s_strip = own ? ctx->fit_stream[1] : stream;
+  gapro_fit_timing* tm = ctx->armed_timing;
+  ctx->armed_timing = nullptr;
+  if (tm) {
+    tm->used[0] = !large.empty() || !staged.empty();
+    tm->used[1] = !strip.empty();
+    if (tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[0], s_staged));
+  }
   if (!large.empty())
-    gapro_launch_fit_large(stream, (int)large.size(), feat_dim, d_feats_spp, d_idx, d_descs, d_init_mean, *opt,
+    gapro_launch_fit_large(s_staged, (int)large.size(), feat_dim, d_feats_spp, d_idx, d_descs, d_init_mean, *opt,
                            d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   if (!staged.empty()) {
+    // fewer fits than CUs: every fit has a CU to itself anyway, so take the whole register file
+    auto kern = (int)staged.size() <= ctx->n_cu ? k_svgp_fit<2> : k_svgp_fit<kWavesPerSimd>;
     if (max_lds > 48 * 1024)
-      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_svgp_fit, hipFuncAttributeMaxDynamicSharedMemorySize,
+      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)max_lds));
-    hipLaunchKernelGGL(k_svgp_fit, dim3((int)staged.size()), dim3(NT), (size_t)max_lds, stream, (int)staged.size(),
+    hipLaunchKernelGGL(kern, dim3((int)staged.size()), dim3(NT), (size_t)max_lds, s_staged, (int)staged.size(),
                        (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size(), d_init_mean, *opt, d_workspace,
                        d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   }
-  // The strip kernel runs beside the staged one (the few large fits leave most CUs idle): it goes to the
-  // context's side stream and is joined back into the caller's stream with an event.
-  hipStream_t sstream = stream;
-  const bool fork = !strip.empty() && (!staged.empty() || !large.empty()) && ctx->side_stream &&
-                    !(opt->reserved & 2);  // debug bit 1: keep both kernels on the caller's stream
-  // No fork event: `stream` has just been synchronised above, so everything the kernels read is complete.
-  // (An event recorded here completes together with the NEXT dispatch of `stream` under this runtime, which
-  // would serialise the two kernels again.)
-  if (fork) sstream = ctx->side_stream;
+  if (tm && tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[1], s_staged));
   if (!strip.empty()) {
     auto kern = feat_dim == 6 ? k_svgp_fit_strip<6, 6> : feat_dim == 32 ? k_svgp_fit_strip<32, 32> : k_svgp_fit_strip<32, 0>;
     if (max_lds_strip > 48 * 1024)
       GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)max_lds_strip));
-    hipLaunchKernelGGL(kern, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, sstream, (int)strip.size(),
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[2], s_strip));
+    hipLaunchKernelGGL(kern, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, s_strip, (int)strip.size(),
                        (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size() + staged.size(), d_init_mean, *opt,
                        d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[3], s_strip));
   }
-  if (fork) {
-    GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, sstream));
-    GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
+  if (own) {
+    if (!large.empty() || !staged.empty()) {
+      GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[0], s_staged));
+      GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[0], 0));
+    }
+    if (!strip.empty()) {
+      GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[1], s_strip));
+      GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[1], 0));
+    }
   }
   GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+int gapro_fit_route(int32_t m, int32_t feat_dim) { return fit_route(m, feat_dim, 0); }
+
+int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
+  if (!ctx || !out) return GAPRO_ERR_BAD_ARG;
+  gapro_fit_timing* t = new (std::nothrow) gapro_fit_timing();
+  if (!t) return GAPRO_ERR_OOM;
+  for (int i = 0; i < 4; ++i)
+    if (hipEventCreate(&t->ev[i]) != hipSuccess) {
+      gapro_fit_timing_destroy(t);
+      return gapro_fail(ctx, GAPRO_ERR_HIP, "gapro_fit_timing_create: hipEventCreate failed");
+    }
+  *out = t;
+  return GAPRO_OK;
+}
+
+void gapro_fit_timing_destroy(gapro_fit_timing* t) {
+  if (!t) return;
+  for (int i = 0; i < 4; ++i)
+    if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
+  delete t;
+}
+
+int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t) {
+  if (!ctx) return GAPRO_ERR_BAD_ARG;
+  ctx->armed_timing = t;
+  if (t) t->used[0] = t->used[1] = false;
+  return GAPRO_OK;
+}
+
+int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms3) {
+  if (!ctx || !t || !out_ms3) return GAPRO_ERR_BAD_ARG;
+  out_ms3[0] = out_ms3[1] = out_ms3[2] = 0.f;
+  for (int k = 0; k < 2; ++k)
+    if (t->used[k]) {
+      GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[2 * k + 1]));
+      GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&out_ms3[k], t->ev[2 * k], t->ev[2 * k + 1]));
+    }
+  if (t->used[0] && t->used[1]) {
+    float s01 = 0.f;  // strip start relative to staged start
+    GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&s01, t->ev[0], t->ev[2]));
+    const float lo = s01 < 0.f ? s01 : 0.f;
+    const float e0 = out_ms3[0], e1 = s01 + out_ms3[1];
+    out_ms3[2] = (e0 > e1 ? e0 : e1) - lo;
+  } else {
+    out_ms3[2] = t->used[0] ? out_ms3[0] : out_ms3[1];
+  }
   return GAPRO_OK;
 }
 

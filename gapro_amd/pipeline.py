@@ -106,18 +106,48 @@ def make_job(coords_float, mask_feats, spp, instance_cls, instance_box, instance
                     int(instance_classes), float(ground_h), float(thresh_spp_occu))
 
 
-def fit_flops(descs, n_fits: int, feat_dim: int, training_iter: int) -> float:
-    """Algorithmic FLOPs of a fit batch, SURVEY.md section 8(d):
+def _desc_table(descs, n_fits: int) -> np.ndarray:
+    return np.frombuffer(descs, dtype=np.int32, count=n_fits * (C.sizeof(FitDesc) // 4)).reshape(n_fits, -1)
+
+
+def fit_flops_each(descs, n_fits: int, feat_dim: int, training_iter: int) -> np.ndarray:
+    """Algorithmic FLOPs of every fit of a batch, SURVEY.md section 8(d):
     F_fit = I (8.33 M^3 + 12 D M^2) + (M^3/3 + 2 M^2 T + 2 D (M^2 + M T)),  M = m1 + m2."""
     if n_fits <= 0:
-        return 0.0
-    raw = np.frombuffer(descs, dtype=np.int32, count=n_fits * (C.sizeof(FitDesc) // 4)).reshape(n_fits, -1)
+        return np.zeros(0)
+    raw = _desc_table(descs, n_fits)
     m = (raw[:, 0] + raw[:, 1]).astype(np.float64)
     t = raw[:, 2].astype(np.float64)
     d = float(feat_dim)
-    per_fit = training_iter * (8.33 * m**3 + 12.0 * d * m * m) + (m**3 / 3.0 + 2.0 * m * m * t
-                                                                  + 2.0 * d * (m * m + m * t))
-    return float(per_fit.sum())
+    return training_iter * (8.33 * m**3 + 12.0 * d * m * m) + (m**3 / 3.0 + 2.0 * m * m * t + 2.0 * d * (m * m + m * t))
+
+
+def fit_flops(descs, n_fits: int, feat_dim: int, training_iter: int) -> float:
+    return float(fit_flops_each(descs, n_fits, feat_dim, training_iter).sum())
+
+
+class FitTiming:
+    """Device-side timing of one fit launch (gapro_fit_timing): HIP events recorded by the library on the
+    streams its kernels run on.  read() blocks until the launch has finished."""
+
+    def __init__(self, ctx, handle, flops_strip, flops_staged, m):
+        self.ctx, self.handle = ctx, handle
+        self.flops_strip, self.flops_staged, self.m = flops_strip, flops_staged, m
+        self.ms = None
+
+    @property
+    def flops(self):
+        return self.flops_strip + self.flops_staged
+
+    def read(self):
+        """(staged kernel ms, strip kernel ms, first start -> last end ms)"""
+        if self.ms is None:
+            out = (C.c_float * 3)()
+            self.ctx.check(self.ctx.lib.gapro_fit_timing_read(self.ctx.handle, self.handle, out))
+            self.ms = (float(out[0]), float(out[1]), float(out[2]))
+            self.ctx.lib.gapro_fit_timing_destroy(self.handle)
+            self.handle = None
+        return self.ms
 
 
 class Pipeline:
@@ -139,12 +169,14 @@ class Pipeline:
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap
         self.last_stats = {}
+        self.trace = None  # set to a list to collect (time, batch id, stage) host timestamps
         # optional HIP-event timing of the fit launches (bench.py): list of (start_event, end_event, flops)
         self.profile_fit = False
         self.fit_events = []
         self.profile_stages = False  # bench.py --stage-times: synchronising per-stage wall clock
         self.stage_times = {}
         self._pin_cache = {}
+        self._pin_events = {}
 
     # ------------------------------------------------------------------ stage A
     def _prepare_launch(self, job: SceneJob, hdr_ptr: int):
@@ -244,24 +276,44 @@ class Pipeline:
         return self._finish(self._start(jobs, keep_debug))
 
     def run_pipelined(self, batches: Sequence[Sequence[SceneJob]]):
-        """Several batches back to back, software-pipelined over two HIP streams: while the fit launch of
-        batch i occupies the GPU, the host enumerates the schedule of batch i+1 (and its partition
-        kernels slot in between fit workgroups).  Same results as run() batch by batch."""
+        """Several batches back to back, software-pipelined.  The fit workgroups fill every CU for the whole
+        launch and the short partition / broadcast kernels cannot be dispatched beside them (measured: they
+        wait for the launch to drain, whatever the stream priorities), so the order is built around that:
+
+            partition(i+1) on the idle GPU -> launch fit(i) -> while it runs, on the host: schedule(i+1),
+            merge(i-1); broadcast(i-1) is enqueued without waiting for it
+
+        Only the partition kernels (and their two host round trips) are left between two fit launches.
+        Same results as run() batch by batch."""
         if not hasattr(self, "_streams"):
             self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-        outs, prev = [], None
-        for i, jobs in enumerate(batches):
-            stream = self._streams[i % 2]
-            stream.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(stream):
-                cur = self._start(jobs, False)
-            if prev is not None:
-                with torch.cuda.stream(prev["stream"]):
-                    outs.append(self._finish(prev))
-            prev = cur
-        if prev is not None:
-            with torch.cuda.stream(prev["stream"]):
-                outs.append(self._finish(prev))
+        outs = []
+        # inputs produced on the caller's stream are ordered before both pipeline streams ONCE: an event on
+        # the (legacy default) stream recorded per batch would also wait for every blocking stream
+        ready = torch.cuda.current_stream(self.device).record_event()
+        for st in self._streams:
+            st.wait_event(ready)
+        n = len(batches)
+        states = [None] * n
+
+        def on(i, fn, *a):
+            with torch.cuda.stream(self._streams[i % 2]):
+                return fn(*a)
+
+        if n:
+            states[0] = on(0, self._partition, batches[0], False)
+            on(0, self._schedule_all, states[0])
+        for i in range(n):
+            if i + 1 < n:
+                states[i + 1] = on(i + 1, self._partition, batches[i + 1], False)
+            on(i, self._launch, states[i])
+            if i + 1 < n:
+                on(i + 1, self._schedule_all, states[i + 1])
+            if i > 0:
+                outs.append(on(i - 1, self._finish, states[i - 1], False))
+                states[i - 1] = None
+        if n:
+            outs.append(on(n - 1, self._finish, states[n - 1], True))
         for st in self._streams:
             torch.cuda.current_stream(self.device).wait_stream(st)
         return outs
@@ -276,19 +328,33 @@ class Pipeline:
 
     def _start(self, jobs: Sequence[SceneJob], keep_debug: bool = False):
         """Stages A-D: everything up to and including the (asynchronous) fit launch."""
-        lib, devc = self.lib, self.device
+        state = self._partition(jobs, keep_debug)
+        self._schedule_all(state)
+        self._launch(state)
+        return state
+
+    def _marker(self, jobs):
         import time as _time
-        _t = [_time.perf_counter()]
+        t = [_time.perf_counter()]
 
         def _mark(name):
+            if self.trace is not None:  # host-side timeline, no synchronisation added
+                self.trace.append((_time.perf_counter(), id(jobs) & 0xFFFF, name))
             if self.profile_stages:
-                torch.cuda.synchronize(devc)
+                torch.cuda.synchronize(self.device)
                 now = _time.perf_counter()
-                self.stage_times[name] = self.stage_times.get(name, 0.0) + (now - _t[0])
-                _t[0] = now
+                self.stage_times[name] = self.stage_times.get(name, 0.0) + (now - t[0])
+                t[0] = now
 
+        return _mark
+
+    def _partition(self, jobs: Sequence[SceneJob], keep_debug: bool = False):
+        """Stages A-B on the current stream: superpoint ids, pooled features, occupancy tables on the host."""
+        devc = self.device
+        _mark = self._marker(jobs)
         stream = torch.cuda.current_stream(devc)
         slot = "s%x" % int(stream.cuda_stream)
+        _mark("start")
         self._prepare_all(jobs)
         _mark("A prepare")
         D = int(jobs[0].feats.shape[1])
@@ -307,11 +373,16 @@ class Pipeline:
             off = self._pool(job, feats_spp_all, stage, off)
         stream.synchronize()  # one sync: pooled tables of every scene are on the host
         _mark("B pool")
+        return dict(jobs=jobs, stream=stream, keep_debug=keep_debug, mark=_mark, feats_spp_all=feats_spp_all,
+                    slot=slot, pending=None, n_fits=0, n_out=0)
+
+    def _schedule_all(self, state):
+        """Stage C (host only): static pair schedule of every scene, fit descriptors of the whole batch."""
+        lib = self.lib
+        jobs, _mark = state["jobs"], state["mark"]
         for job in jobs:
             self._schedule(job)
         _mark("C schedule")
-
-        # ---- stage D: one launch for every fit of every scene
         n_fits = sum(j.counts.n_fits for j in jobs)
         n_idx = sum(j.counts.n_fit_idx for j in jobs)
         n_out = sum(j.counts.n_fit_out for j in jobs)
@@ -330,21 +401,29 @@ class Pipeline:
             io += job.counts.n_fit_idx
             oo += job.counts.n_fit_out
         _mark("C export")
-        pending = None
-        if n_fits:
-            pending = self.fit_launch(feats_spp_all, descs, n_fits, h_idx, n_out, keep_debug=keep_debug, slot=slot)
-        return dict(jobs=jobs, n_fits=n_fits, n_out=n_out, pending=pending, stream=stream, keep_debug=keep_debug,
-                    mark=_mark, feats_spp_all=feats_spp_all, slot=slot)
+        state.update(n_fits=n_fits, n_out=n_out, descs=descs, h_idx=h_idx)
 
-    def _finish(self, state):
-        """Stages E-F: wait for the fit results, ordered merge on the host, broadcast on the device."""
+    def _launch(self, state):
+        """Stage D: one (asynchronous) launch for every fit of every scene."""
+        if state["n_fits"]:
+            state["pending"] = self.fit_launch(state["feats_spp_all"], state["descs"], state["n_fits"], state["h_idx"],
+                                               state["n_out"], keep_debug=state["keep_debug"], slot=state["slot"])
+        state["mark"]("D launched")
+
+    def _finish(self, state, sync: bool = True):
+        """Stages E-F: wait for the fit results, ordered merge on the host, broadcast on the device.  With
+        sync=False the broadcast kernels are only enqueued (the outputs are ordered on the current stream)."""
         lib, ctx, devc = self.lib, self.ctx, self.device
         jobs, keep_debug, _mark = state["jobs"], state["keep_debug"], state["mark"]
+        _mark("finish")
         res = self.fit_collect(state["pending"]) if state["pending"] is not None else None
         _mark("D fit")
         tot_s = sum(job.n_spps for job in jobs)
-        tables = self._pinned(state["slot"] + "labels", tot_s * 12)
-        d_tables = torch.empty(tot_s * 12, dtype=torch.uint8, device=devc)
+        tables = self._pinned(state["slot"] + "labels", tot_s * 20)
+        busy = self._pin_events.pop(state["slot"] + "labels", None)
+        if busy is not None:
+            busy.synchronize()  # the previous batch of this slot has uploaded its label tables
+        d_tables = torch.empty(tot_s * 20, dtype=torch.uint8, device=devc)
         tab_np = tables.numpy()
         views, off = [], 0
         for job in jobs:
@@ -352,8 +431,8 @@ class Pipeline:
             sem_spp = tab_np[off:off + 4 * S].view(np.int32)
             inst_spp = tab_np[off + 4 * S:off + 8 * S].view(np.int32)
             prob_spp = tab_np[off + 8 * S:off + 12 * S].view(np.float32)
-            mu_spp = np.empty(S, np.float32)
-            var_spp = np.empty(S, np.float32)
+            mu_spp = tab_np[off + 12 * S:off + 16 * S].view(np.float32)
+            var_spp = tab_np[off + 16 * S:off + 20 * S].view(np.float32)
             if job.counts.n_fits:
                 a, b = job.out_base, job.out_base + job.counts.n_fit_out
                 pn, lb, mu, var = (res["probs_new"][a:b], res["labels"][a:b], res["mu"][a:b], res["var"][a:b])
@@ -365,11 +444,12 @@ class Pipeline:
                                           _ptr(mu_spp), _ptr(var_spp))
             if rc != 0:
                 raise _lib.GaproError(rc, "gapro_schedule_merge")
-            views.append((off, mu_spp, var_spp))
+            views.append(off)
             job.host.update(sem_spp=sem_spp.copy(), inst_spp=inst_spp.copy(), prob_spp=prob_spp.copy())
-            off += 12 * S
-        d_tables.copy_(tables[:tot_s * 12], non_blocking=True)  # one H2D copy for the whole batch
-        for job, (off, mu_spp, var_spp) in zip(jobs, views):
+            off += 20 * S
+        d_tables.copy_(tables[:tot_s * 20], non_blocking=True)  # one H2D copy for the whole batch
+        self._pin_events[state["slot"] + "labels"] = torch.cuda.current_stream(devc).record_event()
+        for job, off in zip(jobs, views):
             S, n = job.n_spps, job.n_points
             d_sem_spp = d_tables[off:off + 4 * S].view(torch.int32)
             d_inst_spp = d_tables[off + 4 * S:off + 8 * S].view(torch.int32)
@@ -380,11 +460,13 @@ class Pipeline:
             ctx.check(lib.gapro_broadcast_labels(ctx.handle, _stream_handle(devc), n, _ptr(job.spp_inv),
                                                  _ptr(d_sem_spp), _ptr(d_inst_spp), _ptr(d_prob_spp), _ptr(sem),
                                                  _ptr(ins), _ptr(prb)))
-            job.outputs = (sem, ins, prb, torch.from_numpy(mu_spp).to(devc), torch.from_numpy(var_spp).to(devc))
+            job.outputs = (sem, ins, prb, d_tables[off + 12 * S:off + 16 * S].view(torch.float32),
+                           d_tables[off + 16 * S:off + 20 * S].view(torch.float32))
             if not keep_debug:
                 lib.gapro_schedule_free(job.schedule)
                 job.schedule = None
-        torch.cuda.current_stream(devc).synchronize()  # the pinned label tables are reused by the next batch
+        if sync:
+            torch.cuda.current_stream(devc).synchronize()
         _mark("E+F merge/broadcast")
         self.last_stats = dict(n_fits=state["n_fits"], n_fit_out=state["n_out"], fit=res)
         return [j.outputs for j in jobs]
@@ -421,18 +503,22 @@ class Pipeline:
         loss = stat[0:8 * n_fits].view(torch.float64)
         status = stat[8 * n_fits:12 * n_fits].view(torch.int32)
         if self.profile_fit:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record(torch.cuda.current_stream(devc))
+            tm = C.c_void_p()
+            ctx.check(lib.gapro_fit_timing_create(ctx.handle, C.byref(tm)))
+            ctx.check(lib.gapro_fit_timing_arm(ctx.handle, tm))
         ctx.check(lib.gapro_svgp_fit_batch(
             ctx.handle, _stream_handle(devc), n_fits, D, _ptr(feats_spp), _ptr(d_idx), C.cast(descs, C.c_void_p),
             _ptr(d_descs), _ptr(d_init),
             C.byref(self.opt), _ptr(ws), ws_bytes, _ptr(probs), _ptr(probs_new), _ptr(labels), _ptr(mu), _ptr(var),
             _ptr(status), _ptr(loss)))
         if self.profile_fit:
-            ev1.record(torch.cuda.current_stream(devc))
-            self.fit_events.append((ev0, ev1, fit_flops(descs, n_fits, D, int(self.opt.training_iter))))
-            raw = np.frombuffer(descs, dtype=np.int32, count=n_fits * (C.sizeof(FitDesc) // 4)).reshape(n_fits, -1)
-            self.last_fit_m = (raw[:, 0] + raw[:, 1]).copy()
+            each = fit_flops_each(descs, n_fits, D, int(self.opt.training_iter))
+            raw = _desc_table(descs, n_fits)
+            m = (raw[:, 0] + raw[:, 1]).copy()
+            route = {int(v): int(lib.gapro_fit_route(int(v), D)) for v in np.unique(m)}
+            is_strip = np.array([route[int(v)] == 0 for v in m]) & (int(self.opt.reserved) & 1 == 0)
+            self.fit_events.append(FitTiming(ctx, tm, float(each[is_strip].sum()), float(each[~is_strip].sum()), m))
+            self.last_fit_m = m
         # results travel to pinned host memory on the same stream; nobody waits here
         h_out = self._pinned(slot + "fit_out", no * 17)
         h_stat = self._pinned(slot + "fit_stat", n_fits * 12)

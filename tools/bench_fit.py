@@ -78,9 +78,12 @@ def run_mix(pipe, args):
         with torch.cuda.stream(torch.cuda.Stream() if args.own_stream else torch.cuda.current_stream()):
             pipe.fit_descs(feats, descs, n, h_idx, oo)
         torch.cuda.synchronize()
-        e0, e1, fl = pipe.fit_events[0]
+        ev = pipe.fit_events[0]
+        fl = ev.flops
         if r > 0:
-            times.append(e0.elapsed_time(e1))
+            times.append(ev.read()[2])
+        else:
+            ev.read()
     ms = float(np.median(times))
     print("mix %s fork=%s : %9.2f ms/launch  %9.1f fits/s  %7.3f TFLOP/s" % (args.mix, not args.no_fork, ms,
                                                                            n / (ms * 1e-3), fl / (ms * 1e-3) / 1e12))
@@ -146,9 +149,10 @@ def main():
             pipe.fit_events = []
             res = pipe.fit_descs(feats, descs, n, h_idx, oo, keep_debug=args.profile)
             torch.cuda.synchronize()
-            e0, e1, fl = pipe.fit_events[0]
+            ev = pipe.fit_events[0]
+            fl = ev.flops
             if r > 0:
-                times.append(e0.elapsed_time(e1))
+                times.append(ev.read()[2])
         ms = float(np.median(times))
         tf = fl / (ms * 1e-3) / 1e12
         print("M=%4d T=%3d D=%2d fits=%4d iters=%d : %9.2f ms/launch  %9.1f fits/s  %7.3f TFLOP/s  (%.2f%% of 78.6)  "
