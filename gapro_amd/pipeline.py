@@ -177,6 +177,7 @@ class Pipeline:
         self.stage_times = {}
         self._pin_cache = {}
         self._pin_events = {}
+        self._ws = {}  # slot -> fit workspace (device, float64)
 
     # ------------------------------------------------------------------ stage A
     def _prepare_launch(self, job: SceneJob, hdr_ptr: int):
@@ -287,6 +288,8 @@ class Pipeline:
         Same results as run() batch by batch."""
         if not hasattr(self, "_streams"):
             self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            for st in self._streams:
+                self._ws.setdefault("s%x" % int(st.cuda_stream), None)
         outs = []
         # inputs produced on the caller's stream are ordered before both pipeline streams ONCE: an event on
         # the (legacy default) stream recorded per batch would also wait for every blocking stream
@@ -317,6 +320,20 @@ class Pipeline:
         for st in self._streams:
             torch.cuda.current_stream(self.device).wait_stream(st)
         return outs
+
+    def _workspace(self, slot: str, n_doubles: int) -> torch.Tensor:
+        """Grow-only fit workspace per pipeline slot.  Every registered slot grows together and new memory is
+        touched once here: a slot first used inside a timed region would otherwise pay the allocation and the
+        first-touch mapping of several GB inside its fit kernel."""
+        self._ws.setdefault(slot, None)
+        cur = self._ws[slot]
+        if cur is None or cur.numel() < n_doubles:
+            size = int(n_doubles * 1.05) + 1024
+            for k in list(self._ws):
+                if self._ws[k] is None or self._ws[k].numel() < size:
+                    self._ws[k] = None  # release before growing
+                    self._ws[k] = torch.zeros(size, dtype=torch.float64, device=self.device)
+        return self._ws[slot][:n_doubles]
 
     def _pinned(self, tag: str, nbytes: int) -> torch.Tensor:
         """Growable page-locked staging buffers, reused across batches (hipHostMalloc is slow)."""
@@ -490,7 +507,7 @@ class Pipeline:
         d_idx = torch.from_numpy(h_idx).to(devc)
         d_init = torch.from_numpy(np.ascontiguousarray(init_mean, dtype=np.float64)).to(devc) \
             if init_mean is not None else None
-        ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=devc)
+        ws = self._workspace(slot, ws_bytes // 8)
         no = max(n_out, 1)
         # per-test-superpoint outputs in one device block: probs f32 | probs_new f32 | mu f32 | var f32 | labels u8
         out = torch.empty(no * 17, dtype=torch.uint8, device=devc)
@@ -544,7 +561,7 @@ class Pipeline:
                    labels=raw[16 * no:17 * no].copy(), loss=st_raw[0:8 * n_fits].view(np.float64).copy(), status=st,
                    ws_bytes=p["ws_bytes"])
         if p["ws"] is not None:
-            res["workspace"] = p["ws"]
+            res["workspace"] = p["ws"].clone()  # the slot's workspace is reused by the next launch
             res["descs"] = p["descs"]
         p["keep"] = None
         return res

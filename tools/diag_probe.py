@@ -10,8 +10,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-sys.argv = [sys.argv[0]]
-from tools.bench_fit import build_mix  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_fit import build_mix  # noqa: E402
 from gapro_amd.pipeline import Pipeline  # noqa: E402
 
 

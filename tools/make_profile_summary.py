@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Turn one tools/run_measure.sh output directory into the committed profile files:
+
+    python tools/make_profile_summary.py gpurun_out/<tag> <tag> [--scenes-per-step 64 --points 150000 --feat-dim 6]
+
+writes profiles/<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc_summary.txt, <tag>_pmc_traffic.json (HBM bytes
+per launch of the fit kernels, corrected with the calibration run of the same pass) and <tag>_summary.md.
+"""
+import argparse
+import csv
+import json
+import os
+import re
+import shutil
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def counters(path):
+    acc = defaultdict(list)
+    if not os.path.exists(path):
+        return acc
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
+    return acc
+
+
+def mean_of(acc, key_substr, counter):
+    vals = [v for (k, c), vs in acc.items() if key_substr in k and c == counter for v in vs]
+    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("tag")
+    ap.add_argument("--scenes-per-step", type=int, default=64)
+    ap.add_argument("--points", type=int, default=150000)
+    ap.add_argument("--feat-dim", type=int, default=6)
+    a = ap.parse_args()
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    src = a.src
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, a.tag + "_bench.json"))
+    shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(out, a.tag + "_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "pmc_summary.txt"), os.path.join(out, a.tag + "_pmc_summary.txt"))
+    with open(os.path.join(src, "bench.json")) as fh:
+        bench = json.loads(fh.read().strip().splitlines()[-1])
+
+    # calibration: known byte counts -> bytes per counter unit
+    n_bytes = 8 * (1 << 26)
+    cf = counters(os.path.join(src, "calib_fetch", "calib_counter_collection.csv"))
+    cw = counters(os.path.join(src, "calib_write", "calib_counter_collection.csv"))
+    f_mean, f_n = mean_of(cf, "k_stream_calib", "FETCH_SIZE")   # every launch reads n_bytes
+    w_sum = sum(v for (k, c), vs in cw.items() if "k_stream_calib" in k and c == "WRITE_SIZE" for v in vs)
+    w_launches = sum(len(vs) for (k, c), vs in cw.items() if "k_stream_calib" in k and c == "WRITE_SIZE")
+    fetch_unit = n_bytes / f_mean if f_mean else None            # bytes per FETCH_SIZE unit in this access pattern
+    write_unit = n_bytes * (w_launches / 2) / w_sum if w_sum else None  # half of the launches (mode 1) write n_bytes
+    pf = counters(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"))
+    pw = counters(os.path.join(src, "pmc_write", "bench_counter_collection.csv"))
+    traffic = {"workload": {"scenes_per_step": a.scenes_per_step, "points": a.points, "feat_dim": a.feat_dim},
+               "calibration": {"kernel": "k_stream_calib (one double per lane, grid-stride, 512 MiB per pass)",
+                               "bytes_per_FETCH_SIZE_unit": fetch_unit, "bytes_per_WRITE_SIZE_unit": write_unit,
+                               "note": "guide: FETCH_SIZE is in KiB and reports half of a coalesced streaming read "
+                                       "on gfx950 (x2048 B per unit expected); WRITE_SIZE is KiB, exact (x1024)"}}
+    for key, sub in (("strip_kernel", "k_svgp_fit_strip"), ("staged_kernel", "k_svgp_fit<")):
+        fm, fn = mean_of(pf, sub, "FETCH_SIZE")
+        wm, wn = mean_of(pw, sub, "WRITE_SIZE")
+        if fm is None or wm is None or not fetch_unit or not write_unit:
+            continue
+        traffic[key] = {"launches_profiled": fn, "FETCH_SIZE_mean": fm, "WRITE_SIZE_mean": wm,
+                        "read_bytes_per_launch": fm * fetch_unit, "written_bytes_per_launch": wm * write_unit,
+                        "hbm_bytes_per_launch": fm * fetch_unit + wm * write_unit}
+    with open(os.path.join(out, a.tag + "_pmc_traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+
+    rows = []
+    with open(os.path.join(src, "stats", "bench_kernel_stats.csv")) as fh:
+        for r in csv.DictReader(fh):
+            name = re.sub(r"\(anonymous namespace\)::|void ", "", r["Name"]).split("(")[0]
+            rows.append((name, int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6,
+                         float(r["Percentage"])))
+    rl = bench["roofline"]
+    fl = bench.get("fit_launch", {})
+    md = ["# rocprofv3 summary, %s" % a.tag, "",
+          "Commands (on the MI355X box, see tools/run_measure.sh):", "",
+          "    python bench.py                                   -> %s_bench.json" % a.tag,
+          "    rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   -> %s_kernel_stats.csv" % a.tag,
+          "    rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+          "    rocprofv3 --kernel-trace --pmc WRITE_SIZE -- (same)            -> %s_pmc_summary.txt, %s_pmc_traffic.json" % (a.tag, a.tag),
+          "    rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/pmc_calib.py   (calibration, same file)", "",
+          "Workload: %s" % bench["config"]["workload"], "",
+          "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+    for name, calls, avg, tot, pct in rows[:14]:
+        md.append("| %s | %d | %.1f | %.2f | %.2f |" % (name, calls, avg, tot, pct))
+    md += ["",
+           "bench.py (un-profiled run): %.1f scenes/s, %.1f ms per step of %d scenes; dominant kernel %s: avg launch "
+           "%.2f ms by HIP events on its stream, %.3g algorithmic FLOP per launch -> %.2f TFLOP/s = %.1f %% of the %.1f "
+           "TFLOP/s FP64 MFMA peak." % (bench["value"], bench["ms_per_step"], bench["config"]["scenes_per_step_per_gpu"],
+                                       rl["kernel"].split(" ")[0], rl["avg_launch_ms"], rl["flops_per_launch"],
+                                       rl["achieved"], 100 * rl["frac"], rl["peak"]),
+           "Whole fit launch (strip + staged kernel side by side): %.2f ms, %.2f TFLOP/s, %.0f fits/s."
+           % (fl.get("avg_ms_first_start_to_last_end", 0), fl.get("tflops", 0), fl.get("fits_per_s", 0)), ""]
+    if "strip_kernel" in traffic:
+        t = traffic["strip_kernel"]
+        ms = rl["avg_launch_ms"]
+        md += ["HBM traffic of the strip kernel (PMC, corrected by the calibration pass: %.0f B per FETCH_SIZE unit, "
+               "%.0f B per WRITE_SIZE unit): %.1f GB read + %.1f GB written per launch = %.2f TB/s over the %.1f ms "
+               "launch (HBM peak 8 TB/s, ~6.3 achievable); algorithmic FLOP / HBM byte = %.2f."
+               % (fetch_unit, write_unit, t["read_bytes_per_launch"] / 1e9, t["written_bytes_per_launch"] / 1e9,
+                  t["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e12, ms, rl["flops_per_launch"] / t["hbm_bytes_per_launch"]), ""]
+    with open(os.path.join(out, a.tag + "_summary.md"), "w") as fh:
+        fh.write("\n".join(md))
+    print("\n".join(md))
+
+
+if __name__ == "__main__":
+    main()
