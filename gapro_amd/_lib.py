@@ -41,6 +41,17 @@ class FitDesc(C.Structure):
                 ("ws_offset", C.c_int64)]
 
 
+class SceneTask(C.Structure):
+    """gapro_scene_task: the device pointers of one scene of a batched partition call."""
+    _fields_ = [("n_points", C.c_int64), ("coords", C.c_void_p), ("feats", C.c_void_p), ("spp", C.c_void_p),
+                ("spp_inv", C.c_void_p), ("prepare_ws", C.c_void_p), ("spp_range_cap", C.c_int64),
+                ("boxes", C.c_void_p), ("n_boxes", C.c_int32), ("n_spps", C.c_int32), ("fixed_shift", C.c_int32),
+                ("thresh_spp_occu", C.c_float), ("feat_sum", C.c_void_p), ("occ_count", C.c_void_p),
+                ("point_count", C.c_void_p), ("feats_spp", C.c_void_p), ("occ_bits", C.c_void_p),
+                ("n_bbs", C.c_void_p), ("sem_spp", C.c_void_p), ("inst_spp", C.c_void_p), ("prob_spp", C.c_void_p),
+                ("sem", C.c_void_p), ("inst", C.c_void_p), ("prob", C.c_void_p)]
+
+
 class FitOptions(C.Structure):
     _fields_ = [("training_iter", C.c_int32), ("lr", C.c_double), ("jitter", C.c_double),
                 ("min_variance", C.c_double), ("eval_stale_chol", C.c_int32), ("reserved", C.c_int32)]
@@ -61,6 +72,9 @@ SIGNATURES = {
     "gapro_partition_pool": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                        _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_broadcast_labels": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "gapro_partition_prepare_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "gapro_partition_pool_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "gapro_broadcast_labels_batch": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "gapro_schedule_build": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(_P)]),
     "gapro_schedule_free": (None, [_P]),
     "gapro_schedule_get_counts": (C.c_int, [_P, C.POINTER(ScheduleCounts)]),

@@ -8,6 +8,8 @@
 
 #include "../../include/gapro_hip.h"
 
+constexpr unsigned kTaskRing = 1024;
+
 struct gapro_ctx {
   int device = 0;
   int n_cu = 0;
@@ -17,6 +19,11 @@ struct gapro_ctx {
   // the few large fits of the staged kernel and the strip kernel share the GPU.
   hipStream_t fit_stream[2] = {nullptr, nullptr};
   hipEvent_t ev_join[2] = {nullptr, nullptr};
+  // single-scene partition calls stage their one-task batch through this ring (pinned host + device mirror);
+  // a slot is reused after kTaskRing further calls, long after the stream has consumed it
+  gapro_scene_task* h_task_ring = nullptr;
+  gapro_scene_task* d_task_ring = nullptr;
+  unsigned task_pos = 0;
   struct gapro_fit_timing* armed_timing = nullptr;  // consumed by the next gapro_svgp_fit_batch
 };
 

@@ -24,6 +24,11 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
     delete ctx;
     return GAPRO_ERR_OOM;
   }
+  if (hipHostMalloc((void**)&ctx->h_task_ring, kTaskRing * sizeof(gapro_scene_task), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void**)&ctx->d_task_ring, kTaskRing * sizeof(gapro_scene_task)) != hipSuccess) {
+    gapro_ctx_destroy(ctx);
+    return GAPRO_ERR_OOM;
+  }
   for (int k = 0; k < 2; ++k)
     if (hipStreamCreateWithFlags(&ctx->fit_stream[k], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) != hipSuccess) {
@@ -37,6 +42,8 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
 void gapro_ctx_destroy(gapro_ctx* ctx) {
   if (!ctx) return;
   if (ctx->h_header_pinned) (void)hipHostFree(ctx->h_header_pinned);
+  if (ctx->h_task_ring) (void)hipHostFree(ctx->h_task_ring);
+  if (ctx->d_task_ring) (void)hipFree(ctx->d_task_ring);
   for (int k = 0; k < 2; ++k) {
     if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     if (ctx->fit_stream[k]) (void)hipStreamDestroy(ctx->fit_stream[k]);

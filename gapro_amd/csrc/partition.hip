@@ -7,6 +7,8 @@
 // LDS, integer atomics for the per-superpoint tallies (bit-reproducible, order-independent).
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -24,6 +26,9 @@ struct PrepareWorkspace {  // device layout, all offsets 16-byte aligned
   gapro_scene_header header;
   StatsPartial partials[kMaxStatBlocks];
 };
+
+static_assert(sizeof(gapro_scene_task) == 176, "gapro_scene_task layout is part of the ABI (ctypes mirror)");
+constexpr size_t kFlagsOffset = (sizeof(PrepareWorkspace) + 255) / 256 * 256;
 
 __device__ inline double wave_min(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
@@ -53,10 +58,22 @@ __device__ inline float wave_max_f(float v) {
 }
 
 // ---- K1: per-block partial statistics ---------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_stats(long long n, int d, const double* __restrict__ coords,
-                                                    const float* __restrict__ feats,
-                                                    const long long* __restrict__ spp,
-                                                    StatsPartial* __restrict__ partials) {
+// Every kernel below handles scene blockIdx.y of a batch: its pointers come from tasks[blockIdx.y].
+__device__ inline PrepareWorkspace* prep_ws(const gapro_scene_task& t) { return (PrepareWorkspace*)t.prepare_ws; }
+__device__ inline unsigned* prep_flags(const gapro_scene_task& t) {
+  return (unsigned*)((char*)t.prepare_ws + kFlagsOffset);
+}
+__device__ inline unsigned* prep_bsum(const gapro_scene_task& t) {
+  return (unsigned*)((char*)t.prepare_ws + kFlagsOffset + ((size_t)t.spp_range_cap * sizeof(unsigned) + 255) / 256 * 256);
+}
+
+__global__ __launch_bounds__(kThreads) void k_stats(const gapro_scene_task* __restrict__ tasks, int d) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long n = t.n_points;
+  const double* __restrict__ coords = t.coords;
+  const float* __restrict__ feats = t.feats;
+  const long long* __restrict__ spp = (const long long*)t.spp;
+  StatsPartial* __restrict__ partials = prep_ws(t)->partials;
   const long long tid = (long long)blockIdx.x * kThreads + threadIdx.x;
   const long long stride = (long long)gridDim.x * kThreads;
   double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -96,8 +113,11 @@ __global__ __launch_bounds__(kThreads) void k_stats(long long n, int d, const do
 }
 
 // ---- K1b: fold partials into the scene header --------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_stats_final(long long n, int n_partials, long long range_cap,
-                                                          PrepareWorkspace* ws) {
+__global__ __launch_bounds__(kThreads) void k_stats_final(const gapro_scene_task* __restrict__ tasks, int n_partials,
+                                                          gapro_scene_header* __restrict__ headers) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long n = t.n_points, range_cap = t.spp_range_cap;
+  PrepareWorkspace* ws = prep_ws(t);
   double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   long long smin = 0x7fffffffffffffffLL, smax = -0x7fffffffffffffffLL - 1;
   float fa = 0.f;
@@ -142,12 +162,27 @@ __global__ __launch_bounds__(kThreads) void k_stats_final(long long n, int n_par
   const unsigned long long range = (unsigned long long)p.smax - (unsigned long long)p.smin;
   if (range >= (unsigned long long)range_cap) h.status = GAPRO_ERR_SPP_RANGE;
   ws->header = h;
+  headers[blockIdx.y] = h;
 }
 
 // ---- K2: presence flags -------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_flags(long long n, const long long* __restrict__ spp,
-                                                    const PrepareWorkspace* __restrict__ ws,
-                                                    unsigned* __restrict__ flags) {
+// zero the flag words of the id range actually present (after the statistics are known)
+__global__ __launch_bounds__(kThreads) void k_clear_flags(const gapro_scene_task* __restrict__ tasks) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const PrepareWorkspace* ws = prep_ws(t);
+  if (ws->header.status != GAPRO_OK) return;
+  const long long range = ws->header.spp_max - ws->header.spp_min + 1;
+  unsigned* __restrict__ flags = prep_flags(t);
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < range; i += stride) flags[i] = 0u;
+}
+
+__global__ __launch_bounds__(kThreads) void k_flags(const gapro_scene_task* __restrict__ tasks) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long n = t.n_points;
+  const long long* __restrict__ spp = (const long long*)t.spp;
+  const PrepareWorkspace* ws = prep_ws(t);
+  unsigned* __restrict__ flags = prep_flags(t);
   if (ws->header.status != GAPRO_OK) return;
   const long long smin = ws->header.spp_min;
   const long long stride = (long long)gridDim.x * kThreads;
@@ -175,9 +210,11 @@ __device__ inline unsigned block_exclusive_scan(unsigned v, unsigned* total) {
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(kThreads) void k_scan_blocksum(const PrepareWorkspace* __restrict__ ws,
-                                                            const unsigned* __restrict__ flags,
-                                                            unsigned* __restrict__ bsum) {
+__global__ __launch_bounds__(kThreads) void k_scan_blocksum(const gapro_scene_task* __restrict__ tasks) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const PrepareWorkspace* ws = prep_ws(t);
+  const unsigned* __restrict__ flags = prep_flags(t);
+  unsigned* __restrict__ bsum = prep_bsum(t);
   if (ws->header.status != GAPRO_OK) return;
   const long long range = ws->header.spp_max - ws->header.spp_min + 1;
   const long long base = (long long)blockIdx.x * kScanChunk;
@@ -192,8 +229,11 @@ __global__ __launch_bounds__(kThreads) void k_scan_blocksum(const PrepareWorkspa
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(kThreads) void k_scan_offsets(PrepareWorkspace* __restrict__ ws,
-                                                           unsigned* __restrict__ bsum) {
+__global__ __launch_bounds__(kThreads) void k_scan_offsets(const gapro_scene_task* __restrict__ tasks,
+                                                           gapro_scene_header* __restrict__ headers) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  PrepareWorkspace* ws = prep_ws(t);
+  unsigned* __restrict__ bsum = prep_bsum(t);
   if (ws->header.status != GAPRO_OK) return;
   const long long range = ws->header.spp_max - ws->header.spp_min + 1;
   const int nb = (int)((range + kScanChunk - 1) / kScanChunk);
@@ -206,12 +246,17 @@ __global__ __launch_bounds__(kThreads) void k_scan_offsets(PrepareWorkspace* __r
     if (i < nb) bsum[i] = carry + ex;
     carry += tot;
   }
-  if (threadIdx.x == 0) ws->header.n_spps = (int)carry;
+  if (threadIdx.x == 0) {
+    ws->header.n_spps = (int)carry;
+    headers[blockIdx.y].n_spps = (int)carry;
+  }
 }
 
-__global__ __launch_bounds__(kThreads) void k_scan_final(const PrepareWorkspace* __restrict__ ws,
-                                                         unsigned* __restrict__ flags_to_rank,
-                                                         const unsigned* __restrict__ bsum) {
+__global__ __launch_bounds__(kThreads) void k_scan_final(const gapro_scene_task* __restrict__ tasks) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const PrepareWorkspace* ws = prep_ws(t);
+  unsigned* __restrict__ flags_to_rank = prep_flags(t);
+  const unsigned* __restrict__ bsum = prep_bsum(t);
   if (ws->header.status != GAPRO_OK) return;
   const long long range = ws->header.spp_max - ws->header.spp_min + 1;
   const long long base = (long long)blockIdx.x * kScanChunk;
@@ -233,10 +278,13 @@ __global__ __launch_bounds__(kThreads) void k_scan_final(const PrepareWorkspace*
   }
 }
 
-__global__ __launch_bounds__(kThreads) void k_rank_lookup(long long n, const long long* __restrict__ spp,
-                                                          const PrepareWorkspace* __restrict__ ws,
-                                                          const unsigned* __restrict__ rank,
-                                                          int* __restrict__ spp_inv) {
+__global__ __launch_bounds__(kThreads) void k_rank_lookup(const gapro_scene_task* __restrict__ tasks) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long n = t.n_points;
+  const long long* __restrict__ spp = (const long long*)t.spp;
+  const PrepareWorkspace* ws = prep_ws(t);
+  const unsigned* __restrict__ rank = prep_flags(t);
+  int* __restrict__ spp_inv = t.spp_inv;
   if (ws->header.status != GAPRO_OK) return;
   const long long smin = ws->header.spp_min;
   const long long stride = (long long)gridDim.x * kThreads;
@@ -251,13 +299,29 @@ __global__ __launch_bounds__(kThreads) void k_rank_lookup(long long n, const lon
 // D%8 adds the point count, and lane k tests boxes k, k+8, ...  Box corners (with the +-0.005 margin
 // applied in float64, as gen_ps_utils.py:350 does) sit in LDS.
 constexpr int kLanesPerPoint = 8;
-__global__ __launch_bounds__(kThreads) void k_pool(long long n, int d, int nb, int shift,
-                                                   const double* __restrict__ coords,
-                                                   const float* __restrict__ feats,
-                                                   const int* __restrict__ spp_inv,
-                                                   const double* __restrict__ boxes,
-                                                   unsigned long long* __restrict__ feat_sum,
-                                                   int* __restrict__ occ_count, int* __restrict__ point_count) {
+// zero the integer tallies of every scene (feat_sum, occ_count, point_count)
+__global__ __launch_bounds__(kThreads) void k_pool_clear(const gapro_scene_task* __restrict__ tasks, int d) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long S = t.n_spps, nf = S * d, no = S * t.n_boxes;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nf + no + S; i += stride) {
+    if (i < nf) t.feat_sum[i] = 0;
+    else if (i < nf + no) t.occ_count[i - nf] = 0;
+    else t.point_count[i - nf - no] = 0;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_pool(const gapro_scene_task* __restrict__ tasks, int d) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long n = t.n_points;
+  const int nb = t.n_boxes, shift = t.fixed_shift;
+  const double* __restrict__ coords = t.coords;
+  const float* __restrict__ feats = t.feats;
+  const int* __restrict__ spp_inv = t.spp_inv;
+  const double* __restrict__ boxes = t.boxes;
+  unsigned long long* __restrict__ feat_sum = (unsigned long long*)t.feat_sum;
+  int* __restrict__ occ_count = t.occ_count;
+  int* __restrict__ point_count = t.point_count;
   extern __shared__ double sh_box[];  // [nb][6]: lo xyz, hi xyz
   for (int j = threadIdx.x; j < nb * 6; j += kThreads) {
     const int c = j % 6;
@@ -286,13 +350,16 @@ __global__ __launch_bounds__(kThreads) void k_pool(long long n, int d, int nb, i
 }
 
 // ---- K5: per-superpoint finalisation -----------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_pool_finalize(int n_spps, int d, int nb, int shift, float thresh,
-                                                            const long long* __restrict__ feat_sum,
-                                                            const int* __restrict__ occ_count,
-                                                            const int* __restrict__ point_count,
-                                                            float* __restrict__ feats_spp,
-                                                            unsigned long long* __restrict__ occ_bits,
-                                                            int* __restrict__ n_bbs) {
+__global__ __launch_bounds__(kThreads) void k_pool_finalize(const gapro_scene_task* __restrict__ tasks, int d) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const int n_spps = t.n_spps, nb = t.n_boxes, shift = t.fixed_shift;
+  const float thresh = t.thresh_spp_occu;
+  const long long* __restrict__ feat_sum = (const long long*)t.feat_sum;
+  const int* __restrict__ occ_count = t.occ_count;
+  const int* __restrict__ point_count = t.point_count;
+  float* __restrict__ feats_spp = t.feats_spp;
+  unsigned long long* __restrict__ occ_bits = (unsigned long long*)t.occ_bits;
+  int* __restrict__ n_bbs = t.n_bbs;
   const int s = blockIdx.x * kThreads + threadIdx.x;
   if (s >= n_spps) return;
   const int pc = point_count[s] > 0 ? point_count[s] : 1;  // torch_scatter clamps the count at 1
@@ -317,12 +384,16 @@ __global__ __launch_bounds__(kThreads) void k_pool_finalize(int n_spps, int d, i
 }
 
 // ---- K6: superpoint -> point broadcast ----------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_broadcast(long long n, const int* __restrict__ spp_inv,
-                                                        const int* __restrict__ sem_spp,
-                                                        const int* __restrict__ inst_spp,
-                                                        const float* __restrict__ prob_spp,
-                                                        int* __restrict__ sem, int* __restrict__ inst,
-                                                        float* __restrict__ prob) {
+__global__ __launch_bounds__(kThreads) void k_broadcast(const gapro_scene_task* __restrict__ tasks) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long n = t.n_points;
+  const int* __restrict__ spp_inv = t.spp_inv;
+  const int* __restrict__ sem_spp = t.sem_spp;
+  const int* __restrict__ inst_spp = t.inst_spp;
+  const float* __restrict__ prob_spp = t.prob_spp;
+  int* __restrict__ sem = t.sem;
+  int* __restrict__ inst = t.inst;
+  float* __restrict__ prob = t.prob;
   const long long stride = (long long)gridDim.x * kThreads;
   for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
     const int r = spp_inv[i];
@@ -353,6 +424,111 @@ size_t gapro_partition_prepare_workspace_bytes(int64_t n_points, int64_t spp_ran
   return bytes;
 }
 
+// ---- batched launches --------------------------------------------------------------------------
+static int check_tasks(gapro_ctx* ctx, const char* who, int32_t n_scenes, const gapro_scene_task* h_tasks,
+                       gapro_scene_task* d_tasks) {
+  if (!ctx) return GAPRO_ERR_BAD_ARG;
+  if (n_scenes <= 0 || n_scenes > 65535 || !h_tasks || !d_tasks)
+    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "%s: bad argument", who);
+  return GAPRO_OK;
+}
+
+int gapro_partition_prepare_batch(gapro_ctx* ctx, void* stream_, int32_t n_scenes, int32_t feat_dim,
+                                  const gapro_scene_task* h_tasks, gapro_scene_task* d_tasks,
+                                  gapro_scene_header* d_headers, gapro_scene_header* h_headers_pinned) {
+  int rc = check_tasks(ctx, "gapro_partition_prepare_batch", n_scenes, h_tasks, d_tasks);
+  if (rc != GAPRO_OK) return rc;
+  if (feat_dim <= 0 || !d_headers || !h_headers_pinned)
+    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_prepare_batch: bad argument");
+  long long n_max = 0, cap_max = 0;
+  for (int i = 0; i < n_scenes; ++i) {
+    const gapro_scene_task& t = h_tasks[i];
+    if (t.n_points <= 0 || !t.coords || !t.feats || !t.spp || !t.spp_inv || !t.prepare_ws || t.spp_range_cap < 1)
+      return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_prepare_batch: scene %d: bad argument", i);
+    n_max = std::max<long long>(n_max, t.n_points);
+    cap_max = std::max<long long>(cap_max, t.spp_range_cap);
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_tasks, h_tasks, (size_t)n_scenes * sizeof(gapro_scene_task),
+                                      hipMemcpyHostToDevice, stream));
+  const unsigned ny = (unsigned)n_scenes;
+  const int g_stats = grid_for(n_max, kMaxStatBlocks);
+  const int g_pts = grid_for(n_max);
+  const int g_scan = (int)((cap_max + kScanChunk - 1) / kScanChunk);
+  hipLaunchKernelGGL(k_stats, dim3(g_stats, ny), dim3(kThreads), 0, stream, d_tasks, (int)feat_dim);
+  hipLaunchKernelGGL(k_stats_final, dim3(1, ny), dim3(kThreads), 0, stream, d_tasks, g_stats, d_headers);
+  hipLaunchKernelGGL(k_clear_flags, dim3(grid_for(cap_max, 512), ny), dim3(kThreads), 0, stream, d_tasks);
+  hipLaunchKernelGGL(k_flags, dim3(g_pts, ny), dim3(kThreads), 0, stream, d_tasks);
+  hipLaunchKernelGGL(k_scan_blocksum, dim3(g_scan, ny), dim3(kThreads), 0, stream, d_tasks);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(1, ny), dim3(kThreads), 0, stream, d_tasks, d_headers);
+  hipLaunchKernelGGL(k_scan_final, dim3(g_scan, ny), dim3(kThreads), 0, stream, d_tasks);
+  hipLaunchKernelGGL(k_rank_lookup, dim3(g_pts, ny), dim3(kThreads), 0, stream, d_tasks);
+  GAPRO_LAUNCH_CHECK(ctx);
+  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(h_headers_pinned, d_headers, (size_t)n_scenes * sizeof(gapro_scene_header),
+                                      hipMemcpyDeviceToHost, stream));
+  return GAPRO_OK;
+}
+
+int gapro_partition_pool_batch(gapro_ctx* ctx, void* stream_, int32_t n_scenes, int32_t feat_dim,
+                               const gapro_scene_task* h_tasks, gapro_scene_task* d_tasks) {
+  int rc = check_tasks(ctx, "gapro_partition_pool_batch", n_scenes, h_tasks, d_tasks);
+  if (rc != GAPRO_OK) return rc;
+  long long n_max = 0, clear_max = 0;
+  int nb_max = 0, s_max = 0;
+  for (int i = 0; i < n_scenes; ++i) {
+    const gapro_scene_task& t = h_tasks[i];
+    if (t.n_points <= 0 || feat_dim <= 0 || t.n_boxes <= 0 || t.n_spps <= 0 || !t.coords || !t.feats || !t.spp_inv ||
+        !t.boxes || !t.feat_sum || !t.occ_count || !t.point_count || !t.feats_spp || !t.occ_bits || !t.n_bbs)
+      return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_pool_batch: scene %d: bad argument", i);
+    n_max = std::max<long long>(n_max, t.n_points);
+    nb_max = std::max(nb_max, (int)t.n_boxes);
+    s_max = std::max(s_max, (int)t.n_spps);
+    clear_max = std::max<long long>(clear_max, (long long)t.n_spps * (feat_dim + t.n_boxes + 1));
+  }
+  const size_t lds = (size_t)nb_max * 6 * sizeof(double);
+  if (lds > 64 * 1024) return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_pool: too many boxes (%d)", nb_max);
+  hipStream_t stream = (hipStream_t)stream_;
+  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_tasks, h_tasks, (size_t)n_scenes * sizeof(gapro_scene_task),
+                                      hipMemcpyHostToDevice, stream));
+  const unsigned ny = (unsigned)n_scenes;
+  hipLaunchKernelGGL(k_pool_clear, dim3(grid_for(clear_max, 256), ny), dim3(kThreads), 0, stream, d_tasks, (int)feat_dim);
+  // the whole batch shares the GPU: cap the per-scene grid so that the batch is a few waves of workgroups
+  const int cap = n_scenes >= 8 ? 512 : 4096;
+  hipLaunchKernelGGL(k_pool, dim3(grid_for(n_max * kLanesPerPoint, cap), ny), dim3(kThreads), lds, stream, d_tasks,
+                     (int)feat_dim);
+  hipLaunchKernelGGL(k_pool_finalize, dim3((s_max + kThreads - 1) / kThreads, ny), dim3(kThreads), 0, stream, d_tasks,
+                     (int)feat_dim);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+int gapro_broadcast_labels_batch(gapro_ctx* ctx, void* stream_, int32_t n_scenes, const gapro_scene_task* h_tasks,
+                                 gapro_scene_task* d_tasks) {
+  int rc = check_tasks(ctx, "gapro_broadcast_labels_batch", n_scenes, h_tasks, d_tasks);
+  if (rc != GAPRO_OK) return rc;
+  long long n_max = 0;
+  for (int i = 0; i < n_scenes; ++i) {
+    const gapro_scene_task& t = h_tasks[i];
+    if (t.n_points <= 0 || !t.spp_inv || !t.sem_spp || !t.inst_spp || !t.prob_spp || !t.sem || !t.inst || !t.prob)
+      return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_broadcast_labels_batch: scene %d: bad argument", i);
+    n_max = std::max<long long>(n_max, t.n_points);
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_tasks, h_tasks, (size_t)n_scenes * sizeof(gapro_scene_task),
+                                      hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_broadcast, dim3(grid_for(n_max, n_scenes >= 8 ? 256 : 2048), (unsigned)n_scenes), dim3(kThreads),
+                     0, stream, d_tasks);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+// ---- single-scene forms: the same kernels with a one-task batch staged through the context's ring --
+static gapro_scene_task* ring_slot(gapro_ctx* ctx, gapro_scene_task** h_slot) {
+  const unsigned i = ctx->task_pos++ % kTaskRing;
+  *h_slot = ctx->h_task_ring + i;
+  return ctx->d_task_ring + i;
+}
+
 int gapro_partition_prepare_async(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_t feat_dim,
                                   const double* d_coords, const float* d_feats, const int64_t* d_spp,
                                   int64_t spp_range_cap, void* d_workspace, size_t workspace_bytes,
@@ -363,31 +539,14 @@ int gapro_partition_prepare_async(gapro_ctx* ctx, void* stream_, int64_t n_point
     return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_prepare: bad argument");
   if (workspace_bytes < gapro_partition_prepare_workspace_bytes(n_points, spp_range_cap))
     return gapro_fail(ctx, GAPRO_ERR_WORKSPACE, "gapro_partition_prepare: workspace too small");
-  hipStream_t stream = (hipStream_t)stream_;
-  char* base = (char*)d_workspace;
-  PrepareWorkspace* ws = (PrepareWorkspace*)base;
-  unsigned* flags = (unsigned*)(base + align_up(sizeof(PrepareWorkspace), 256));
-  unsigned* bsum = (unsigned*)((char*)flags + align_up((size_t)spp_range_cap * sizeof(unsigned), 256));
-
-  const int g_stats = grid_for(n_points, kMaxStatBlocks);
-  hipLaunchKernelGGL(k_stats, dim3(g_stats), dim3(kThreads), 0, stream, (long long)n_points, (int)feat_dim, d_coords,
-                     d_feats, (const long long*)d_spp, ws->partials);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(kThreads), 0, stream, (long long)n_points, g_stats,
-                     (long long)spp_range_cap, ws);
-  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, (size_t)spp_range_cap * sizeof(unsigned), stream));
-  const int g_pts = grid_for(n_points);
-  hipLaunchKernelGGL(k_flags, dim3(g_pts), dim3(kThreads), 0, stream, (long long)n_points, (const long long*)d_spp, ws,
-                     flags);
-  const int g_scan = (int)((spp_range_cap + kScanChunk - 1) / kScanChunk);
-  hipLaunchKernelGGL(k_scan_blocksum, dim3(g_scan), dim3(kThreads), 0, stream, ws, flags, bsum);
-  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(kThreads), 0, stream, ws, bsum);
-  hipLaunchKernelGGL(k_scan_final, dim3(g_scan), dim3(kThreads), 0, stream, ws, flags, bsum);
-  hipLaunchKernelGGL(k_rank_lookup, dim3(g_pts), dim3(kThreads), 0, stream, (long long)n_points,
-                     (const long long*)d_spp, ws, flags, d_spp_inv);
-  GAPRO_LAUNCH_CHECK(ctx);
-  GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(h_header_pinned, &ws->header, sizeof(gapro_scene_header), hipMemcpyDeviceToHost,
-                                      stream));
-  return GAPRO_OK;
+  gapro_scene_task* h;
+  gapro_scene_task* d = ring_slot(ctx, &h);
+  *h = gapro_scene_task{};
+  h->n_points = n_points; h->coords = d_coords; h->feats = d_feats; h->spp = d_spp; h->spp_inv = d_spp_inv;
+  h->prepare_ws = d_workspace; h->spp_range_cap = spp_range_cap;
+  // the header travels through the workspace's own header slot
+  return gapro_partition_prepare_batch(ctx, stream_, 1, feat_dim, h, d, &((PrepareWorkspace*)d_workspace)->header,
+                                       h_header_pinned);
 }
 
 int gapro_partition_prepare(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_t feat_dim,
@@ -414,35 +573,26 @@ int gapro_partition_pool(gapro_ctx* ctx, void* stream_, int64_t n_points, int32_
                          int64_t* d_feat_sum, int32_t* d_occ_count, int32_t* d_point_count, float* d_feats_spp,
                          uint64_t* d_occ_bits, int32_t* d_n_bbs) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
-  if (n_points <= 0 || feat_dim <= 0 || n_boxes <= 0 || n_spps <= 0 || !d_coords || !d_feats || !d_spp_inv ||
-      !d_boxes || !d_feat_sum || !d_occ_count || !d_point_count || !d_feats_spp || !d_occ_bits || !d_n_bbs)
-    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_pool: bad argument");
-  const size_t lds = (size_t)n_boxes * 6 * sizeof(double);
-  if (lds > 64 * 1024) return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_partition_pool: too many boxes (%d)", n_boxes);
-  hipStream_t stream = (hipStream_t)stream_;
-  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_feat_sum, 0, (size_t)n_spps * feat_dim * sizeof(int64_t), stream));
-  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_occ_count, 0, (size_t)n_spps * n_boxes * sizeof(int32_t), stream));
-  GAPRO_HIP_CHECK(ctx, hipMemsetAsync(d_point_count, 0, (size_t)n_spps * sizeof(int32_t), stream));
-  hipLaunchKernelGGL(k_pool, dim3(grid_for(n_points * kLanesPerPoint, 4096)), dim3(kThreads), lds, stream, (long long)n_points, (int)feat_dim,
-                     (int)n_boxes, (int)fixed_shift, d_coords, d_feats, d_spp_inv, d_boxes,
-                     (unsigned long long*)d_feat_sum, d_occ_count, d_point_count);
-  hipLaunchKernelGGL(k_pool_finalize, dim3((n_spps + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, (int)n_spps,
-                     (int)feat_dim, (int)n_boxes, (int)fixed_shift, thresh_spp_occu, (const long long*)d_feat_sum,
-                     d_occ_count, d_point_count, d_feats_spp, (unsigned long long*)d_occ_bits, d_n_bbs);
-  GAPRO_LAUNCH_CHECK(ctx);
-  return GAPRO_OK;
+  gapro_scene_task* h;
+  gapro_scene_task* d = ring_slot(ctx, &h);
+  *h = gapro_scene_task{};
+  h->n_points = n_points; h->coords = d_coords; h->feats = d_feats; h->spp_inv = (int32_t*)d_spp_inv;
+  h->boxes = d_boxes; h->n_boxes = n_boxes; h->n_spps = n_spps; h->fixed_shift = fixed_shift;
+  h->thresh_spp_occu = thresh_spp_occu; h->feat_sum = d_feat_sum; h->occ_count = d_occ_count;
+  h->point_count = d_point_count; h->feats_spp = d_feats_spp; h->occ_bits = d_occ_bits; h->n_bbs = d_n_bbs;
+  return gapro_partition_pool_batch(ctx, stream_, 1, feat_dim, h, d);
 }
 
 int gapro_broadcast_labels(gapro_ctx* ctx, void* stream_, int64_t n_points, const int32_t* d_spp_inv,
                            const int32_t* d_sem_spp, const int32_t* d_inst_spp, const float* d_prob_spp,
                            int32_t* d_sem, int32_t* d_inst, float* d_prob) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
-  if (n_points <= 0 || !d_spp_inv || !d_sem_spp || !d_inst_spp || !d_prob_spp || !d_sem || !d_inst || !d_prob)
-    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_broadcast_labels: bad argument");
-  hipLaunchKernelGGL(k_broadcast, dim3(grid_for(n_points)), dim3(kThreads), 0, (hipStream_t)stream_,
-                     (long long)n_points, d_spp_inv, d_sem_spp, d_inst_spp, d_prob_spp, d_sem, d_inst, d_prob);
-  GAPRO_LAUNCH_CHECK(ctx);
-  return GAPRO_OK;
+  gapro_scene_task* h;
+  gapro_scene_task* d = ring_slot(ctx, &h);
+  *h = gapro_scene_task{};
+  h->n_points = n_points; h->spp_inv = (int32_t*)d_spp_inv; h->sem_spp = d_sem_spp; h->inst_spp = d_inst_spp;
+  h->prob_spp = d_prob_spp; h->sem = d_sem; h->inst = d_inst; h->prob = d_prob;
+  return gapro_broadcast_labels_batch(ctx, stream_, 1, h, d);
 }
 
 }  // extern "C"

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Context, FitDesc, SceneHeader, ScheduleCounts
+from ._lib import Context, FitDesc, SceneHeader, SceneTask, ScheduleCounts
 
 
 def _ptr(t) -> C.c_void_p:
@@ -178,21 +178,29 @@ class Pipeline:
         self._pin_cache = {}
         self._pin_events = {}
         self._ws = {}  # slot -> fit workspace (device, float64)
+        self._keep = {}
+
+    # ------------------------------------------------------------------ batched partition plumbing
+    def _task_array(self, jobs: Sequence[SceneJob]):
+        """One gapro_scene_task per scene (host ctypes array + its device mirror), created once per batch and
+        refilled stage by stage."""
+        tasks = (SceneTask * len(jobs))()
+        for t, job in zip(tasks, jobs):
+            t.n_points = job.n_points
+            t.coords, t.feats, t.spp = job.coords.data_ptr(), job.feats.data_ptr(), job.spp.data_ptr()
+        d_tasks = torch.empty(len(jobs) * C.sizeof(SceneTask), dtype=torch.uint8, device=self.device)
+        return tasks, d_tasks
+
+    @staticmethod
+    def _carve(sizes, align=256):
+        """Offsets of consecutive `align`-aligned regions of the given byte sizes, and the total."""
+        offs, tot = [], 0
+        for sz in sizes:
+            offs.append(tot)
+            tot += (int(sz) + align - 1) // align * align
+        return offs, max(tot, align)
 
     # ------------------------------------------------------------------ stage A
-    def _prepare_launch(self, job: SceneJob, hdr_ptr: int):
-        """Enqueue the scene statistics + dense ranks; the header lands in pinned memory at hdr_ptr."""
-        n = job.n_points
-        cap = int(self.spp_range_cap) if self.spp_range_cap else max(4 * n, 1 << 20)
-        nbytes = self.lib.gapro_partition_prepare_workspace_bytes(n, cap)
-        job.dev["prep_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        job.spp_inv = torch.empty(n, dtype=torch.int32, device=self.device)
-        self.ctx.check(self.lib.gapro_partition_prepare_async(
-            self.ctx.handle, _stream_handle(self.device), n, int(job.feats.shape[1]), _ptr(job.coords),
-            _ptr(job.feats), _ptr(job.spp), cap, _ptr(job.dev["prep_ws"]), nbytes, _ptr(job.spp_inv),
-            C.c_void_p(hdr_ptr)))
-        job.host["range_cap"] = cap
-
     def _prepare_finish(self, job: SceneJob, hdr: SceneHeader):
         if hdr.status != 0:
             raise _lib.GaproError(int(hdr.status), "superpoint id range [%d, %d] exceeds the rank table (%d slots)"
@@ -218,42 +226,86 @@ class Pipeline:
         self._prepare_all([job])
 
     def _prepare_all(self, jobs: Sequence[SceneJob]):
+        """Scene statistics + dense superpoint ranks of every scene: one launch per kernel, one sync."""
+        lib, devc = self.lib, self.device
+        tasks, d_tasks = self._task_array(jobs)
+        D = int(jobs[0].feats.shape[1])
+        caps = [int(self.spp_range_cap) if self.spp_range_cap else max(4 * j.n_points, 1 << 20) for j in jobs]
+        ws_off, ws_tot = self._carve([lib.gapro_partition_prepare_workspace_bytes(j.n_points, c)
+                                      for j, c in zip(jobs, caps)])
+        prep_ws = torch.empty(ws_tot, dtype=torch.uint8, device=devc)
+        inv_off, inv_tot = self._carve([4 * j.n_points for j in jobs])
+        spp_inv_all = torch.empty(inv_tot, dtype=torch.uint8, device=devc)
         hsz = C.sizeof(SceneHeader)
-        pinned = torch.empty(len(jobs) * hsz, dtype=torch.uint8, pin_memory=True)
-        for i, job in enumerate(jobs):
-            self._prepare_launch(job, pinned.data_ptr() + i * hsz)
-        torch.cuda.current_stream(self.device).synchronize()  # one sync for the whole batch
+        d_headers = torch.empty(len(jobs) * hsz, dtype=torch.uint8, device=devc)
+        pinned = self._pinned("headers%x" % int(torch.cuda.current_stream(devc).cuda_stream), len(jobs) * hsz)
+        for t, job, cap, wo, io in zip(tasks, jobs, caps, ws_off, inv_off):
+            job.spp_inv = spp_inv_all[io:io + 4 * job.n_points].view(torch.int32)
+            job.host["range_cap"] = cap
+            t.spp_inv, t.prepare_ws, t.spp_range_cap = job.spp_inv.data_ptr(), prep_ws.data_ptr() + wo, cap
+        self.ctx.check(lib.gapro_partition_prepare_batch(
+            self.ctx.handle, _stream_handle(devc), len(jobs), D, C.cast(tasks, C.c_void_p), _ptr(d_tasks),
+            _ptr(d_headers), _ptr(pinned)))
+        torch.cuda.current_stream(devc).synchronize()  # one sync for the whole batch
         raw = pinned.numpy()
         for i, job in enumerate(jobs):
             self._prepare_finish(job, SceneHeader.from_buffer_copy(raw[i * hsz:(i + 1) * hsz].tobytes()))
+        return tasks, d_tasks
 
     # ------------------------------------------------------------------ stage B
     def _pool(self, job: SceneJob, feats_spp_all: torch.Tensor, stage: Optional[torch.Tensor] = None, off: int = 0):
-        S, B, D = job.n_spps, job.n_boxes, int(job.feats.shape[1])
-        W = (B + 63) // 64
-        d = job.dev
-        d["boxes"] = torch.from_numpy(job.boxes).to(self.device, non_blocking=True)
-        d["feat_sum"] = torch.empty((S, D), dtype=torch.int64, device=self.device)
-        d["occ_count"] = torch.empty((S, B), dtype=torch.int32, device=self.device)
-        d["point_count"] = torch.empty(S, dtype=torch.int32, device=self.device)
-        d["occ_bits"] = torch.empty((S, W), dtype=torch.int64, device=self.device)
-        d["n_bbs"] = torch.empty(S, dtype=torch.int32, device=self.device)
-        d["feats_spp"] = feats_spp_all[job.feats_row_base:job.feats_row_base + S]
-        self.ctx.check(self.lib.gapro_partition_pool(
-            self.ctx.handle, _stream_handle(self.device), job.n_points, D, B, S, int(job.header.fixed_shift),
-            C.c_float(job.thresh_spp_occu), _ptr(job.coords), _ptr(job.feats), _ptr(job.spp_inv), _ptr(d["boxes"]),
-            _ptr(d["feat_sum"]), _ptr(d["occ_count"]), _ptr(d["point_count"]), _ptr(d["feats_spp"]),
-            _ptr(d["occ_bits"]), _ptr(d["n_bbs"])))
-        # stage the two small tables the host scheduler needs into pinned memory (no sync here)
-        h = job.host
+        """Single-scene form (tests)."""
+        tasks, d_tasks = self._task_array([job])
+        tasks[0].spp_inv = job.spp_inv.data_ptr()
+        self._pool_all([job], tasks, d_tasks, feats_spp_all, stage)
+
+    def _pool_all(self, jobs: Sequence[SceneJob], tasks, d_tasks, feats_spp_all: torch.Tensor,
+                  stage: Optional[torch.Tensor] = None):
+        """Fused membership + pooling of every scene: one launch per kernel; the two small tables the host
+        scheduler needs (occ_bits, n_bbs) of all scenes come back in ONE device-to-host copy (no sync here)."""
+        lib, devc = self.lib, self.device
+        D = int(jobs[0].feats.shape[1])
+        # boxes of every scene: one pinned staging buffer, one upload
+        box_off, box_tot = self._carve([j.boxes.nbytes for j in jobs], 64)
+        slot = "%x" % int(torch.cuda.current_stream(devc).cuda_stream)
+        h_boxes = self._pinned("boxes" + slot, box_tot)
+        hb = h_boxes.numpy()
+        for job, bo in zip(jobs, box_off):
+            hb[bo:bo + job.boxes.nbytes] = job.boxes.view(np.uint8).reshape(-1)
+        d_boxes = torch.empty(box_tot, dtype=torch.uint8, device=devc)
+        d_boxes.copy_(h_boxes[:box_tot], non_blocking=True)
+        # host-visible tables [occ_bits | n_bbs] per scene, laid out exactly like the pinned staging area
+        tab_sizes = [j.n_spps * (((j.n_boxes + 63) // 64) * 8 + 4) for j in jobs]
+        tab_off, tab_tot = self._carve(tab_sizes, 16)
+        d_tables = torch.empty(tab_tot, dtype=torch.uint8, device=devc)
+        # integer tallies [feat_sum i64 | occ_count i32 | point_count i32] per scene
+        tal_sizes = [j.n_spps * (8 * D + 4 * j.n_boxes + 4) for j in jobs]
+        tal_off, tal_tot = self._carve(tal_sizes, 16)
+        d_tallies = torch.empty(tal_tot, dtype=torch.uint8, device=devc)
         if stage is None:
-            stage, off = torch.empty(S * (W * 8 + 4) + 16, dtype=torch.uint8, pin_memory=True), 0
-        nb1, nb2 = S * W * 8, S * 4
-        h["occ_bits_pin"] = stage[off:off + nb1].view(torch.int64).view(S, W)
-        h["n_bbs_pin"] = stage[off + nb1:off + nb1 + nb2].view(torch.int32)
-        h["occ_bits_pin"].copy_(d["occ_bits"], non_blocking=True)
-        h["n_bbs_pin"].copy_(d["n_bbs"], non_blocking=True)
-        return off + ((nb1 + nb2 + 15) // 16) * 16
+            stage = torch.empty(tab_tot, dtype=torch.uint8, pin_memory=True)
+        for t, job, bo, to, ao in zip(tasks, jobs, box_off, tab_off, tal_off):
+            S, B = job.n_spps, job.n_boxes
+            W = (B + 63) // 64
+            d = job.dev
+            d["boxes"] = d_boxes[bo:bo + job.boxes.nbytes].view(torch.float64).view(B, 6)
+            d["feat_sum"] = d_tallies[ao:ao + 8 * S * D].view(torch.int64).view(S, D)
+            d["occ_count"] = d_tallies[ao + 8 * S * D:ao + 8 * S * D + 4 * S * B].view(torch.int32).view(S, B)
+            d["point_count"] = d_tallies[ao + 8 * S * D + 4 * S * B:ao + 8 * S * D + 4 * S * B + 4 * S].view(torch.int32)
+            d["occ_bits"] = d_tables[to:to + 8 * S * W].view(torch.int64).view(S, W)
+            d["n_bbs"] = d_tables[to + 8 * S * W:to + 8 * S * W + 4 * S].view(torch.int32)
+            d["feats_spp"] = feats_spp_all[job.feats_row_base:job.feats_row_base + S]
+            t.boxes, t.n_boxes, t.n_spps = d["boxes"].data_ptr(), B, S
+            t.fixed_shift, t.thresh_spp_occu = int(job.header.fixed_shift), float(job.thresh_spp_occu)
+            t.feat_sum, t.occ_count, t.point_count = (d["feat_sum"].data_ptr(), d["occ_count"].data_ptr(),
+                                                      d["point_count"].data_ptr())
+            t.feats_spp, t.occ_bits, t.n_bbs = d["feats_spp"].data_ptr(), d["occ_bits"].data_ptr(), d["n_bbs"].data_ptr()
+            h = job.host
+            h["occ_bits_pin"] = stage[to:to + 8 * S * W].view(torch.int64).view(S, W)
+            h["n_bbs_pin"] = stage[to + 8 * S * W:to + 8 * S * W + 4 * S].view(torch.int32)
+        self.ctx.check(lib.gapro_partition_pool_batch(self.ctx.handle, _stream_handle(devc), len(jobs), D,
+                                                      C.cast(tasks, C.c_void_p), _ptr(d_tasks)))
+        stage[:tab_tot].copy_(d_tables, non_blocking=True)
 
     # ------------------------------------------------------------------ stage C
     def _schedule(self, job: SceneJob):
@@ -372,7 +424,7 @@ class Pipeline:
         stream = torch.cuda.current_stream(devc)
         slot = "s%x" % int(stream.cuda_stream)
         _mark("start")
-        self._prepare_all(jobs)
+        tasks, d_tasks = self._prepare_all(jobs)
         _mark("A prepare")
         D = int(jobs[0].feats.shape[1])
         base = 0
@@ -385,13 +437,11 @@ class Pipeline:
         # one pinned staging area for the tables the host scheduler needs from every scene
         need = sum(job.n_spps * (((job.n_boxes + 63) // 64) * 8 + 4) + 16 for job in jobs)
         stage = self._pinned(slot + "tables", need)
-        off = 0
-        for job in jobs:
-            off = self._pool(job, feats_spp_all, stage, off)
+        self._pool_all(jobs, tasks, d_tasks, feats_spp_all, stage)
         stream.synchronize()  # one sync: pooled tables of every scene are on the host
         _mark("B pool")
         return dict(jobs=jobs, stream=stream, keep_debug=keep_debug, mark=_mark, feats_spp_all=feats_spp_all,
-                    slot=slot, pending=None, n_fits=0, n_out=0)
+                    slot=slot, pending=None, n_fits=0, n_out=0, tasks=tasks, d_tasks=d_tasks)
 
     def _schedule_all(self, state):
         """Stage C (host only): static pair schedule of every scene, fit descriptors of the whole batch."""
@@ -466,22 +516,27 @@ class Pipeline:
             off += 20 * S
         d_tables.copy_(tables[:tot_s * 20], non_blocking=True)  # one H2D copy for the whole batch
         self._pin_events[state["slot"] + "labels"] = torch.cuda.current_stream(devc).record_event()
-        for job, off in zip(jobs, views):
+        tasks, d_tasks = state["tasks"], state["d_tasks"]
+        out_off, out_tot = self._carve([12 * job.n_points for job in jobs], 16)
+        d_out = torch.empty(out_tot, dtype=torch.uint8, device=devc)  # [sem | inst | prob] per scene
+        for t, job, off, oo in zip(tasks, jobs, views, out_off):
             S, n = job.n_spps, job.n_points
-            d_sem_spp = d_tables[off:off + 4 * S].view(torch.int32)
-            d_inst_spp = d_tables[off + 4 * S:off + 8 * S].view(torch.int32)
-            d_prob_spp = d_tables[off + 8 * S:off + 12 * S].view(torch.float32)
-            sem = torch.empty(n, dtype=torch.int32, device=devc)
-            ins = torch.empty(n, dtype=torch.int32, device=devc)
-            prb = torch.empty(n, dtype=torch.float32, device=devc)
-            ctx.check(lib.gapro_broadcast_labels(ctx.handle, _stream_handle(devc), n, _ptr(job.spp_inv),
-                                                 _ptr(d_sem_spp), _ptr(d_inst_spp), _ptr(d_prob_spp), _ptr(sem),
-                                                 _ptr(ins), _ptr(prb)))
+            sem = d_out[oo:oo + 4 * n].view(torch.int32)
+            ins = d_out[oo + 4 * n:oo + 8 * n].view(torch.int32)
+            prb = d_out[oo + 8 * n:oo + 12 * n].view(torch.float32)
+            t.sem_spp = d_tables.data_ptr() + off
+            t.inst_spp = d_tables.data_ptr() + off + 4 * S
+            t.prob_spp = d_tables.data_ptr() + off + 8 * S
+            t.sem, t.inst, t.prob = sem.data_ptr(), ins.data_ptr(), prb.data_ptr()
             job.outputs = (sem, ins, prb, d_tables[off + 12 * S:off + 16 * S].view(torch.float32),
                            d_tables[off + 16 * S:off + 20 * S].view(torch.float32))
             if not keep_debug:
                 lib.gapro_schedule_free(job.schedule)
                 job.schedule = None
+        ctx.check(lib.gapro_broadcast_labels_batch(ctx.handle, _stream_handle(devc), len(jobs),
+                                                   C.cast(tasks, C.c_void_p), _ptr(d_tasks)))
+        # the task array must outlive the (possibly delayed) upload enqueued above
+        self._keep[state["slot"]] = (tasks, d_tasks)
         if sync:
             torch.cuda.current_stream(devc).synchronize()
         _mark("E+F merge/broadcast")

@@ -107,6 +107,53 @@ int gapro_broadcast_labels(gapro_ctx* ctx, void* stream, int64_t n_points, const
                            const int32_t* d_sem_spp, const int32_t* d_inst_spp, const float* d_prob_spp,
                            int32_t* d_sem, int32_t* d_inst, float* d_prob);
 
+/* ---- Batched forms: every scene of a batch in ONE launch per kernel (grid.y = scene). ----------
+ * A 64-scene batch through the per-scene calls above is ~1200 launches of 3-5 us kernels; the batched
+ * calls are ~15.  One gapro_scene_task per scene holds the device pointers of that scene; the three
+ * calls read the fields of their stage (the caller fills n_spps / fixed_shift from the headers between
+ * prepare and pool).  `h_tasks` is copied to `d_tasks` (device, n_scenes tasks) on the stream and must
+ * stay valid until the stream has executed that copy. */
+typedef struct {
+  /* every stage */
+  int64_t n_points;
+  const double* coords;       /* f64[N,3] */
+  const float* feats;         /* f32[N,D] */
+  const int64_t* spp;         /* i64[N]   */
+  int32_t* spp_inv;           /* i32[N]   out of prepare, in of pool / broadcast */
+  /* prepare */
+  void* prepare_ws;           /* >= gapro_partition_prepare_workspace_bytes(N, spp_range_cap) */
+  int64_t spp_range_cap;
+  /* pool */
+  const double* boxes;        /* f64[B,6] */
+  int32_t n_boxes, n_spps, fixed_shift;
+  float thresh_spp_occu;
+  int64_t* feat_sum;          /* i64[S,D] tmp */
+  int32_t* occ_count;         /* i32[S,B] */
+  int32_t* point_count;       /* i32[S]   */
+  float* feats_spp;           /* f32[S,D] */
+  uint64_t* occ_bits;         /* u64[S,ceil(B/64)] */
+  int32_t* n_bbs;             /* i32[S]   */
+  /* broadcast */
+  const int32_t* sem_spp;     /* i32[S] */
+  const int32_t* inst_spp;    /* i32[S] */
+  const float* prob_spp;      /* f32[S] */
+  int32_t* sem;               /* i32[N] */
+  int32_t* inst;              /* i32[N] */
+  float* prob;                /* f32[N] */
+} gapro_scene_task;
+
+/* gapro_partition_prepare_async for n_scenes scenes; the headers land in h_headers_pinned[n_scenes]
+ * (page-locked) through d_headers[n_scenes] (device) once the stream reaches that point. */
+int gapro_partition_prepare_batch(gapro_ctx* ctx, void* stream, int32_t n_scenes, int32_t feat_dim,
+                                  const gapro_scene_task* h_tasks, gapro_scene_task* d_tasks,
+                                  gapro_scene_header* d_headers, gapro_scene_header* h_headers_pinned);
+/* gapro_partition_pool for n_scenes scenes (zeroes the tallies itself). */
+int gapro_partition_pool_batch(gapro_ctx* ctx, void* stream, int32_t n_scenes, int32_t feat_dim,
+                               const gapro_scene_task* h_tasks, gapro_scene_task* d_tasks);
+/* gapro_broadcast_labels for n_scenes scenes. */
+int gapro_broadcast_labels_batch(gapro_ctx* ctx, void* stream, int32_t n_scenes,
+                                 const gapro_scene_task* h_tasks, gapro_scene_task* d_tasks);
+
 /* ------------------------------------------------------------------------------------------
  * Static pair schedule and merge (host).  Replaces the control flow of gen_ps_utils.py:365-476.
  * Which pairs are fitted and on which superpoints depends only on (boxes, bb_occupancy_spp),

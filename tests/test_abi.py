@@ -29,6 +29,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(_lib.SceneHeader) == 3 * 8 + 3 * 8 + 8 + 8 + 4 + 4 + 4 + 4
     assert C.sizeof(_lib.FitDesc) == 8 * 4 + 3 * 8
     assert C.sizeof(_lib.FitOptions) == 40
+    assert C.sizeof(_lib.SceneTask) == 176
     assert C.sizeof(_lib.ScheduleCounts) == 4 + 4 + 8 + 8 + 8 + 4 + 4
 
 

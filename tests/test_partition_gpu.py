@@ -103,3 +103,82 @@ def test_partition_reports_superpoint_range_overflow():
     with pytest.raises(GaproError) as e:
         _run_partition(kw, spp_range_cap=1 << 16)
     assert e.value.code == -6
+
+
+def _synth_kw(seed, n_points):
+    from gapro_amd.gen_ps_utils import getInstanceInfo
+    from gapro_amd.synth import make_scene
+
+    sc = make_scene(seed=seed, n_points=n_points)
+    xyz = sc.aligned_xyz()
+    _, cls, box, vol, _ = getInstanceInfo(xyz, sc.inst, sc.sem)
+    return dict(coords_float=xyz, mask_feats=sc.default_feats().astype(np.float32), spp=sc.spp,
+                instance_cls=cls.astype(np.int64), instance_box=box.astype(np.float32),
+                instance_box_volume=vol.astype(np.float32), wall_box=[], wall_box_volume=[])
+
+
+def test_partition_batch_of_ragged_scenes_matches_oracle():
+    """One batched launch over scenes of very different sizes (grid.y = scene): every scene bit-exact."""
+    import torch
+    from gapro_amd.pipeline import Pipeline, make_job
+
+    kws = [_synth_kw(11, 40000), _synth_kw(12, 1500), _synth_kw(13, 90000), _synth_kw(14, 300)]
+    pipe = Pipeline(device=0, training_iter=0)
+    jobs = [make_job(kw["coords_float"], kw["mask_feats"], kw["spp"], kw["instance_cls"], kw["instance_box"],
+                     kw["instance_box_volume"], kw["wall_box"], kw["wall_box_volume"], 18, 0.1, 0.999) for kw in kws]
+    tasks, d_tasks = pipe._prepare_all(jobs)
+    base = 0
+    for job in jobs:
+        job.feats_row_base = base
+        base += job.n_spps
+    feats_spp_all = torch.empty((base, 6), dtype=torch.float32, device=pipe.device)
+    pipe._pool_all(jobs, tasks, d_tasks, feats_spp_all)
+    torch.cuda.synchronize()
+    for kw, job in zip(kws, jobs):
+        _check_against_oracle(kw, job)
+
+
+def test_single_scene_c_entry_points_match_the_batched_ones():
+    """gapro_partition_prepare / _pool / gapro_broadcast_labels (one-scene ABI) against the batched path."""
+    import torch
+    from gapro_amd.pipeline import _ptr
+
+    kw = _synth_kw(21, 20000)
+    pipe, job = _run_partition(kw)  # batched path
+    lib, ctx, dev = pipe.lib, pipe.ctx, pipe.device
+    n, D, S, B = job.n_points, 6, job.n_spps, job.n_boxes
+    cap = max(4 * n, 1 << 20)
+    nbytes = lib.gapro_partition_prepare_workspace_bytes(n, cap)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    spp_inv = torch.empty(n, dtype=torch.int32, device=dev)
+    from gapro_amd._lib import SceneHeader
+    hdr = SceneHeader()
+    ctx.check(lib.gapro_partition_prepare(ctx.handle, None, n, D, _ptr(job.coords), _ptr(job.feats), _ptr(job.spp),
+                                          cap, _ptr(ws), nbytes, _ptr(spp_inv), C.byref(hdr)))
+    assert (hdr.n_spps, hdr.fixed_shift, hdr.spp_min, hdr.spp_max) == (
+        job.header.n_spps, job.header.fixed_shift, job.header.spp_min, job.header.spp_max)
+    assert torch.equal(spp_inv, job.spp_inv)
+    W = (B + 63) // 64
+    boxes = torch.from_numpy(job.boxes).to(dev)
+    feat_sum = torch.empty((S, D), dtype=torch.int64, device=dev)
+    occ = torch.empty((S, B), dtype=torch.int32, device=dev)
+    pc = torch.empty(S, dtype=torch.int32, device=dev)
+    fs = torch.empty((S, D), dtype=torch.float32, device=dev)
+    bits = torch.empty((S, W), dtype=torch.int64, device=dev)
+    nbb = torch.empty(S, dtype=torch.int32, device=dev)
+    ctx.check(lib.gapro_partition_pool(ctx.handle, None, n, D, B, S, int(hdr.fixed_shift), C.c_float(0.999),
+                                       _ptr(job.coords), _ptr(job.feats), _ptr(spp_inv), _ptr(boxes), _ptr(feat_sum),
+                                       _ptr(occ), _ptr(pc), _ptr(fs), _ptr(bits), _ptr(nbb)))
+    torch.cuda.synchronize()
+    for a, b in ((occ, job.dev["occ_count"]), (pc, job.dev["point_count"]), (fs, job.dev["feats_spp"]),
+                 (bits, job.dev["occ_bits"]), (nbb, job.dev["n_bbs"])):
+        assert torch.equal(a, b)
+    sem_spp = torch.arange(S, dtype=torch.int32, device=dev)
+    prob_spp = torch.rand(S, device=dev)
+    sem = torch.empty(n, dtype=torch.int32, device=dev)
+    ins = torch.empty(n, dtype=torch.int32, device=dev)
+    prb = torch.empty(n, dtype=torch.float32, device=dev)
+    ctx.check(lib.gapro_broadcast_labels(ctx.handle, None, n, _ptr(spp_inv), _ptr(sem_spp), _ptr(sem_spp),
+                                         _ptr(prob_spp), _ptr(sem), _ptr(ins), _ptr(prb)))
+    torch.cuda.synchronize()
+    assert torch.equal(sem, sem_spp[spp_inv.long()]) and torch.equal(prb, prob_spp[spp_inv.long()])
