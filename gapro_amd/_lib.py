@@ -52,6 +52,14 @@ class SceneTask(C.Structure):
                 ("sem", C.c_void_p), ("inst", C.c_void_p), ("prob", C.c_void_p)]
 
 
+class InstanceHeader(C.Structure):
+    _fields_ = [("instance_num", C.c_int32), ("n_boxes", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class EvalHeader(C.Structure):
+    _fields_ = [("n_gt", C.c_int32), ("n_ps", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
 class FitOptions(C.Structure):
     _fields_ = [("training_iter", C.c_int32), ("lr", C.c_double), ("jitter", C.c_double),
                 ("min_variance", C.c_double), ("eval_stale_chol", C.c_int32), ("reserved", C.c_int32)]
@@ -75,6 +83,13 @@ SIGNATURES = {
     "gapro_partition_prepare_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "gapro_partition_pool_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "gapro_broadcast_labels_batch": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "gapro_instance_info_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "gapro_instance_info": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P, _P, _P, _P,
+                                      _P, _P]),
+    "gapro_eval_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "gapro_eval_miou": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P, _P, _P,
+                                  _P]),
+    "gapro_eval_sem_confusion": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, _P]),
     "gapro_schedule_build": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(_P)]),
     "gapro_schedule_free": (None, [_P]),
     "gapro_schedule_get_counts": (C.c_int, [_P, C.POINTER(ScheduleCounts)]),

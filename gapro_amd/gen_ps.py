@@ -34,12 +34,12 @@ import numpy as np
 import torch
 
 from .dist_utils import pending_scenes, shard_scenes
-from .gen_ps_utils import getInstanceInfo
+from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device
 from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
 
 
-def load_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
+def load_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None, device=None):
     """gen_ps.py:37-77: load, build features from UN-aligned xyz, axis-align, boxes, wall boxes."""
     scan_name = filename.split("/")[-1][:12]
     xyz, rgb, semantic_label, instance_label = torch.load(filename, weights_only=False)
@@ -54,7 +54,10 @@ def load_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
     pts = np.ones((xyz.shape[0], 4))
     pts[:, 0:3] = xyz[:, 0:3]
     xyz_al = np.dot(pts, A.transpose())[:, :3]  # :65-69
-    info = getInstanceInfo(xyz_al, instance_label=instance_label, semantic_label=semantic_label)
+    if device is not None:  # the driver: GT boxes in one pass on the device (gapro_instance_info)
+        info = getInstanceInfo_device(xyz_al, instance_label, semantic_label, device=device)
+    else:  # no device given: the reference's host function, mirrored
+        info = getInstanceInfo(xyz_al, instance_label=instance_label, semantic_label=semantic_label)
     if info is None:
         return None
     _, instance_cls, instance_box, instance_box_volume, _ = info
@@ -89,7 +92,7 @@ def run_worker(filenames, args, device_index):
         scenes = []
         for fn in pending[i:i + args.batch_scenes]:
             try:
-                sc = load_scene(fn, args.data_root, args.use_deepfeat, args.deepfeat_folder)
+                sc = load_scene(fn, args.data_root, args.use_deepfeat, args.deepfeat_folder, device=dev)
                 if sc is None:
                     print("[gen_ps] %s: no instances, skipped" % fn, file=sys.stderr)
                     failed += 1

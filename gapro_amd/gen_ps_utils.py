@@ -122,6 +122,63 @@ def getInstanceInfo(xyz, instance_label, semantic_label, dataset_name="scannetv2
     return instance_num, instance_cls, instance_box, instance_box_volume, corners_label
 
 
+def getInstanceInfo_device(xyz, instance_label, semantic_label, dataset_name="scannetv2", device=None,
+                           return_corners=False):
+    """getInstanceInfo (gen_ps_utils.py:195-239) on the GPU: one pass over the points behind
+    ``gapro_instance_info`` (gapro_amd/csrc/labels.hip) instead of an O(N * I) ``np.where`` loop.
+
+    Inputs: arrays or tensors (moved to the device as float64, the dtype the ScanNet .pth files hold).  Returns
+    the reference's tuple ``(instance_num, instance_cls f64[B], instance_box f64[B,6], instance_box_volume
+    f64[B], corners_label f32[N,6] or None)`` as host NumPy arrays (they are tiny), or None without instances.
+    SURVEY.md section 8(f) row 2."""
+    import ctypes as C
+
+    from ._lib import Context, InstanceHeader
+
+    if device is None:
+        device = xyz.device if isinstance(xyz, torch.Tensor) and xyz.is_cuda else torch.device("cuda", 0)
+    device = torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("getInstanceInfo_device needs a HIP device; getInstanceInfo is the host form")
+
+    def dev64(a):
+        a = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        return a.to(device=device, dtype=torch.float64).contiguous()
+
+    coords, inst, sem = dev64(xyz), dev64(instance_label).view(-1), dev64(semantic_label).view(-1)
+    n = int(coords.shape[0])
+    if n == 0:
+        return None
+    ctx = Context.get(device.index or 0)
+    lib = ctx.lib
+    with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        cap = 1024
+        while True:
+            ws_bytes = int(lib.gapro_instance_info_workspace_bytes(cap))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+            box = torch.empty((cap, 6), dtype=torch.float64, device=device)
+            cls = torch.empty(cap, dtype=torch.float64, device=device)
+            vol = torch.empty(cap, dtype=torch.float64, device=device)
+            corners = torch.empty((n, 6), dtype=torch.float32, device=device) if return_corners else None
+            d_hdr = torch.empty(C.sizeof(InstanceHeader), dtype=torch.uint8, device=device)
+            h_hdr = torch.empty(C.sizeof(InstanceHeader), dtype=torch.uint8, pin_memory=True)
+            ctx.check(lib.gapro_instance_info(
+                ctx.handle, stream, n, coords.data_ptr(), inst.data_ptr(), sem.data_ptr(), cap,
+                1 if dataset_name == "scannetv2" else 0, ws.data_ptr(), ws_bytes, box.data_ptr(), cls.data_ptr(),
+                vol.data_ptr(), corners.data_ptr() if corners is not None else None, d_hdr.data_ptr(), h_hdr.data_ptr()))
+            torch.cuda.current_stream(device).synchronize()
+            hdr = InstanceHeader.from_buffer_copy(h_hdr.numpy().tobytes())
+            if hdr.status == 0:
+                break
+            cap = max(2 * cap, int(inst.max()) + 1)  # an id beyond the table: size it from the data and retry
+    nb = int(hdr.n_boxes)
+    if nb == 0:
+        return None
+    return (int(hdr.instance_num), cls[:nb].cpu().numpy(), box[:nb].cpu().numpy(), vol[:nb].cpu().numpy(),
+            corners.cpu().numpy() if corners is not None else None)
+
+
 def batch_giou_cross(boxes1, boxes2):
     """Reference gen_ps_utils.py:33-61 (torch, any device): returns (iou, giou)."""
     boxes1 = boxes1[:, None, :]

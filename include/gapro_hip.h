@@ -155,6 +155,54 @@ int gapro_broadcast_labels_batch(gapro_ctx* ctx, void* stream, int32_t n_scenes,
                                  const gapro_scene_task* h_tasks, gapro_scene_task* d_tasks);
 
 /* ------------------------------------------------------------------------------------------
+ * Label-side kernels on either end of the path (not needed by a caller of
+ * gen_pseudo_label_gaussian_process itself).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t instance_num;  /* int(instance_label.max()) + 1            gen_ps_utils.py:200 */
+  int32_t n_boxes;       /* non-empty instance ids = rows of the outputs              */
+  int32_t status;        /* GAPRO_ERR_BAD_ARG: an id >= max_instances was met         */
+  int32_t reserved;
+} gapro_instance_header;
+
+size_t gapro_instance_info_workspace_bytes(int32_t max_instances);
+/* getInstanceInfo (gen_ps_utils.py:195-239) in one pass over the points: per non-empty GT instance id, in
+ * ascending id order, the axis-aligned box [min xyz | max xyz] (f64), the class = semantic label of the
+ * instance's first point (minus 2 unless -100 when scannet_class_shift != 0, :236-237) and the volume
+ * prod(clip(max - min, 0)) (f64).  Labels come as the float64 arrays the ScanNet .pth files hold.
+ *   in : d_coords f64[N,3], d_instance_label f64[N], d_semantic_label f64[N]
+ *   out: d_box f64[<=max_instances,6], d_cls f64[..], d_volume f64[..], d_corners f32[N,6] or NULL
+ *        (corners_label, :203,219-220), header (device + page-locked host copy, enqueue only)     */
+int gapro_instance_info(gapro_ctx* ctx, void* stream, int64_t n_points, const double* d_coords,
+                        const double* d_instance_label, const double* d_semantic_label, int32_t max_instances,
+                        int32_t scannet_class_shift, void* d_workspace, size_t workspace_bytes, double* d_box,
+                        double* d_cls, double* d_volume, float* d_corners, gapro_instance_header* d_header,
+                        gapro_instance_header* h_header_pinned);
+
+typedef struct {
+  int32_t n_gt;          /* instance_label.max() + 1                  eval_ps_labels.py:101 */
+  int32_t n_ps;          /* ps_instance_label.max() + 1               :109 */
+  int32_t status;
+  int32_t reserved;
+} gapro_eval_header;
+
+size_t gapro_eval_workspace_bytes(int32_t max_gt, int32_t max_ps);
+/* get_miou_scene (eval_ps_labels.py:100-147, cal_iou :35-42): for every GT instance id g < n_gt the largest
+ * IoU = inter / (|gt| + |ps| - inter + 1e-4) (float32, the reference's operation order) over the pseudo
+ * instances whose class (label of their first point) equals the GT instance's, and that class (-1 for an
+ * empty id; the caller keeps the rows with class >= 0, :139).  Labels are int64, as the reference passes.
+ *   out: d_max_iou f32[max_gt], d_gt_cls f32[max_gt] (first n_gt entries), header */
+int gapro_eval_miou(gapro_ctx* ctx, void* stream, int64_t n_points, const int64_t* d_semantic_label,
+                    const int64_t* d_instance_label, const int64_t* d_ps_semantic_label,
+                    const int64_t* d_ps_instance_label, int32_t max_gt, int32_t max_ps, void* d_workspace,
+                    size_t workspace_bytes, float* d_max_iou, float* d_gt_cls, gapro_eval_header* d_header,
+                    gapro_eval_header* h_header_pinned);
+/* get_scene_sem_conf (eval_ps_labels.py:150-172): conf i64[C,C], rows = GT class, columns = pseudo class,
+ * over the points with GT != -100; a pseudo label of -100 counts as a wrong class. */
+int gapro_eval_sem_confusion(gapro_ctx* ctx, void* stream, int64_t n_points, const int64_t* d_semantic_label,
+                             const int64_t* d_ps_semantic_label, int32_t num_classes, int64_t* d_conf);
+
+/* ------------------------------------------------------------------------------------------
  * Static pair schedule and merge (host).  Replaces the control flow of gen_ps_utils.py:365-476.
  * Which pairs are fitted and on which superpoints depends only on (boxes, bb_occupancy_spp),
  * never on GP outputs, so the whole schedule is enumerated before any fit runs.

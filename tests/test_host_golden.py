@@ -136,9 +136,9 @@ def test_schedule_rejects_bad_arguments():
 
 
 def test_get_miou_scene_matches_reference(golden):
-    """gen_ps --eval_pslabel metric (eval_ps_labels.py:100-147) on the reference's own outputs."""
+    """The evaluator oracle (eval_ps_labels.py:100-147) against the IoUs the imported reference produced."""
     import torch
-    from gapro_amd.eval_ps_labels import get_miou_scene
+    from oracle.eval_oracle import get_miou_scene
 
     gt_sem = torch.from_numpy(golden["sem_gt"]).int()
     gt_ins = torch.from_numpy(golden["inst_gt"]).int()
