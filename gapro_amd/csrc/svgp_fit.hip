@@ -724,14 +724,55 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
   const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D;
   const ColMap cm = col_map(Mp);
   const int j = cm.col;
-  double zj[DMAX], acc[DMAX];
+  double acc[DMAX];
 #pragma unroll
-  for (int d = 0; d < DMAX; ++d) {
-    zj[d] = (d < D) ? Zt[d * Mp + j] : 0.0;
-    acc[d] = 0.0;
-  }
+  for (int d = 0; d < DMAX; ++d) acc[d] = 0.0;
   double gs = 0.0, gl = 0.0;
-  if (cm.active && j < M) {
+  if (DMAX > 8) {
+    // Wide features (deep features, D = 32): the difference vectors are never held in registers.  With
+    //   sum_i w_i (Z_j - P_i) = Z_j sum_i w_i - sum_i w_i P_i
+    // only acc[d] = sum_i w_i P_i[d] and the scalar sum of the weights are accumulated; Z_j, Z_i, X_i are
+    // re-read from LDS (conflict-free / broadcast), which keeps the pass inside a 128-VGPR budget.
+    double wsum = 0.0;
+    if (cm.active && j < M) {
+      for (int i = cm.grp; i < M; i += cm.G) {
+        const size_t o = (size_t)i * Mp + j;
+        const double gsym = 0.5 * (Gm[o] + GTm[o]);
+        const double g3 = ZX ? GKXT[o] : 0.0;  // G_KX[j][i]
+        double d2 = 0.0, d2x = 0.0;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+          const double zjd = Zt[d * Mp + j];
+          const double a = zjd - Zt[d * Mp + i];
+          d2 += a * a;
+          if (ZX) {
+            const double bx = zjd - Xt[d * Mp + i];
+            d2x += bx * bx;
+          }
+        }
+        const double e = KG_EXP(-0.5 * inv_l2 * d2);
+        const double w = gsym * s * e;
+        gs += gsym * e;
+        gl += w * d2;
+        double wx = 0.0;
+        if (ZX) {
+          const double ex = KG_EXP(-0.5 * inv_l2 * d2x);
+          wx = g3 * s * ex;
+          gs += g3 * ex;
+          gl += wx * d2x;
+        }
+        wsum += 2.0 * w + wx;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+          if (d < D) acc[d] += 2.0 * w * Zt[d * Mp + i] + (ZX ? wx * Xt[d * Mp + i] : 0.0);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) acc[d] = (d < D) ? wsum * Zt[d * Mp + j] - acc[d] : 0.0;
+  } else if (cm.active && j < M) {
+    double zj[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) zj[d] = (d < D) ? Zt[d * Mp + j] : 0.0;
     // the (up to) 3 U operand loads of U rows are issued before the first exp: one memory round trip per
     // U rows instead of one per row (U is chosen per calling kernel to fit its register budget; a distinct U
     // also keeps the two kernels from sharing one instantiation compiled for the tighter budget)

@@ -67,6 +67,21 @@ def test_fit_matches_oracle(m1, m2, t, d, iters):
     _compare(out, _oracle(feats, b1, b2, it, iters))
 
 
+@pytest.mark.parametrize("m1,m2,t,iters", [(150, 170, 60, 50), (260, 270, 90, 5)])
+def test_fit_large_inducing_sets(m1, m2, t, iters):
+    """BASELINE configs[3] territory (large overlap regions): M_p = 320 runs the LDS-staged kernel, M_p = 544 is
+    beyond it and runs the generic (all-in-global-memory) kernel."""
+    import ctypes as C
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    assert _lib.load().gapro_fit_route(m1 + m2, 6) == (1 if m1 + m2 <= 512 else 2)
+    feats, b1, b2, it = make_gp_problem(40 + m1, m1, m2, t, 6)
+    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=iters)[0]
+    _compare(out, _oracle(feats, b1, b2, it, iters))
+
+
 def test_fit_ill_conditioned_problems_stay_finite():
     """Perfectly symmetric (1 vs 1) or far-apart (d = 32, unit std) problems have gradients that are pure
     rounding noise, which Adam normalises to full steps: implementations legitimately differ there
