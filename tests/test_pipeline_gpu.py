@@ -76,3 +76,63 @@ def test_api_conventions(golden):
         assert torch.equal(a, b.cpu())
     _, inv = np.unique(kw["spp"], return_inverse=True)
     assert torch.equal(dev_out[3].cpu(), cpu_out[3][torch.from_numpy(inv)])
+
+
+def _bench_scene(seed, n_points=150000):
+    from gapro_amd.gen_ps_utils import getInstanceInfo
+    from gapro_amd.synth import make_scene
+
+    sc = make_scene(seed=seed, n_points=n_points, n_objects=25, with_walls_json=False)
+    xyz = sc.aligned_xyz()
+    _, cls, box, vol, _ = getInstanceInfo(xyz, sc.inst, sc.sem)
+    return dict(coords_float=xyz, mask_feats=sc.default_feats().astype(np.float32), spp=sc.spp,
+                instance_cls=cls.astype(np.int64), instance_box=box.astype(np.float32),
+                instance_box_volume=vol.astype(np.float32), wall_box=[], wall_box_volume=[])
+
+
+def test_full_size_scenes_size_independent_properties():
+    """bench.py-sized scenes (150k points, the configs[1] shape), checked through properties that do not need
+    the CPU oracle at that size: pipelined == batch-by-batch (bitwise), repeatable, point-order invariant
+    (the pooled sums are exact integers), per-superpoint consistency of the broadcast labels."""
+    import torch
+    from gapro_amd.pipeline import Pipeline, make_job
+
+    kws = [_bench_scene(s) for s in range(4)]
+    pipe = Pipeline(device=0, training_iter=50)
+
+    def jobs(kw_list):
+        return [make_job(kw["coords_float"], kw["mask_feats"], kw["spp"], kw["instance_cls"], kw["instance_box"],
+                         kw["instance_box_volume"], kw["wall_box"], kw["wall_box_volume"], 18, 0.1, 0.999) for kw in kw_list]
+
+    seq = [pipe.run(jobs(kws[:2])), pipe.run(jobs(kws[2:]))]
+    pip = pipe.run_pipelined([jobs(kws[:2]), jobs(kws[2:])])
+    again = pipe.run_pipelined([jobs(kws[:2]), jobs(kws[2:])])
+    torch.cuda.synchronize()
+    for b in range(2):
+        for s in range(2):
+            for x, y, z in zip(seq[b][s], pip[b][s], again[b][s]):
+                assert torch.equal(x, y) and torch.equal(x, z)
+    # per-superpoint consistency and value ranges
+    for kw, outs in zip(kws, seq[0] + seq[1]):
+        sem, ins, prob, mu, var = [o.cpu().numpy() for o in outs]
+        uniq, inv = np.unique(kw["spp"], return_inverse=True)
+        assert len(mu) == len(uniq) == len(var)
+        for arr in (sem, ins, prob):
+            first = np.zeros(len(uniq), dtype=arr.dtype)
+            first[inv] = arr
+            np.testing.assert_array_equal(arr, first[inv])  # one value per superpoint
+        n_inst = len(kw["instance_cls"])
+        assert ins.max() < n_inst and ((ins >= 0) | (ins == -100)).all()
+        assert ((prob >= 0) & (prob <= 1)).all() and np.isfinite(prob).all()
+        gp = mu != -100
+        assert gp.any() and (var[gp] > 0).all() and (var[~gp] == -100).all()
+    # point-order invariance: a permuted scene gives the permuted labels (and the same mu / var)
+    kw = kws[0]
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(kw["spp"]))
+    kwp = dict(kw, coords_float=kw["coords_float"][perm], mask_feats=kw["mask_feats"][perm], spp=kw["spp"][perm])
+    outp = pipe.run(jobs([kwp]))[0]
+    base = seq[0][0]
+    for a, b in zip(base[:3], outp[:3]):
+        assert torch.equal(a.cpu()[torch.from_numpy(perm)], b.cpu())
+    assert torch.equal(base[3], outp[3]) and torch.equal(base[4], outp[4])
