@@ -12,14 +12,16 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
     --split train|val      which scene list (reference: train)
     --devices 0,1,..       one worker process per listed GPU; scenes are dealt round-robin over the
                            workers (independent scenes, no collective); default: this process, cuda:0
-    --batch_scenes B       scenes whose GP fits share one launch (default 8)
+    --batch_scenes B       scenes whose GP fits share one launch (default 32)
     --init_mean_std S      std of the random initial variational mean (gpytorch: 1e-3 unseeded;
                            default 0 = deterministic), --seed seeds it
     --broadcast_mu_var     write mu/var at point length (what the released data loaders index)
+    --loader_threads T     threads that read scenes from disk a batch ahead and write the results (default 4)
 
 Differences from the reference, on purpose: output files are written atomically (tmp + rename); a scene
-that raises is reported and skipped instead of killing the run; a scene without instances (the
-reference crashes unpacking None, gen_ps_utils.py:229-230 / gen_ps.py:72) is skipped.
+that fails to load is reported and skipped instead of killing the run; a scene without instances (the
+reference crashes unpacking None, gen_ps_utils.py:229-230 / gen_ps.py:72) is skipped; batches are
+software-pipelined (the partition of batch i+1 and the merge of batch i-1 run around the GP fits of batch i).
 """
 from __future__ import annotations
 
@@ -39,8 +41,9 @@ from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
 
 
-def load_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None, device=None):
-    """gen_ps.py:37-77: load, build features from UN-aligned xyz, axis-align, boxes, wall boxes."""
+def read_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
+    """gen_ps.py:37-69, the disk / host half (thread-safe, no device work): load the scene, build the features
+    from UN-aligned xyz, axis-align, read the wall quads."""
     scan_name = filename.split("/")[-1][:12]
     xyz, rgb, semantic_label, instance_label = torch.load(filename, weights_only=False)
     spp = torch.load(osp.join(data_root, "superpoints", scan_name + ".pth"), weights_only=False)
@@ -54,21 +57,32 @@ def load_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None, de
     pts = np.ones((xyz.shape[0], 4))
     pts[:, 0:3] = xyz[:, 0:3]
     xyz_al = np.dot(pts, A.transpose())[:, :3]  # :65-69
-    if device is not None:  # the driver: GT boxes in one pass on the device (gapro_instance_info)
-        info = getInstanceInfo_device(xyz_al, instance_label, semantic_label, device=device)
-    else:  # no device given: the reference's host function, mirrored
-        info = getInstanceInfo(xyz_al, instance_label=instance_label, semantic_label=semantic_label)
-    if info is None:
-        return None
-    _, instance_cls, instance_box, instance_box_volume, _ = info
     wall_cls, wall_box, wall_volume = get_wall_boxes(scan_name, data_root=data_root)
     return dict(scan_name=scan_name, coords_float=xyz_al, mask_feats=np.asarray(mask_feats, dtype=np.float32),
-                spp=spp.astype(np.int64), instance_cls=np.asarray(instance_cls).astype(np.int64),
-                instance_box=instance_box.astype(np.float32),
-                instance_box_volume=instance_box_volume.astype(np.float32),
+                spp=spp.astype(np.int64),
                 wall_box=np.asarray(wall_box, dtype=np.float32) if len(wall_box) else [],
                 wall_box_volume=np.asarray(wall_volume, dtype=np.float32) if len(wall_box) else [],
                 semantic_label=semantic_label, instance_label=instance_label)
+
+
+def add_instance_info(sc, device=None):
+    """gen_ps.py:71-77: the GT boxes of a scene read by read_scene; None when the scene has no instance."""
+    if device is not None:  # the driver: one pass on the device (gapro_instance_info)
+        info = getInstanceInfo_device(sc["coords_float"], sc["instance_label"], sc["semantic_label"], device=device)
+    else:  # no device given: the reference's host function, mirrored
+        info = getInstanceInfo(sc["coords_float"], instance_label=sc["instance_label"],
+                               semantic_label=sc["semantic_label"])
+    if info is None:
+        return None
+    _, instance_cls, instance_box, instance_box_volume, _ = info
+    sc.update(instance_cls=np.asarray(instance_cls).astype(np.int64), instance_box=instance_box.astype(np.float32),
+              instance_box_volume=instance_box_volume.astype(np.float32))
+    return sc
+
+
+def load_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None, device=None):
+    """gen_ps.py:37-77: load, build features from UN-aligned xyz, axis-align, boxes, wall boxes."""
+    return add_instance_info(read_scene(filename, data_root, use_deepfeat, deepfeat_folder), device)
 
 
 def save_scene(save_path, outs, spp_inv=None, broadcast_mu_var=False):
@@ -83,39 +97,54 @@ def save_scene(save_path, outs, spp_inv=None, broadcast_mu_var=False):
 
 
 def run_worker(filenames, args, device_index):
+    """One GPU: scenes are read from disk by a pool of loader threads (a batch ahead), go through the
+    software-pipelined generator batch by batch (Pipeline.run_stream), and are written by the same pool."""
+    import concurrent.futures as cf
+
     pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
     dev = pipe.device
     done = failed = 0
     t0 = time.time()
     pending = pending_scenes(filenames, args.save_folder)  # :39-41
-    for i in range(0, len(pending), args.batch_scenes):
-        scenes = []
-        for fn in pending[i:i + args.batch_scenes]:
-            try:
-                sc = load_scene(fn, args.data_root, args.use_deepfeat, args.deepfeat_folder, device=dev)
-                if sc is None:
-                    print("[gen_ps] %s: no instances, skipped" % fn, file=sys.stderr)
+    chunks = [pending[i:i + args.batch_scenes] for i in range(0, len(pending), args.batch_scenes)]
+    pool = cf.ThreadPoolExecutor(max_workers=max(1, args.loader_threads))
+    meta = []  # per yielded batch: (scenes, jobs)
+
+    def submit(chunk):
+        return [(fn, pool.submit(read_scene, fn, args.data_root, args.use_deepfeat, args.deepfeat_folder)) for fn in chunk]
+
+    def batches():
+        nonlocal failed
+        ahead = [submit(c) for c in chunks[:2]]  # the disk reads of two batches are in flight
+        for k in range(len(chunks)):
+            futs = ahead.pop(0)
+            if k + 2 < len(chunks):
+                ahead.append(submit(chunks[k + 2]))
+            scenes = []
+            for fn, fut in futs:
+                try:
+                    sc = add_instance_info(fut.result(), dev)
+                    if sc is None:
+                        print("[gen_ps] %s: no instances, skipped" % fn, file=sys.stderr)
+                        failed += 1
+                        continue
+                    scenes.append(sc)
+                except Exception as e:  # noqa: BLE001 - one bad scene must not kill the run
+                    print("[gen_ps] %s: load failed: %r" % (fn, e), file=sys.stderr)
                     failed += 1
-                    continue
-                scenes.append(sc)
-            except Exception as e:  # noqa: BLE001 - one bad scene must not kill the run
-                print("[gen_ps] %s: load failed: %r" % (fn, e), file=sys.stderr)
-                failed += 1
-        if not scenes:
-            continue
-        try:
+            if not scenes:
+                continue
             jobs = [make_job(s["coords_float"], s["mask_feats"], s["spp"], s["instance_cls"], s["instance_box"],
                              s["instance_box_volume"], s["wall_box"], s["wall_box_volume"],
                              instance_classes=18, ground_h=0.1, thresh_spp_occu=0.999, device=dev)  # :106-110
                     for s in scenes]
-            outs = pipe.run(jobs)
-        except Exception as e:  # noqa: BLE001
-            print("[gen_ps] batch starting at %s failed: %r" % (scenes[0]["scan_name"], e), file=sys.stderr)
-            failed += len(scenes)
-            continue
+            meta.append((scenes, jobs))
+            yield jobs
+
+    writes = []
+    for outs in pipe.run_stream(batches()):
+        scenes, jobs = meta.pop(0)
         for s, job, o in zip(scenes, jobs, outs):
-            save_scene(osp.join(args.save_folder, s["scan_name"] + ".pth"), o, job.spp_inv, args.broadcast_mu_var)
-            done += 1
             if args.eval_pslabel:
                 from .eval_ps_labels import get_miou_scene
 
@@ -125,6 +154,14 @@ def run_worker(filenames, args, device_index):
                 sem_gt[(sem_gt == -1) | (sem_gt == -2)] = 18
                 ious = get_miou_scene(sem_gt.long(), ins_gt.long(), o[0].long(), o[1].long())
                 print("miou", ious)
+            host = tuple(t.cpu() for t in o)  # device -> host here; the file write goes to the pool
+            inv = job.spp_inv.cpu() if args.broadcast_mu_var else None
+            writes.append(pool.submit(save_scene, osp.join(args.save_folder, s["scan_name"] + ".pth"), host, inv,
+                                      args.broadcast_mu_var))
+            done += 1
+    for w in writes:
+        w.result()
+    pool.shutdown()
     dt = time.time() - t0
     print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)"
           % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0))
@@ -141,10 +178,11 @@ def main(argv=None):
     parser.add_argument("--data_root", type=str, default="dataset/scannetv2")
     parser.add_argument("--split", type=str, default="train", choices=["train", "val"])
     parser.add_argument("--devices", type=str, default="0")
-    parser.add_argument("--batch_scenes", type=int, default=8)
+    parser.add_argument("--batch_scenes", type=int, default=32)
     parser.add_argument("--init_mean_std", type=float, default=0.0)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--broadcast_mu_var", action="store_true")
+    parser.add_argument("--loader_threads", type=int, default=4)
     parser.add_argument("--worker_rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = parser.parse_args(argv)
 

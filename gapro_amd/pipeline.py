@@ -348,27 +348,7 @@ class Pipeline:
         ready = torch.cuda.current_stream(self.device).record_event()
         for st in self._streams:
             st.wait_event(ready)
-        n = len(batches)
-        states = [None] * n
-
-        def on(i, fn, *a):
-            with torch.cuda.stream(self._streams[i % 2]):
-                return fn(*a)
-
-        if n:
-            states[0] = on(0, self._partition, batches[0], False)
-            on(0, self._schedule_all, states[0])
-        for i in range(n):
-            if i + 1 < n:
-                states[i + 1] = on(i + 1, self._partition, batches[i + 1], False)
-            on(i, self._launch, states[i])
-            if i + 1 < n:
-                on(i + 1, self._schedule_all, states[i + 1])
-            if i > 0:
-                outs.append(on(i - 1, self._finish, states[i - 1], False))
-                states[i - 1] = None
-        if n:
-            outs.append(on(n - 1, self._finish, states[n - 1], True))
+        outs = list(self._stream_batches(iter(batches)))
         for st in self._streams:
             torch.cuda.current_stream(self.device).wait_stream(st)
         return outs
@@ -386,6 +366,46 @@ class Pipeline:
                     self._ws[k] = None  # release before growing
                     self._ws[k] = torch.zeros(size, dtype=torch.float64, device=self.device)
         return self._ws[slot][:n_doubles]
+
+    def run_stream(self, batches):
+        """run_pipelined for an ITERATOR of batches (e.g. a dataset being read from disk): yields the outputs of
+        every batch, in order, one batch behind the one being launched.  The consumer may use the yielded
+        tensors on the current stream right away (they are ordered after the pipeline's streams)."""
+        if not hasattr(self, "_streams"):
+            self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            for st in self._streams:
+                self._ws.setdefault("s%x" % int(st.cuda_stream), None)
+        ready = torch.cuda.current_stream(self.device).record_event()
+        for st in self._streams:
+            st.wait_event(ready)
+        for i, out in enumerate(self._stream_batches(iter(batches))):
+            torch.cuda.current_stream(self.device).wait_stream(self._streams[i % 2])
+            yield out
+
+    def _stream_batches(self, it):
+        """The software pipeline of run_pipelined / run_stream over an iterator (lookahead of one batch)."""
+        def on(i, fn, *a):
+            with torch.cuda.stream(self._streams[i % 2]):
+                return fn(*a)
+
+        cur = next(it, None)
+        if cur is None:
+            return
+        i = 0
+        cur_state = on(0, self._partition, cur, False)
+        on(0, self._schedule_all, cur_state)
+        prev_state = None
+        while cur_state is not None:
+            nxt = next(it, None)
+            nxt_state = on(i + 1, self._partition, nxt, False) if nxt is not None else None
+            on(i, self._launch, cur_state)
+            if nxt_state is not None:
+                on(i + 1, self._schedule_all, nxt_state)
+            if prev_state is not None:
+                yield on(i - 1, self._finish, prev_state, False)
+            prev_state, cur_state = cur_state, nxt_state
+            i += 1
+        yield on(i - 1, self._finish, prev_state, True)
 
     def _pinned(self, tag: str, nbytes: int) -> torch.Tensor:
         """Growable page-locked staging buffers, reused across batches (hipHostMalloc is slow)."""

@@ -76,3 +76,22 @@ def test_cli_end_to_end_and_resume(tmp_path, capsys):
     assert sorted(os.listdir(save)) == files
     assert os.path.getmtime(os.path.join(save, files[0])) == stamp[files[0]]
     assert "Finish" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_cli_batching_does_not_change_the_files(tmp_path):
+    """Five scenes as 3 pipelined batches of <= 2 and as one batch of 5: identical outputs, scene by scene."""
+    from gapro_amd import gen_ps
+
+    root, scenes = _dataset(tmp_path, 5)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    gen_ps.main(["--save_folder", a, "--data_root", root, "--batch_scenes", "2", "--loader_threads", "2"])
+    gen_ps.main(["--save_folder", b, "--data_root", root, "--batch_scenes", "5", "--broadcast_mu_var"])
+    for s in scenes:
+        x = torch.load(os.path.join(a, s.scan_name + ".pth"), weights_only=False)
+        y = torch.load(os.path.join(b, s.scan_name + ".pth"), weights_only=False)
+        for u, v in zip(x[:3], y[:3]):
+            np.testing.assert_array_equal(u, v)
+        _, inv = np.unique(s.spp, return_inverse=True)
+        np.testing.assert_array_equal(x[3][inv], y[3])  # --broadcast_mu_var = superpoint values at point length
+        np.testing.assert_array_equal(x[4][inv], y[4])
