@@ -90,6 +90,10 @@ SIGNATURES = {
     "gapro_eval_miou": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P, _P, _P,
                                   _P]),
     "gapro_eval_sem_confusion": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, _P]),
+    "gapro_label_pool_mean": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gapro_weighted_bce_with_logits": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "gapro_kl_gp_loss": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P,
+                                   _P]),
     "gapro_schedule_build": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, C.POINTER(_P)]),
     "gapro_schedule_free": (None, [_P]),
     "gapro_schedule_get_counts": (C.c_int, [_P, C.POINTER(ScheduleCounts)]),

@@ -203,6 +203,31 @@ int gapro_eval_sem_confusion(gapro_ctx* ctx, void* stream, int64_t n_points, con
                              const int64_t* d_ps_semantic_label, int32_t num_classes, int64_t* d_conf);
 
 /* ------------------------------------------------------------------------------------------
+ * Consumer-side label ops: what the training code does with the generated labels.
+ * Forward values and the gradients w.r.t. the network outputs come out of the same call; reductions are
+ * float64 sums of float32 terms.  `grad_out` scales the gradients (pass 1 and multiply later to stay async).
+ * ---------------------------------------------------------------------------------------- */
+/* custom_scatter_mean (ISBNet/isbnet/model/model_utils.py:600-613) of the three label channels at once
+ * (isbnet.py:387-389): out[s] = mean of the points with index s (count clamped at 1, as torch_scatter does).
+ *   d_index i64[N] in [0, n_out), d_sums_ws f64[3 n_out] and d_counts_ws i32[n_out] are scratch. */
+int gapro_label_pool_mean(gapro_ctx* ctx, void* stream, int64_t n_points, int32_t n_out, const int64_t* d_index,
+                          const float* d_prob, const float* d_mu, const float* d_var, double* d_sums_ws,
+                          int32_t* d_counts_ws, float* d_out_prob, float* d_out_mu, float* d_out_var);
+/* Probability-weighted BCE with logits (ISBNet/isbnet/model/criterion.py:287-288):
+ *   loss = sum_{g,p} bce(x[g][p], y[g][p]) w[p] / sum_p w[p] / (G + 1e-6),  x, y f32[G,P] row-major, w f32[P];
+ *   d_grad_logits f32[G,P] or NULL; d_acc2 f64[2] scratch. */
+int gapro_weighted_bce_with_logits(gapro_ctx* ctx, void* stream, int32_t n_rows, int64_t n_cols, const float* d_logits,
+                                   const float* d_targets, const float* d_weights, float grad_out, double* d_acc2,
+                                   float* d_loss, float* d_grad_logits);
+/* KL-to-GP auxiliary loss (ISBNet/isbnet/model/criterion.py:435-463): labels of -100 are ignored; GP variances
+ * <= epsilon use the (exp(logvar) - 1)^2 + (mu - mu_l)^2 branch, the others the Gaussian KL expression; each
+ * branch is averaged over its own count (+1e-4) and scaled by `weight`.  Gradients w.r.t. mu_pred / logvar_pred
+ * (f32[n], or both NULL); d_acc4 f64[4] scratch. */
+int gapro_kl_gp_loss(gapro_ctx* ctx, void* stream, int64_t n, const float* d_mu_labels, const float* d_var_labels,
+                     const float* d_mu_pred, const float* d_logvar_pred, float epsilon, float weight, float grad_out,
+                     double* d_acc4, float* d_loss, float* d_grad_mu, float* d_grad_logvar);
+
+/* ------------------------------------------------------------------------------------------
  * Static pair schedule and merge (host).  Replaces the control flow of gen_ps_utils.py:365-476.
  * Which pairs are fitted and on which superpoints depends only on (boxes, bb_occupancy_spp),
  * never on GP outputs, so the whole schedule is enumerated before any fit runs.
