@@ -90,6 +90,9 @@ SIGNATURES = {
     "gapro_eval_miou": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_int32, C.c_int32, _P, C.c_size_t, _P, _P, _P,
                                   _P]),
     "gapro_eval_sem_confusion": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, _P]),
+    "gapro_label_heuristic_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "gapro_label_heuristic": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32,
+                                        C.c_int32, _P, C.c_size_t, _P, _P]),
     "gapro_label_pool_mean": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_weighted_bce_with_logits": (C.c_int, [_P, _P, C.c_int32, C.c_int64, _P, _P, _P, C.c_float, _P, _P, _P]),
     "gapro_kl_gp_loss": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P, _P,

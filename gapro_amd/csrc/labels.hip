@@ -328,6 +328,214 @@ __global__ __launch_bounds__(kThreads) void k_sem_conf(long long n, const long l
     if (s_conf[j]) atomicAdd((unsigned long long*)&conf[j], (unsigned long long)s_conf[j]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Heuristic labelers: gen_pseudo_label (gen_ps_utils.py:485-569) and gen_pseudo_label_box2mask (:242-290)
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLabMaxBoxes = 256;
+constexpr int kLabChunk = 2048;  // points per workgroup in the multi-box rank scan (256 threads x 8)
+
+struct LabWs {
+  unsigned long long* bits;  // [N][W] occupancy bits of every point
+  int* raw;                  // [N] label before the superpoint alignment: box, -1 (no box), -2 (rule "none")
+  unsigned* chunk;           // [ceil(N / kLabChunk) + 1] multi-box points per chunk -> exclusive offsets
+  int* label_count;          // [S][B + 1]
+  int* occ_count;            // [S][B]
+  int* point_count;          // [S]
+  int* label_spp;            // [S]
+};
+__host__ __device__ inline size_t lab_align(size_t x) { return (x + 255) / 256 * 256; }
+__host__ __device__ inline LabWs lab_ws(void* ws, long long n, int S, int B) {
+  const int W = (B + 63) / 64;
+  char* p = (char*)ws;
+  LabWs t;
+  t.bits = (unsigned long long*)p; p += lab_align((size_t)n * W * 8);
+  t.raw = (int*)p; p += lab_align((size_t)n * 4);
+  t.chunk = (unsigned*)p; p += lab_align(((size_t)(n + kLabChunk - 1) / kLabChunk + 1) * 4);
+  t.label_count = (int*)p; p += lab_align((size_t)S * (B + 1) * 4);
+  t.occ_count = (int*)p; p += lab_align((size_t)S * B * 4);
+  t.point_count = (int*)p; p += lab_align((size_t)S * 4);
+  t.label_spp = (int*)p;
+  return t;
+}
+
+// box corners with the 0.005 margin applied in float32 to the float32 box (:502-504), compared in float64
+__device__ inline void lab_stage_boxes(const float* __restrict__ box, int B, double* sh) {
+  for (int j = threadIdx.x; j < B * 6; j += kThreads) {
+    const int c = j % 6;
+    sh[j] = (double)(c < 3 ? box[j] - 0.005f : box[j] + 0.005f);
+  }
+  __syncthreads();
+}
+
+// K1: occupancy bits, number of boxes, label for every rule except the multi-box case of "dist"
+__global__ __launch_bounds__(kThreads) void k_lab_points(long long n, const double* __restrict__ coords, int B,
+                                                         const float* __restrict__ box, const float* __restrict__ vol,
+                                                         int rule, LabWs t) {
+  extern __shared__ double sh_box[];
+  lab_stage_boxes(box, B, sh_box);
+  const int W = (B + 63) / 64;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    int nbb = 0, first = -1, best = -1;
+    float best_v = 0.f;
+    for (int w = 0; w < W; ++w) {
+      unsigned long long bits = 0;
+      const int b_end = min(B, (w + 1) * 64);
+      for (int b = w * 64; b < b_end; ++b) {
+        const double* bx = sh_box + 6 * b;
+        const bool in = (x >= bx[0]) & (y >= bx[1]) & (z >= bx[2]) & (x <= bx[3]) & (y <= bx[4]) & (z <= bx[5]);
+        if (in) {
+          bits |= 1ull << (b - w * 64);
+          if (nbb == 0) first = b;
+          const float v = vol[b];
+          if (nbb == 0 || v < best_v) {  // scatter_min: strict '<', the first minimum wins
+            best_v = v;
+            best = b;
+          }
+          ++nbb;
+        }
+      }
+      t.bits[i * W + w] = bits;
+    }
+    int lab;
+    if (nbb == 0) lab = -1;
+    else if (nbb == 1) lab = first;
+    else lab = rule == 0 ? best : (rule == 2 ? -2 : -3);  // -3: "dist", resolved by k_lab_dist
+    t.raw[i] = lab;
+  }
+}
+
+// multi-box points per chunk, then exclusive offsets (one workgroup)
+__global__ __launch_bounds__(kThreads) void k_lab_chunk_count(long long n, LabWs t) {
+  const long long base = (long long)blockIdx.x * kLabChunk;
+  int c = 0;
+  for (int j = threadIdx.x; j < kLabChunk; j += kThreads) {
+    const long long i = base + j;
+    if (i < n && t.raw[i] == -3) ++c;
+  }
+  __shared__ int sh[kThreads / 64];
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int j = 0; j < kThreads / 64; ++j) s += sh[j];
+    t.chunk[blockIdx.x] = (unsigned)s;
+  }
+}
+__global__ __launch_bounds__(kThreads) void k_lab_chunk_scan(int n_chunks, LabWs t) {
+  if (threadIdx.x != 0) return;  // a few dozen chunks per scene
+  unsigned run = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const unsigned v = t.chunk[c];
+    t.chunk[c] = run;
+    run += v;
+  }
+  t.chunk[n_chunks] = run;
+}
+// "dist" (:523-531), reproducing the reference's indexing: the k-th multi-box point (k = its rank among the
+// multi-box points) is measured from the coordinates of SCENE POINT k, not from its own
+__global__ __launch_bounds__(kThreads) void k_lab_dist(long long n, const double* __restrict__ coords, int B,
+                                                       const float* __restrict__ box, LabWs t) {
+  extern __shared__ double sh_center[];  // [B][3], (lo + hi) / 2 in float32 (:497)
+  for (int j = threadIdx.x; j < B * 3; j += kThreads) {
+    const int b = j / 3, k = j - 3 * b;
+    sh_center[j] = (double)((box[6 * b + k] + box[6 * b + 3 + k]) / 2.0f);
+  }
+  __shared__ int s_rank[kThreads / 64];
+  __syncthreads();
+  const int W = (B + 63) / 64;
+  const long long base = (long long)blockIdx.x * kLabChunk;
+  unsigned run = t.chunk[blockIdx.x];
+  // eight sub-blocks of 256 consecutive points: rank = chunk offset + multi-box points before this one
+  for (int sub = 0; sub < kLabChunk / kThreads; ++sub) {
+    const long long i = base + sub * kThreads + threadIdx.x;
+    const bool multi = i < n && t.raw[i] == -3;
+    const unsigned long long ball = __ballot(multi);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_rank[w] = __popcll(ball);
+    __syncthreads();
+    unsigned before = run + __popcll(ball & ((1ull << lane) - 1ull));
+    unsigned total = 0;
+    for (int j = 0; j < kThreads / 64; ++j) {
+      if (j < w) before += s_rank[j];
+      total += s_rank[j];
+    }
+    if (multi) {
+      const long long k = before;  // coordinates of scene point k
+      const double x = coords[3 * k], y = coords[3 * k + 1], z = coords[3 * k + 2];
+      int best = -1;
+      double best_d = 0.0;
+      for (int b = 0; b < B; ++b) {
+        if (!((t.bits[i * W + (b >> 6)] >> (b & 63)) & 1ull)) continue;
+        const double dx = x - sh_center[3 * b], dy = y - sh_center[3 * b + 1], dz = z - sh_center[3 * b + 2];
+        const double d = dx * dx + dy * dy + dz * dz;
+        if (best < 0 || d < best_d) {
+          best_d = d;
+          best = b;
+        }
+      }
+      t.raw[i] = best;
+    }
+    run += total;
+    __syncthreads();
+  }
+}
+
+// per-superpoint tallies for the alignment (:539-553 / :277-283)
+__global__ __launch_bounds__(kThreads) void k_lab_tally(long long n, const int* __restrict__ spp_inv, int B, int masked,
+                                                        LabWs t) {
+  const int W = (B + 63) / 64;
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    const int s = spp_inv[i], lab = t.raw[i];
+    atomicAdd(&t.label_count[(long long)s * (B + 1) + (lab >= 0 ? lab + 1 : 0)], 1);
+    if (masked) {
+      atomicAdd(&t.point_count[s], 1);
+      for (int w = 0; w < W; ++w) {
+        unsigned long long bits = t.bits[i * W + w];
+        while (bits) {
+          const int b = __ffsll((long long)bits) - 1;
+          bits &= bits - 1;
+          atomicAdd(&t.occ_count[(long long)s * B + 64 * w + b], 1);
+        }
+      }
+    }
+  }
+}
+// spp_align_label (:99-123): argmax of the label counts (first maximum), box rows masked by
+// bb_occupancy_spp = mean occupancy >= 0.7 (float32, :545) when `masked`
+__global__ __launch_bounds__(kThreads) void k_lab_argmax(int S, int B, int masked, LabWs t) {
+  const int s = blockIdx.x * kThreads + threadIdx.x;
+  if (s >= S) return;
+  const float pc = (float)(t.point_count[s] > 0 ? t.point_count[s] : 1);
+  int best = 0, best_c = t.label_count[(long long)s * (B + 1)];
+  for (int l = 1; l <= B; ++l) {
+    int c = t.label_count[(long long)s * (B + 1) + l];
+    if (masked && !((float)t.occ_count[(long long)s * B + l - 1] / pc >= 0.7f)) c = 0;
+    if (c > best_c) {
+      best_c = c;
+      best = l;
+    }
+  }
+  t.label_spp[s] = best;
+}
+__global__ __launch_bounds__(kThreads) void k_lab_final(long long n, const int* __restrict__ spp_inv, int align,
+                                                        const long long* __restrict__ cls, int instance_classes,
+                                                        LabWs t, int* __restrict__ sem, int* __restrict__ inst) {
+  const long long stride = (long long)gridDim.x * kThreads;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+    int lab = t.raw[i];
+    if (align) {
+      const int v = t.label_spp[spp_inv[i]];
+      lab = v > 0 ? v - 1 : -1;  // :551-553
+    }
+    sem[i] = lab >= 0 ? (int)cls[lab] : (lab == -1 ? instance_classes : -100);
+    inst[i] = lab >= 0 ? lab : -100;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -408,6 +616,53 @@ int gapro_eval_sem_confusion(gapro_ctx* ctx, void* stream_, int64_t n_points, co
   hipLaunchKernelGGL(k_sem_conf, dim3(grid_for(n_points, 256)), dim3(kThreads), bins * sizeof(int), stream,
                      (long long)n_points, (const long long*)d_semantic_label, (const long long*)d_ps_semantic_label,
                      (int)num_classes, (long long*)d_conf);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+size_t gapro_label_heuristic_workspace_bytes(int64_t n_points, int32_t n_spps, int32_t n_boxes) {
+  if (n_points < 1) n_points = 1;
+  if (n_spps < 1) n_spps = 1;
+  if (n_boxes < 1) n_boxes = 1;
+  LabWs t = lab_ws(nullptr, n_points, n_spps, n_boxes);
+  return (size_t)((char*)t.label_spp - (char*)nullptr) + lab_align((size_t)n_spps * 4);
+}
+
+int gapro_label_heuristic(gapro_ctx* ctx, void* stream_, int64_t n_points, const double* d_coords,
+                          const int32_t* d_spp_inv, int32_t n_spps, int32_t n_boxes, const float* d_box,
+                          const float* d_volume, const int64_t* d_cls, int32_t rule, int32_t align,
+                          int32_t instance_classes, void* d_workspace, size_t workspace_bytes, int32_t* d_sem,
+                          int32_t* d_inst) {
+  if (!ctx) return GAPRO_ERR_BAD_ARG;
+  if (n_points <= 0 || !d_coords || n_boxes <= 0 || n_boxes > kLabMaxBoxes || !d_box || !d_volume || !d_cls ||
+      rule < 0 || rule > 3 || !d_workspace || !d_sem || !d_inst || (align && (!d_spp_inv || n_spps <= 0)))
+    return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_label_heuristic: bad argument");
+  if (workspace_bytes < gapro_label_heuristic_workspace_bytes(n_points, n_spps, n_boxes))
+    return gapro_fail(ctx, GAPRO_ERR_WORKSPACE, "gapro_label_heuristic: workspace too small");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = n_boxes, S = align ? n_spps : 1;
+  LabWs t = lab_ws(d_workspace, n_points, n_spps, n_boxes);
+  const int box2mask = rule == 3;  // volume rule, alignment without the occupancy mask (:277-283)
+  hipLaunchKernelGGL(k_lab_points, dim3(grid_for(n_points, 2048)), dim3(kThreads), (size_t)B * 6 * sizeof(double), stream,
+                     (long long)n_points, d_coords, B, d_box, d_volume, box2mask ? 0 : (int)rule, t);
+  if (rule == 1) {
+    const int n_chunks = (int)((n_points + kLabChunk - 1) / kLabChunk);
+    hipLaunchKernelGGL(k_lab_chunk_count, dim3(n_chunks), dim3(kThreads), 0, stream, (long long)n_points, t);
+    hipLaunchKernelGGL(k_lab_chunk_scan, dim3(1), dim3(kThreads), 0, stream, n_chunks, t);
+    hipLaunchKernelGGL(k_lab_dist, dim3(n_chunks), dim3(kThreads), (size_t)B * 3 * sizeof(double), stream,
+                       (long long)n_points, d_coords, B, d_box, t);
+  }
+  if (align) {
+    const int masked = box2mask ? 0 : 1;
+    GAPRO_HIP_CHECK(ctx, hipMemsetAsync(t.label_count, 0, (size_t)S * (B + 1) * 4, stream));
+    GAPRO_HIP_CHECK(ctx, hipMemsetAsync(t.occ_count, 0, (size_t)S * B * 4, stream));
+    GAPRO_HIP_CHECK(ctx, hipMemsetAsync(t.point_count, 0, (size_t)S * 4, stream));
+    hipLaunchKernelGGL(k_lab_tally, dim3(grid_for(n_points, 2048)), dim3(kThreads), 0, stream, (long long)n_points,
+                       d_spp_inv, B, masked, t);
+    hipLaunchKernelGGL(k_lab_argmax, dim3((S + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, S, B, masked, t);
+  }
+  hipLaunchKernelGGL(k_lab_final, dim3(grid_for(n_points, 2048)), dim3(kThreads), 0, stream, (long long)n_points,
+                     d_spp_inv, (int)(align != 0), (const long long*)d_cls, (int)instance_classes, t, d_sem, d_inst);
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
 }

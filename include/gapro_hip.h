@@ -202,6 +202,20 @@ int gapro_eval_miou(gapro_ctx* ctx, void* stream, int64_t n_points, const int64_
 int gapro_eval_sem_confusion(gapro_ctx* ctx, void* stream, int64_t n_points, const int64_t* d_semantic_label,
                              const int64_t* d_ps_semantic_label, int32_t num_classes, int64_t* d_conf);
 
+/* Heuristic labelers: gen_pseudo_label (gen_ps_utils.py:485-569; rule 0 = "volume",
+ * 1 = "dist", 2 = "none") and gen_pseudo_label_box2mask (:242-290; rule 3).  Membership in the INSTANCE boxes
+ * (float32 box, 0.005 margin applied in float32, compared in float64), the rule for points inside several boxes,
+ * then (align != 0, the scannetv2 branch) the superpoint vote spp_align_label (:99-123) with the >= 0.7
+ * occupancy mask (not for box2mask).  "dist" reproduces the reference's indexing of the coordinate array by the
+ * rank among the multi-box points (:525).  d_spp_inv = dense superpoint ranks from gapro_partition_prepare.
+ *   out: d_sem i32[N] (class, instance_classes for background, -100), d_inst i32[N] (box index or -100) */
+size_t gapro_label_heuristic_workspace_bytes(int64_t n_points, int32_t n_spps, int32_t n_boxes);
+int gapro_label_heuristic(gapro_ctx* ctx, void* stream, int64_t n_points, const double* d_coords,
+                          const int32_t* d_spp_inv, int32_t n_spps, int32_t n_boxes, const float* d_box,
+                          const float* d_volume, const int64_t* d_cls, int32_t rule, int32_t align,
+                          int32_t instance_classes, void* d_workspace, size_t workspace_bytes, int32_t* d_sem,
+                          int32_t* d_inst);
+
 /* ------------------------------------------------------------------------------------------
  * Consumer-side label ops: what the training code does with the generated labels.
  * Forward values and the gradients w.r.t. the network outputs come out of the same call; reductions are
