@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scenes-per-step", type=int, default=64)
+    ap.add_argument("--scenes-per-step", type=int, default=256)
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--feat-dim", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
