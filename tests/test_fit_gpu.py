@@ -175,3 +175,23 @@ def test_strip_and_staged_kernels_agree():
         np.testing.assert_allclose(x[4], y[4], rtol=1e-6)
         np.testing.assert_allclose(x[3], y[3], rtol=1e-5, atol=1e-7)
         np.testing.assert_array_equal(x[2], y[2])
+
+
+def test_fit_reports_non_finite_inputs_instead_of_returning_garbage():
+    """A NaN feature makes K_ZZ non-finite: the Cholesky flags it on the device and the host raises (gpytorch
+    raises NotPSDError / NanError in the same situation); the other fits of the batch do not hide it."""
+    from gapro_amd._lib import GaproError
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    f0, b1, b2, it = make_gp_problem(1, 10, 12, 5, 6)
+    f1, c1, c2, ct = make_gp_problem(2, 40, 30, 9, 6)
+    f1 = f1.copy()
+    f1[c1[3], 2] = np.nan
+    feats = np.concatenate([f0, f1])
+    off = len(f0)
+    with pytest.raises(GaproError) as e:
+        fit_gp_spp_batch(feats, [(b1, b2, it), (c1 + off, c2 + off, ct + off)], training_iter=5)
+    assert e.value.code in (-4, -5)
+    ok = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=5)[0]  # the clean fit alone is fine
+    assert np.isfinite(ok[3]).all()
