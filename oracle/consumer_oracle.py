@@ -25,22 +25,30 @@ def scatter_mean3(prob, mu, var, idx, n_out=None):
     return tuple(outs)
 
 
-def weighted_bce(mask_logit_pred, inst_label, prob_labels_b):
-    num_gt_batch = mask_logit_pred.shape[0]
-    bce_loss = F.binary_cross_entropy_with_logits(mask_logit_pred, inst_label, reduction="none")
-    return ((bce_loss * prob_labels_b).sum() / prob_labels_b.sum()).sum() / (num_gt_batch + 1e-6)
+def weighted_bce(logits, targets, point_weights):
+    """criterion.py:287-288: per-element BCE-with-logits, weighted per point (column), normalised by the weight
+    sum and by the number of rows (+1e-6)."""
+    rows = logits.shape[0]
+    per_elem = torch.clamp(logits, min=0) - logits * targets + torch.log1p(torch.exp(-logits.abs()))
+    return (per_elem * point_weights[None, :]).sum() / point_weights.sum() / (rows + 1e-6)
 
 
 def kl_to_gp(mu_pred, logvar_pred, mu_labels, var_labels, weight=1.0, epsilon=1e-4):
-    loss = torch.zeros((), dtype=mu_pred.dtype)
-    mask_kl_varzero = (mu_labels != -100) & (var_labels != -100) & (var_labels <= epsilon)
-    mask_kl_var = (mu_labels != -100) & (var_labels != -100) & (var_labels > epsilon)
-    if mask_kl_varzero.sum() > 0:
-        l0 = (torch.exp(logvar_pred[mask_kl_varzero]) - 1) ** 2 + (mu_pred[mask_kl_varzero] - mu_labels[mask_kl_varzero]) ** 2
-        loss = loss + l0.sum() / (mask_kl_varzero.sum() + 1e-4) * weight
-    if mask_kl_var.sum() > 0:
-        l1 = ((logvar_pred[mask_kl_var] - torch.log(var_labels[mask_kl_var]))
-              + ((mu_pred[mask_kl_var] - mu_labels[mask_kl_var]) ** 2 + var_labels[mask_kl_var] ** 2)
-              * (torch.exp(-2 * logvar_pred[mask_kl_var])) - 0.5)
-        loss = loss + l1.sum() / (mask_kl_var.sum() + 1e-4) * weight
-    return loss
+    """criterion.py:435-463: labelled entries (neither label is -100) split by the GP variance; tiny variances
+    pull the predicted variance to 1 and the mean to the label, the others use the Gaussian KL expression; each
+    group is averaged over its own size (+1e-4) and scaled by ``weight``; an empty group contributes nothing."""
+    labelled = (mu_labels != -100) & (var_labels != -100)
+    tiny = labelled & (var_labels <= epsilon)
+    rest = labelled & (var_labels > epsilon)
+    total = torch.zeros((), dtype=mu_pred.dtype)
+    if bool(tiny.any()):
+        dmu = mu_pred[tiny] - mu_labels[tiny]
+        term = (logvar_pred[tiny].exp() - 1.0).square() + dmu.square()
+        total = total + weight * term.sum() / (tiny.sum() + 1e-4)
+    if bool(rest.any()):
+        v = var_labels[rest]
+        lv = logvar_pred[rest]
+        dmu = mu_pred[rest] - mu_labels[rest]
+        term = (lv - v.log()) + (dmu.square() + v.square()) * torch.exp(-2.0 * lv) - 0.5
+        total = total + weight * term.sum() / (rest.sum() + 1e-4)
+    return total
