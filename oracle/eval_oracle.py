@@ -56,39 +56,40 @@ def get_miou_scene(semantic_label, instance_label, ps_semantic_label, ps_instanc
 
 
 def get_scene_sem_conf(semantic_label, ps_semantic_label, num_classes=19):
-    """eval_ps_labels.py:150-172 (inputs are not modified)."""
-    pos = semantic_label != -100
-    sem = semantic_label[pos].clone()
-    ps = ps_semantic_label[pos].clone()
-    unl = ps == -100
-    ps[unl] = torch.where(sem[unl] < 18, sem[unl] + 1, sem[unl] - 1)
-    x = ps + num_classes * sem
-    return torch.bincount(x.long(), minlength=num_classes**2).reshape(num_classes, num_classes)
+    """eval_ps_labels.py:150-172: confusion counts conf[gt, pseudo] over the points whose GT class is not -100; a
+    pseudo label of -100 is replaced by a class that is certainly wrong (gt + 1, or gt - 1 for gt >= 18)."""
+    keep = semantic_label != -100
+    gt = semantic_label[keep].long()
+    ps = ps_semantic_label[keep].long()
+    wrong = torch.where(gt < 18, gt + 1, gt - 1)
+    ps = torch.where(ps == -100, wrong, ps)
+    flat = gt * num_classes + ps
+    return torch.bincount(flat, minlength=num_classes * num_classes).view(num_classes, num_classes)
 
 
 def get_instance_info(xyz, instance_label, semantic_label, scannet=True):
-    """gen_ps_utils.py:195-239, the literal loop: (instance_num, cls, box[B,6], volume[B], corners f32[N,6])."""
-    xyz = np.asarray(xyz, dtype=np.float64)
-    instance_label = np.asarray(instance_label)
-    semantic_label = np.asarray(semantic_label)
-    instance_num = int(instance_label.max()) + 1
-    corners = np.ones((xyz.shape[0], 6), dtype=np.float32) * -100.0
-    cls, box, vol = [], [], []
-    for i_ in range(instance_num):
-        idx = np.where(instance_label == i_)
-        if len(idx[0]) == 0:
+    """gen_ps_utils.py:195-239: for every non-empty instance id in ascending order the box [min | max], the class
+    of the instance's first point (ScanNet: minus 2 unless -100), the volume prod(max(extent, 0)), and per point
+    the float32 offsets to its instance's corners (-100 without instance).
+    Returns (instance_num, cls, box[B,6], volume[B], corners f32[N,6]) or None."""
+    pts = np.asarray(xyz, dtype=np.float64)
+    inst = np.asarray(instance_label)
+    sem = np.asarray(semantic_label)
+    n_ids = int(inst.max()) + 1
+    corners = np.full((len(pts), 6), -100.0, dtype=np.float32)
+    rows = []
+    for ident in range(n_ids):
+        members = np.flatnonzero(inst == ident)
+        if members.size == 0:
             continue
-        sem = semantic_label[idx[0][0]]
-        xyz_i = xyz[idx]
-        mn, mx = xyz_i.min(0), xyz_i.max(0)
-        corners[idx[0], :3] = mn - xyz_i
-        corners[idx[0], 3:] = mx - xyz_i
-        box.append(np.concatenate([mn, mx], axis=0))
-        cls.append(sem)
-        vol.append(np.prod(np.clip(mx - mn, a_min=0.0, a_max=None)))
-    if not cls:
+        p = pts[members]
+        lo, hi = p.min(axis=0), p.max(axis=0)
+        corners[members] = np.concatenate([lo - p, hi - p], axis=1)
+        extent = np.clip(hi - lo, 0.0, None)
+        rows.append((sem[members[0]], np.concatenate([lo, hi]), np.prod(extent)))
+    if not rows:
         return None
-    cls = np.array(cls, dtype=np.float64)
+    cls = np.array([r[0] for r in rows], dtype=np.float64)
     if scannet:
         cls[cls != -100] -= 2
-    return instance_num, cls, np.stack(box, 0), np.array(vol), corners
+    return n_ids, cls, np.stack([r[1] for r in rows]), np.array([r[2] for r in rows]), corners
