@@ -87,7 +87,7 @@ struct Layout {
 };
 inline __host__ __device__ Layout make_layout(int m, int t, int d) {
   Layout L;
-  L.Mp = round_up(m > 0 ? m : 1, 32);
+  L.Mp = gapro_pad_m(m);
   L.Tp = round_up(t > 0 ? t : 1, 32);
   L.D = d;
   L.mat = 0;
@@ -113,11 +113,11 @@ inline __host__ __device__ int scratch_doubles(int Mp) {
   return m > c ? m : c;
 }
 inline __host__ __device__ long long staged_lds_bytes(int m, int d) {
-  const int Mp = round_up(m > 0 ? m : 1, 32);
+  const int Mp = gapro_pad_m(m);
   return 8LL * (2LL * d * Mp + scratch_doubles(Mp));
 }
 inline __host__ __device__ bool staged_ok(int m, int d) {
-  return round_up(m > 0 ? m : 1, 32) <= kMaxMpLds && d <= 32 && staged_lds_bytes(m, d) <= kMaxDynLds;
+  return gapro_pad_m(m) <= kMaxMpLds && d <= 32 && staged_lds_bytes(m, d) <= kMaxDynLds;
 }
 
 enum ScalId { S_C = 0, S_RS, S_RL, S_MC, S_MRS, S_MRL, S_VC, S_VRS, S_VRL, S_LOSS, S_STATUS };
@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   const int fit = blockIdx.x;
   if (fit >= n_fits) return;
   const gapro_fit_desc desc = descs[fit];
-  const int Mp = round_up(desc.m1 + desc.m2, 32);
+  const int Mp = gapro_pad_m(desc.m1 + desc.m2);
   ldsd* Zt = (ldsd*)dyn_lds;
   ldsd* Pt = Zt + D * Mp;
   ldsd* scratch = Pt + D * Mp;
@@ -1346,11 +1346,11 @@ inline __host__ __device__ int strip_region_doubles(int Mp) {
   return a > b ? a : b;
 }
 inline __host__ __device__ long long strip_lds_bytes(int m, int d) {
-  const int Mp = round_up(m > 0 ? m : 1, 32);
+  const int Mp = gapro_pad_m(m);
   return 8LL * (2LL * d * Mp + strip_region_doubles(Mp) + 3 * NT + Mp + 4 * SW + 32);
 }
 inline __host__ __device__ bool strip_ok(int m, int d) {
-  return round_up(m > 0 ? m : 1, 32) <= kStripMaxMp && d <= 32 && strip_lds_bytes(m, d) <= kMaxDynLds;
+  return gapro_pad_m(m) <= kStripMaxMp && d <= 32 && strip_lds_bytes(m, d) <= kMaxDynLds;
 }
 
 enum { K_LE = 0, K_GE = 1 };
@@ -1911,7 +1911,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, con
   const int fit = blockIdx.x;
   if (fit >= n_fits) return;
   const gapro_fit_desc desc = descs[fit];
-  const int Mp = round_up(desc.m1 + desc.m2, 32);
+  const int Mp = gapro_pad_m(desc.m1 + desc.m2);
   ldsd* Zt = (ldsd*)dyn_lds;
   ldsd* Pt = Zt + D * Mp;
   ldsd* region = Pt + D * Mp;

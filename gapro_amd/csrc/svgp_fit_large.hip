@@ -62,7 +62,7 @@ struct Layout {
 };
 inline __host__ __device__ Layout make_layout(int m, int t, int d) {
   Layout L;
-  L.Mp = round_up(m > 0 ? m : 1, 32);
+  L.Mp = gapro_pad_m(m);
   L.Tp = round_up(t > 0 ? t : 1, 32);
   L.D = d;
   L.mat = 0;
