@@ -33,13 +33,14 @@ struct gapro_fit_timing {
   bool used[2] = {false, false};
 };
 
-// Padded size of a fit's M x M matrices: MFMA tiles are 16 wide, so M is rounded up to a multiple of 16; from 128
-// on the products use 32 x 32 wave tiles and M is rounded to a multiple of 32.  (Everything scales with M_p^3:
-// rounding M = 80 to 96 instead of 80 costs 1.7x the work.)
+// Padded size of a fit's M x M matrices: MFMA tiles are 16 wide, so M is rounded up to a multiple of 16 (everything
+// scales with M_p^3: rounding M = 80 to 96 instead of 80 costs 1.7x the work).  The products use 32 x 32 wave tiles
+// from M_p = 128 on where M_p is a multiple of 32, 16 x 16 ones otherwise; beyond 176 the larger tiles win back more
+// than the padding costs (measured), so M is rounded to a multiple of 32 there.
 inline __host__ __device__ int gapro_pad_m(int m) {
   if (m < 1) m = 1;
   const int p16 = (m + 15) / 16 * 16;
-  return p16 <= 112 ? p16 : (m + 31) / 32 * 32;
+  return p16 <= 176 ? p16 : (m + 31) / 32 * 32;
 }
 
 inline int gapro_fail(gapro_ctx* ctx, int code, const char* fmt, ...) {

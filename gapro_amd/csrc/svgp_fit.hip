@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
 #define GAPRO_FIT_BODY(DM, DCV)                                                                              \
   do {                                                                                                       \
-    if (Mp >= 128)                                                                                           \
+    if (Mp >= 128 && Mp % 32 == 0)                                                                           \
       fit_body<2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
     else                                                                                                     \
       fit_body<1, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
