@@ -223,7 +223,7 @@ def main():
             dist.barrier()
 
     if args.warmup:
-        pipe.run_pipelined([make_jobs() for _ in range(args.warmup)])
+        pipe.run_pipelined(make_jobs() for _ in range(args.warmup))
     pipe.profile_fit = True
     pipe.fit_events = []
     pipe.profile_stages = args.stage_times
@@ -235,7 +235,7 @@ def main():
         for _ in range(args.steps):
             pipe.run(make_jobs())
     else:  # K steps back to back; the host work of step i+1 overlaps the fit launch of step i
-        pipe.run_pipelined([make_jobs() for _ in range(args.steps)])
+        pipe.run_pipelined(make_jobs() for _ in range(args.steps))  # jobs of step i+2 are built during fit(i)
     barrier()
     elapsed = time.perf_counter() - t0
     from gapro_amd.dist_utils import barrier_and_max

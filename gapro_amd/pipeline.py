@@ -43,6 +43,30 @@ def _to_np(x, dtype):
     return np.ascontiguousarray(np.asarray(x), dtype=dtype)
 
 
+class LazyViews(dict):
+    """Per-scene views into the batch-wide buffers, created on first access: a batch of 256 scenes would otherwise
+    pay thousands of tensor-view constructions on the host between two fit launches; the kernels only need the
+    addresses, which are plain integer arithmetic."""
+
+    def __init__(self):
+        super().__init__()
+        self._specs = {}
+
+    def spec(self, name, buf, off, nbytes, dtype, shape):
+        self._specs[name] = (buf, off, nbytes, dtype, shape)
+        self.pop(name, None)
+        return buf.data_ptr() + off
+
+    def __missing__(self, name):
+        buf, off, nbytes, dtype, shape = self._specs[name]
+        v = buf[off:off + nbytes].view(dtype).view(*shape)
+        self[name] = v
+        return v
+
+    def __contains__(self, name):
+        return dict.__contains__(self, name) or name in self._specs
+
+
 @dataclass
 class SceneJob:
     """Inputs of one gen_pseudo_label_gaussian_process call (reference gen_ps_utils.py:293-307)."""
@@ -59,19 +83,23 @@ class SceneJob:
     thresh_spp_occu: float = 0.8
     # --- filled by the stages ---
     header: Optional[SceneHeader] = None
-    spp_inv: Optional[torch.Tensor] = None
     n_spps: int = 0
     boxes: Optional[np.ndarray] = None
     boxes_cls: Optional[np.ndarray] = None
     boxes_volume: Optional[np.ndarray] = None
     feats_row_base: int = 0
-    dev: dict = field(default_factory=dict)
-    host: dict = field(default_factory=dict)
+    dev: dict = field(default_factory=LazyViews)
+    host: dict = field(default_factory=LazyViews)
     schedule: Optional[C.c_void_p] = None
     counts: Optional[ScheduleCounts] = None
     fit_base: int = 0
     out_base: int = 0
     outputs: Optional[tuple] = None
+
+    @property
+    def spp_inv(self):
+        """i32[N] dense superpoint rank of every point (view into the batch-wide buffer, created on demand)."""
+        return self.dev["spp_inv"] if "spp_inv" in self.dev else None
 
     @property
     def n_points(self):
@@ -208,18 +236,24 @@ class Pipeline:
         job.header = hdr
         job.n_spps = int(hdr.n_spps)
         job.dev.pop("prep_ws", None)
-        # boxes = cat(instance, wall, floor) with torch's dtype promotion (gen_ps_utils.py:317-345)
-        mn = np.array(list(hdr.coord_min), dtype=np.float64)
-        mx = np.array(list(hdr.coord_max), dtype=np.float64)
-        floor = np.array([[mn[0], mn[1], mn[2], mx[0], mx[1], mn[2] + job.ground_h]], dtype=np.float64)
-        floor_vol = np.prod(np.maximum(floor[:, 3:] - floor[:, :3], 0.001), axis=1)
-        nw = len(job.wall_box)
-        job.boxes = np.ascontiguousarray(np.concatenate(
-            [job.instance_box.astype(np.float64), job.wall_box.astype(np.float64), floor], 0))
-        job.boxes_cls = np.ascontiguousarray(np.concatenate(
-            [job.instance_cls, np.full(nw + 1, job.instance_classes, dtype=np.int64)]))
-        job.boxes_volume = np.ascontiguousarray(np.concatenate(
-            [job.instance_box_volume.astype(np.float64), job.wall_box_volume.astype(np.float64), floor_vol]))
+        # boxes = cat(instance, wall, floor) with torch's dtype promotion (gen_ps_utils.py:317-345); the instance
+        # and wall rows do not depend on the scene statistics and are assembled once per job
+        st = job.host.get("_static")
+        if st is None:
+            nw = len(job.wall_box)
+            st = (np.concatenate([job.instance_box.astype(np.float64), job.wall_box.astype(np.float64),
+                                  np.zeros((1, 6))], 0),
+                  np.ascontiguousarray(np.concatenate([job.instance_cls,
+                                                       np.full(nw + 1, job.instance_classes, dtype=np.int64)])),
+                  np.concatenate([job.instance_box_volume.astype(np.float64), job.wall_box_volume.astype(np.float64),
+                                  np.zeros(1)]))
+            dict.__setitem__(job.host, "_static", st)
+        mn, mx = hdr.coord_min, hdr.coord_max
+        boxes, vol = st[0].copy(), st[2].copy()
+        boxes[-1] = (mn[0], mn[1], mn[2], mx[0], mx[1], mn[2] + job.ground_h)
+        floor = boxes[-1]
+        vol[-1] = max(floor[3] - floor[0], 0.001) * max(floor[4] - floor[1], 0.001) * max(floor[5] - floor[2], 0.001)
+        job.boxes, job.boxes_cls, job.boxes_volume = boxes, st[1], vol
 
     def _prepare(self, job: SceneJob):
         """Single-scene, blocking form (tests)."""
@@ -240,9 +274,9 @@ class Pipeline:
         d_headers = torch.empty(len(jobs) * hsz, dtype=torch.uint8, device=devc)
         pinned = self._pinned("headers%x" % int(torch.cuda.current_stream(devc).cuda_stream), len(jobs) * hsz)
         for t, job, cap, wo, io in zip(tasks, jobs, caps, ws_off, inv_off):
-            job.spp_inv = spp_inv_all[io:io + 4 * job.n_points].view(torch.int32)
-            job.host["range_cap"] = cap
-            t.spp_inv, t.prepare_ws, t.spp_range_cap = job.spp_inv.data_ptr(), prep_ws.data_ptr() + wo, cap
+            t.spp_inv = job.dev.spec("spp_inv", spp_inv_all, io, 4 * job.n_points, torch.int32, (job.n_points,))
+            dict.__setitem__(job.host, "range_cap", cap)
+            t.prepare_ws, t.spp_range_cap = prep_ws.data_ptr() + wo, cap
         self.ctx.check(lib.gapro_partition_prepare_batch(
             self.ctx.handle, _stream_handle(devc), len(jobs), D, C.cast(tasks, C.c_void_p), _ptr(d_tasks),
             _ptr(d_headers), _ptr(pinned)))
@@ -284,25 +318,27 @@ class Pipeline:
         d_tallies = torch.empty(tal_tot, dtype=torch.uint8, device=devc)
         if stage is None:
             stage = torch.empty(tab_tot, dtype=torch.uint8, pin_memory=True)
+        fbase, fstride = feats_spp_all.data_ptr(), 4 * D
         for t, job, bo, to, ao in zip(tasks, jobs, box_off, tab_off, tal_off):
             S, B = job.n_spps, job.n_boxes
             W = (B + 63) // 64
             d = job.dev
-            d["boxes"] = d_boxes[bo:bo + job.boxes.nbytes].view(torch.float64).view(B, 6)
-            d["feat_sum"] = d_tallies[ao:ao + 8 * S * D].view(torch.int64).view(S, D)
-            d["occ_count"] = d_tallies[ao + 8 * S * D:ao + 8 * S * D + 4 * S * B].view(torch.int32).view(S, B)
-            d["point_count"] = d_tallies[ao + 8 * S * D + 4 * S * B:ao + 8 * S * D + 4 * S * B + 4 * S].view(torch.int32)
-            d["occ_bits"] = d_tables[to:to + 8 * S * W].view(torch.int64).view(S, W)
-            d["n_bbs"] = d_tables[to + 8 * S * W:to + 8 * S * W + 4 * S].view(torch.int32)
-            d["feats_spp"] = feats_spp_all[job.feats_row_base:job.feats_row_base + S]
-            t.boxes, t.n_boxes, t.n_spps = d["boxes"].data_ptr(), B, S
+            t.boxes = d.spec("boxes", d_boxes, bo, job.boxes.nbytes, torch.float64, (B, 6))
+            t.feat_sum = d.spec("feat_sum", d_tallies, ao, 8 * S * D, torch.int64, (S, D))
+            t.occ_count = d.spec("occ_count", d_tallies, ao + 8 * S * D, 4 * S * B, torch.int32, (S, B))
+            t.point_count = d.spec("point_count", d_tallies, ao + 8 * S * D + 4 * S * B, 4 * S, torch.int32, (S,))
+            t.occ_bits = d.spec("occ_bits", d_tables, to, 8 * S * W, torch.int64, (S, W))
+            t.n_bbs = d.spec("n_bbs", d_tables, to + 8 * S * W, 4 * S, torch.int32, (S,))
+            t.feats_spp = fbase + job.feats_row_base * fstride
+            dict.__setitem__(d, "feats_spp", None)
+            d._specs["feats_spp"] = (feats_spp_all.view(torch.uint8).view(-1), job.feats_row_base * fstride, S * fstride,
+                                     torch.float32, (S, D))
+            dict.pop(d, "feats_spp", None)
+            t.n_boxes, t.n_spps = B, S
             t.fixed_shift, t.thresh_spp_occu = int(job.header.fixed_shift), float(job.thresh_spp_occu)
-            t.feat_sum, t.occ_count, t.point_count = (d["feat_sum"].data_ptr(), d["occ_count"].data_ptr(),
-                                                      d["point_count"].data_ptr())
-            t.feats_spp, t.occ_bits, t.n_bbs = d["feats_spp"].data_ptr(), d["occ_bits"].data_ptr(), d["n_bbs"].data_ptr()
             h = job.host
-            h["occ_bits_pin"] = stage[to:to + 8 * S * W].view(torch.int64).view(S, W)
-            h["n_bbs_pin"] = stage[to + 8 * S * W:to + 8 * S * W + 4 * S].view(torch.int32)
+            h.spec("occ_bits_pin", stage, to, 8 * S * W, torch.int64, (S, W))
+            h.spec("n_bbs_pin", stage, to + 8 * S * W, 4 * S, torch.int32, (S,))
         self.ctx.check(lib.gapro_partition_pool_batch(self.ctx.handle, _stream_handle(devc), len(jobs), D,
                                                       C.cast(tasks, C.c_void_p), _ptr(d_tasks)))
         stage[:tab_tot].copy_(d_tables, non_blocking=True)
@@ -394,11 +430,15 @@ class Pipeline:
         i = 0
         cur_state = on(0, self._partition, cur, False)
         on(0, self._schedule_all, cur_state)
+        nxt = next(it, None)
         prev_state = None
         while cur_state is not None:
-            nxt = next(it, None)
             nxt_state = on(i + 1, self._partition, nxt, False) if nxt is not None else None
             on(i, self._launch, cur_state)
+            # everything below is host work that runs while the fit just launched occupies the GPU: fetching the
+            # batch after next from the iterator (building jobs, reading / uploading scenes), the schedule of the
+            # next batch, the merge of the previous one
+            nxt = next(it, None) if nxt is not None else None
             if nxt_state is not None:
                 on(i + 1, self._schedule_all, nxt_state)
             if prev_state is not None:
