@@ -276,7 +276,7 @@ def main():
     fit_ms3 = [ev.read() for ev in pipe.fit_events]
     fit_ms = [t[2] for t in fit_ms3]
     if rank == 0:
-        print("fit launch device ms per step (staged, strip, span): " + "  ".join("%.1f/%.1f/%.1f" % t for t in fit_ms3),
+        print("fit launch device ms per step (staged, strip, span, small strip): " + "  ".join("%.1f/%.1f/%.1f/%.1f" % t for t in fit_ms3),
               file=sys.stderr)
     fit_fl = [ev.flops for ev in pipe.fit_events]
     stats = pipe.last_stats
@@ -328,17 +328,19 @@ def main():
                        "gp_fits_per_step_per_gpu": int(stats.get("n_fits", 0)),
                        "parallelism": "scene-sharded x%d, no collective" % world},
             "roofline": {"bound": "mfma",
-                         "kernel": "k_svgp_fit_strip<%d,%d> (batched SVGP fit, fits with round_up(M,32) <= 128; f64 MFMA "
+                         "kernel": "k_svgp_fit_strip<%d,%d> (batched SVGP fit, fits with 64 < M_p <= 128; f64 MFMA "
                                    "16x16x4)" % ((args.feat_dim, args.feat_dim) if args.feat_dim in (6, 32) else (32, 0)),
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": strip_ms, "flops_per_launch": strip_fl, "fits_per_launch": n_strip,
                          "timing": "HIP events recorded by the library on the stream the kernel is launched on"},
-            # the whole fit launch: the strip kernel and the staged kernel (larger fits) run side by side
+            # the whole fit launch: strip kernel, small-fit strip kernel (M_p <= 64) and staged kernel (M_p > 128) side by side
             "fit_launch": {"avg_ms_first_start_to_last_end": avg_ms, "flops": float(np.mean(fit_fl)) if fit_fl else 0.0,
                            "tflops": launch_tflops, "frac_of_fp64_mfma_peak": launch_tflops / FP64_MFMA_PEAK_TFLOPS,
                            "fits_per_s": (stats.get("n_fits", 0) / (avg_ms * 1e-3)) if avg_ms > 0 else 0.0,
                            "staged_kernel_avg_ms": staged_ms, "staged_kernel_flops": staged_fl,
+                           "small_strip_kernel_avg_ms": float(np.mean([t[3] for t in fit_ms3])) if fit_ms3 else 0.0,
+                           "small_strip_kernel_flops": float(np.mean([ev.flops_small for ev in pipe.fit_events])) if fit_ms3 else 0.0,
                            "share_of_step": (sum(fit_ms) / (1e3 * elapsed)) if elapsed > 0 else None},
         }
         if cpu_child is not None:

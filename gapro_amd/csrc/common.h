@@ -15,10 +15,10 @@ struct gapro_ctx {
   int n_cu = 0;
   std::string last_error;
   gapro_scene_header* h_header_pinned = nullptr;  // pinned staging for the blocking prepare call
-  // The fit kernels run on two library-owned streams ([0] staged / generic kernel, [1] strip kernel), so that
-  // the few large fits of the staged kernel and the strip kernel share the GPU.
-  hipStream_t fit_stream[2] = {nullptr, nullptr};
-  hipEvent_t ev_join[2] = {nullptr, nullptr};
+  // The fit kernels run on three library-owned streams ([0] staged / generic kernel, [1] strip kernel, [2] the
+  // small-fit strip kernel), so that they share the GPU.
+  hipStream_t fit_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr};
   // single-scene partition calls stage their one-task batch through this ring (pinned host + device mirror);
   // a slot is reused after kTaskRing further calls, long after the stream has consumed it
   gapro_scene_task* h_task_ring = nullptr;
@@ -29,8 +29,8 @@ struct gapro_ctx {
 
 // HIP events around the kernels of one fit launch, recorded on the streams the kernels run on.
 struct gapro_fit_timing {
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // staged start/end, strip start/end
-  bool used[2] = {false, false};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/end: staged, strip, small strip
+  bool used[3] = {false, false, false};
 };
 
 // Padded size of a fit's M x M matrices: MFMA tiles are 16 wide, so M is rounded up to a multiple of 16 (everything

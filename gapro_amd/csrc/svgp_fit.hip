@@ -43,7 +43,10 @@ void gapro_launch_fit_large(hipStream_t stream, int n_fits, int feat_dim, const 
 
 namespace {
 
-constexpr int NT = 512;       // threads per fit
+#ifndef GAPRO_NT
+#define GAPRO_NT 512
+#endif
+constexpr int NT = GAPRO_NT;  // threads per fit (the small-fit translation unit builds this file with 256)
 constexpr int NW = NT / 64;   // waves per fit
 constexpr int kMaxMpLds = 512;          // largest padded M the LDS-staged kernel takes
 constexpr int kMaxDynLds = 150 * 1024;  // dynamic LDS budget (160 KiB per CU minus the static part)
@@ -1461,6 +1464,7 @@ __device__ __noinline__ void strip_mean_var(const ldsd* As, const ldsd* Bs, cons
   __syncthreads();
 }
 
+#if GAPRO_NT >= 10 * 32
 // Likelihood gradients of the strip columns (ten threads per column, one per symmetric Gauss-Hermite pair):
 // gmu_s / gv_s for the strip, and this thread's contributions to sum E, sum g_mu, sum g_v in out3[0..2].
 __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_s, ldsd* gmu_s, ldsd* gv_s, ldsd* sred,
@@ -1517,6 +1521,68 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
   out3[2] = gv_add;
   __syncthreads();
 }
+#else
+// 256 threads cover 25 columns per pass: a 32-column strip takes two
+__device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_s, ldsd* gmu_s, ldsd* gv_s, ldsd* sred,
+                                              int n0, int nc, double c, double min_variance, double Nd,
+                                              double* out3) {
+  const Fit& f = g_sh.f;
+  constexpr int kCols = NT / 10;  // columns per pass: 51 with 512 threads (one pass per strip), 25 with 256
+  const int q = threadIdx.x % 10, nl0 = threadIdx.x / 10;
+  double e_add = 0.0, gc_add = 0.0, gv_add = 0.0;
+  for (int cbase = 0; cbase < nc; cbase += kCols) {
+    const int nl = cbase + nl0;
+    double E = 0.0, dmu = 0.0, dvar = 0.0;
+    const bool on = nl0 < kCols && nl < nc;
+    if (on) {
+      const double mu = mu_s[nl] + c;
+      const double vraw = var_s[nl];
+      const double var = vraw < min_variance ? min_variance : vraw;
+      const double sd = sqrt(2.0 * var);
+      const double y = f.vec[V_Y][n0 + nl];
+      const double t = c_gh_t[q], w = c_gh_w[q];
+      double lp, r;
+      log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
+      E += w * lp; dmu += w * r; dvar -= w * t * r;
+      log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
+      E += w * lp; dmu += w * r; dvar += w * t * r;
+    }
+    sred[threadIdx.x] = E;
+    sred[NT + threadIdx.x] = dmu;
+    sred[2 * NT + threadIdx.x] = dvar;
+    __syncthreads();
+    if (on && q == 0) {
+      double se = 0.0, sm = 0.0, sv = 0.0;
+      for (int qq = 0; qq < 10; ++qq) {
+        se += sred[threadIdx.x + qq];
+        sm += sred[NT + threadIdx.x + qq];
+        sv += sred[2 * NT + threadIdx.x + qq];
+      }
+      const double ipi = 0.56418958354775628695;  // 1/sqrt(pi)
+      const double vraw = var_s[nl];
+      const bool clamped = vraw < min_variance;
+      const double var = clamped ? min_variance : vraw;
+      const double y = f.vec[V_Y][n0 + nl];
+      const double g1 = -(ipi * sm * y) / Nd;
+      const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
+      gmu_s[nl] = g1;
+      gv_s[nl] = g2;
+      e_add += ipi * se;
+      gc_add += g1;
+      gv_add += g2;
+    }
+    if (kCols < SW) __syncthreads();  // another pass may follow and reuses sred
+  }
+  if ((int)threadIdx.x >= nc && threadIdx.x < SW) {
+    gmu_s[threadIdx.x] = 0.0;
+    gv_s[threadIdx.x] = 0.0;
+  }
+  out3[0] = e_add;
+  out3[1] = gc_add;
+  out3[2] = gv_add;
+  __syncthreads();
+}
+#endif
 
 template <int DMAX, int DC>
 __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* region,
@@ -1934,6 +2000,37 @@ __global__ void k_mfma_selftest(const double* __restrict__ P, const double* __re
 
 }  // namespace
 
+#ifdef GAPRO_SMALL_TU
+// ---- small-fit translation unit (svgp_fit_small.hip builds this file with GAPRO_NT = 256) -----------------
+// M_p <= 64 has at most 8 tiles per strip product: with 8 waves each wave has one tile and the CU idles through every
+// memory round trip of the fit it hosts.  Here a fit gets 4 waves (256 VGPRs each, no tighter register budget than
+// the 512-thread kernel) and a CU hosts TWO fits.
+extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_dim, size_t lds_bytes,
+                                            const float* d_feats_spp, const int32_t* d_idx,
+                                            const gapro_fit_desc* d_descs, const double* d_init_mean,
+                                            const gapro_fit_options* opt, double* d_workspace, float* d_probs,
+                                            float* d_probs_new, uint8_t* d_labels, float* d_mu, float* d_var,
+                                            int32_t* d_fit_status, double* d_fit_loss) {
+  auto kern = feat_dim == 6 ? k_svgp_fit_strip<6, 6> : feat_dim == 32 ? k_svgp_fit_strip<32, 32> : k_svgp_fit_strip<32, 0>;
+  if (lds_bytes > 48 * 1024 &&
+      hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+    return GAPRO_ERR_HIP;
+  hipLaunchKernelGGL(kern, dim3(n_fits), dim3(NT), lds_bytes, (hipStream_t)stream, n_fits, feat_dim, d_feats_spp, d_idx,
+                     d_descs, d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status,
+                     d_fit_loss);
+  return hipGetLastError() == hipSuccess ? GAPRO_OK : GAPRO_ERR_HIP;
+}
+// LDS bytes of a small fit in THIS translation unit's layout (NT-dependent reduction scratch)
+extern "C" long long gapro_fit_strip_small_lds_bytes(int m, int feat_dim) { return strip_lds_bytes(m, feat_dim); }
+#else
+extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_dim, size_t lds_bytes,
+                                            const float* d_feats_spp, const int32_t* d_idx,
+                                            const gapro_fit_desc* d_descs, const double* d_init_mean,
+                                            const gapro_fit_options* opt, double* d_workspace, float* d_probs,
+                                            float* d_probs_new, uint8_t* d_labels, float* d_mu, float* d_var,
+                                            int32_t* d_fit_status, double* d_fit_loss);
+extern "C" long long gapro_fit_strip_small_lds_bytes(int m, int feat_dim);
+
 __global__ void k_stream_calib(long long n, const double* __restrict__ src, double* __restrict__ dst, int mode) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   double acc = 0.0;
@@ -1948,10 +2045,15 @@ __global__ void k_stream_calib(long long n, const double* __restrict__ src, doub
   }
 }
 
-// 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel.  flags: gapro_fit_options.reserved
-// debug bits (bit 0: never the strip kernel).
+// 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel, 3 = strip-streaming kernel of the small-fit
+// translation unit (M_p <= 64: 256 threads per fit, two fits per CU).  flags: gapro_fit_options.reserved debug bits
+// (bit 0: never the strip kernels, bit 2: no small-fit kernel).
+constexpr int kSmallFitMp = 64;
 static int fit_route(int m, int feat_dim, int flags) {
-  if (!(flags & 1) && strip_ok(m, feat_dim)) return 0;
+  if (!(flags & 1) && strip_ok(m, feat_dim)) {
+    const bool small = gapro_pad_m(m) <= kSmallFitMp && 2 * gapro_fit_strip_small_lds_bytes(m, feat_dim) + 16384 <= 160 * 1024;
+    return (small && !(flags & 4)) ? 3 : 0;
+  }
   return staged_ok(m, feat_dim) ? 1 : 2;
 }
 
@@ -1996,9 +2098,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // Routing (gapro_fit_route): strip-streaming kernel, LDS-staged kernel, generic kernel (working set beyond
   // LDS).  Every group is sorted longest processing time first (cost ~ M^3): workgroups are dispatched in
   // block order, so the expensive fits start first and the tail of a launch stays short.
-  std::vector<gapro_fit_desc> strip, staged, large;
+  std::vector<gapro_fit_desc> strip, small, staged, large;
   strip.reserve(n_fits);
-  long long need = 0, max_lds = 0, max_lds_strip = 0;
+  small.reserve(n_fits);
+  long long need = 0, max_lds = 0, max_lds_strip = 0, max_lds_small = 0;
   const int route_flags = opt->reserved;
   for (int i = 0; i < n_fits; ++i) {
     gapro_fit_desc d = h_descs[i];
@@ -2011,6 +2114,9 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     if (route == 0) {
       strip.push_back(d);
       max_lds_strip = std::max(max_lds_strip, strip_lds_bytes(m, feat_dim));
+    } else if (route == 3) {
+      small.push_back(d);
+      max_lds_small = std::max(max_lds_small, gapro_fit_strip_small_lds_bytes(m, feat_dim));
     } else if (route == 1) {
       staged.push_back(d);
       max_lds = std::max(max_lds, staged_lds_bytes(m, feat_dim));
@@ -2023,11 +2129,13 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                       workspace_bytes);
   auto by_cost = [](const gapro_fit_desc& a, const gapro_fit_desc& b) { return a.m1 + a.m2 > b.m1 + b.m2; };
   std::stable_sort(strip.begin(), strip.end(), by_cost);
+  std::stable_sort(small.begin(), small.end(), by_cost);
   std::stable_sort(staged.begin(), staged.end(), by_cost);
   std::stable_sort(large.begin(), large.end(), by_cost);
   std::vector<gapro_fit_desc> all(large);
   all.insert(all.end(), staged.begin(), staged.end());
   all.insert(all.end(), strip.begin(), strip.end());
+  all.insert(all.end(), small.begin(), small.end());
   GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_descs, all.data(), all.size() * sizeof(gapro_fit_desc), hipMemcpyHostToDevice,
                                       stream));
   GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));  // `all` is pageable host memory that dies with this call
@@ -2036,14 +2144,16 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // synchronised, so everything the kernels read is complete (and an event recorded here completes together
   // with the NEXT dispatch of `stream` under this runtime, which would serialise the kernels again).  Both
   // are joined back into `stream` with events.
-  const bool own = !(route_flags & 2) && ctx->fit_stream[0] && ctx->fit_stream[1];  // debug bit 1: caller's stream
+  const bool own = !(route_flags & 2) && ctx->fit_stream[0] && ctx->fit_stream[1] && ctx->fit_stream[2];  // debug bit 1
   hipStream_t s_staged = own ? ctx->fit_stream[0] : stream;
   hipStream_t s_strip = own ? ctx->fit_stream[1] : stream;
+  hipStream_t s_small = own ? ctx->fit_stream[2] : stream;
   gapro_fit_timing* tm = ctx->armed_timing;
   ctx->armed_timing = nullptr;
   if (tm) {
     tm->used[0] = !large.empty() || !staged.empty();
     tm->used[1] = !strip.empty();
+    tm->used[2] = !small.empty();
     if (tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[0], s_staged));
   }
   if (!large.empty())
@@ -2071,6 +2181,15 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                        d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[3], s_strip));
   }
+  if (!small.empty()) {
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[4], s_small));
+    const int rc = gapro_launch_fit_strip_small(s_small, (int)small.size(), feat_dim, (size_t)max_lds_small, d_feats_spp,
+                                                d_idx, d_descs + large.size() + staged.size() + strip.size(),
+                                                d_init_mean, opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu,
+                                                d_var, d_fit_status, d_fit_loss);
+    if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: small-fit kernel launch failed");
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[5], s_small));
+  }
   if (own) {
     if (!large.empty() || !staged.empty()) {
       GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[0], s_staged));
@@ -2079,6 +2198,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     if (!strip.empty()) {
       GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[1], s_strip));
       GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[1], 0));
+    }
+    if (!small.empty()) {
+      GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[2], s_small));
+      GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[2], 0));
     }
   }
   GAPRO_LAUNCH_CHECK(ctx);
@@ -2091,7 +2214,7 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
   if (!ctx || !out) return GAPRO_ERR_BAD_ARG;
   gapro_fit_timing* t = new (std::nothrow) gapro_fit_timing();
   if (!t) return GAPRO_ERR_OOM;
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 6; ++i)
     if (hipEventCreate(&t->ev[i]) != hipSuccess) {
       gapro_fit_timing_destroy(t);
       return gapro_fail(ctx, GAPRO_ERR_HIP, "gapro_fit_timing_create: hipEventCreate failed");
@@ -2102,7 +2225,7 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
 
 void gapro_fit_timing_destroy(gapro_fit_timing* t) {
   if (!t) return;
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 6; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   delete t;
 }
@@ -2110,26 +2233,36 @@ void gapro_fit_timing_destroy(gapro_fit_timing* t) {
 int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
   ctx->armed_timing = t;
-  if (t) t->used[0] = t->used[1] = false;
+  if (t) t->used[0] = t->used[1] = t->used[2] = false;
   return GAPRO_OK;
 }
 
-int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms3) {
-  if (!ctx || !t || !out_ms3) return GAPRO_ERR_BAD_ARG;
-  out_ms3[0] = out_ms3[1] = out_ms3[2] = 0.f;
-  for (int k = 0; k < 2; ++k)
-    if (t->used[k]) {
-      GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[2 * k + 1]));
-      GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&out_ms3[k], t->ev[2 * k], t->ev[2 * k + 1]));
-    }
-  if (t->used[0] && t->used[1]) {
-    float s01 = 0.f;  // strip start relative to staged start
-    GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&s01, t->ev[0], t->ev[2]));
-    const float lo = s01 < 0.f ? s01 : 0.f;
-    const float e0 = out_ms3[0], e1 = s01 + out_ms3[1];
-    out_ms3[2] = (e0 > e1 ? e0 : e1) - lo;
-  } else {
-    out_ms3[2] = t->used[0] ? out_ms3[0] : out_ms3[1];
+int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms4) {
+  if (!ctx || !t || !out_ms4) return GAPRO_ERR_BAD_ARG;
+  out_ms4[0] = out_ms4[1] = out_ms4[2] = out_ms4[3] = 0.f;
+  const int slot[3] = {0, 1, 3};  // staged, strip, small-fit strip
+  float start[3] = {0.f, 0.f, 0.f}, end[3] = {0.f, 0.f, 0.f};
+  int ref = -1;
+  for (int k = 0; k < 3; ++k) {
+    if (!t->used[k]) continue;
+    float ms = 0.f;
+    GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[2 * k + 1]));
+    GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
+    out_ms4[slot[k]] = ms;
+    if (ref < 0) ref = k;
+    float off = 0.f;  // start of kernel k relative to the first used kernel's start
+    if (k != ref) GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&off, t->ev[2 * ref], t->ev[2 * k]));
+    start[k] = off;
+    end[k] = off + ms;
+  }
+  if (ref >= 0) {
+    float lo = 0.f, hi = 0.f;
+    for (int k = 0; k < 3; ++k)
+      if (t->used[k]) {
+        lo = start[k] < lo ? start[k] : lo;
+        hi = end[k] > hi ? end[k] : hi;
+      }
+    out_ms4[2] = hi - lo;
   }
   return GAPRO_OK;
 }
@@ -2154,3 +2287,4 @@ int gapro_debug_stream(gapro_ctx* ctx, void* stream_, int64_t n, const double* d
 }
 
 }  // extern "C"
+#endif  // GAPRO_SMALL_TU

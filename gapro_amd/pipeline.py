@@ -158,21 +158,21 @@ class FitTiming:
     """Device-side timing of one fit launch (gapro_fit_timing): HIP events recorded by the library on the
     streams its kernels run on.  read() blocks until the launch has finished."""
 
-    def __init__(self, ctx, handle, flops_strip, flops_staged, m):
+    def __init__(self, ctx, handle, flops_strip, flops_staged, flops_small, m):
         self.ctx, self.handle = ctx, handle
-        self.flops_strip, self.flops_staged, self.m = flops_strip, flops_staged, m
+        self.flops_strip, self.flops_staged, self.flops_small, self.m = flops_strip, flops_staged, flops_small, m
         self.ms = None
 
     @property
     def flops(self):
-        return self.flops_strip + self.flops_staged
+        return self.flops_strip + self.flops_staged + self.flops_small
 
     def read(self):
-        """(staged kernel ms, strip kernel ms, first start -> last end ms)"""
+        """(staged kernel ms, strip kernel ms, first start -> last end ms, small-fit strip kernel ms)"""
         if self.ms is None:
-            out = (C.c_float * 3)()
+            out = (C.c_float * 4)()
             self.ctx.check(self.ctx.lib.gapro_fit_timing_read(self.ctx.handle, self.handle, out))
-            self.ms = (float(out[0]), float(out[1]), float(out[2]))
+            self.ms = (float(out[0]), float(out[1]), float(out[2]), float(out[3]))
             self.ctx.lib.gapro_fit_timing_destroy(self.handle)
             self.handle = None
         return self.ms
@@ -648,8 +648,15 @@ class Pipeline:
             raw = _desc_table(descs, n_fits)
             m = (raw[:, 0] + raw[:, 1]).copy()
             route = {int(v): int(lib.gapro_fit_route(int(v), D)) for v in np.unique(m)}
-            is_strip = np.array([route[int(v)] == 0 for v in m]) & (int(self.opt.reserved) & 1 == 0)
-            self.fit_events.append(FitTiming(ctx, tm, float(each[is_strip].sum()), float(each[~is_strip].sum()), m))
+            flags = int(self.opt.reserved)
+            r = np.array([route[int(v)] for v in m])
+            if flags & 4:
+                r[r == 3] = 0
+            if flags & 1:
+                r[(r == 0) | (r == 3)] = 1
+            is_strip, is_small = r == 0, r == 3
+            self.fit_events.append(FitTiming(ctx, tm, float(each[is_strip].sum()), float(each[~(is_strip | is_small)].sum()),
+                                             float(each[is_small].sum()), m))
             self.last_fit_m = m
         # results travel to pinned host memory on the same stream; nobody waits here
         h_out = self._pinned(slot + "fit_out", no * 17)

@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--mix", default="", help="one launch of mixed sizes, e.g. 160:128,96:1024,64:1024 (M:count)")
     ap.add_argument("--no-fork", action="store_true", help="both fit kernels on one stream")
     ap.add_argument("--own-stream", action="store_true", help="launch from a non-default torch stream")
+    ap.add_argument("--no-small", action="store_true", help="M_p <= 64 on the 512-thread strip kernel (A/B)")
     args = ap.parse_args()
     if args.profile:
         import os
@@ -115,6 +116,8 @@ def main():
     pipe = Pipeline(device=0, training_iter=args.iters, force_staged=args.force_staged)
     if args.no_fork:
         pipe.opt.reserved |= 2
+    if args.no_small:
+        pipe.opt.reserved |= 4
     if args.mix:
         run_mix(pipe, args)
         return
