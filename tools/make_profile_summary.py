@@ -65,7 +65,8 @@ def main():
                                "bytes_per_FETCH_SIZE_unit": fetch_unit, "bytes_per_WRITE_SIZE_unit": write_unit,
                                "note": "guide: FETCH_SIZE is in KiB and reports half of a coalesced streaming read "
                                        "on gfx950 (x2048 B per unit expected); WRITE_SIZE is KiB, exact (x1024)"}}
-    for key, sub in (("strip_kernel", "k_svgp_fit_strip"), ("staged_kernel", "k_svgp_fit<")):
+    for key, sub in (("strip_kernel", "k_svgp_fit_strip<"), ("small_strip_kernel", "k_svgp_fit_strip256<"),
+                     ("staged_kernel", "k_svgp_fit<")):
         fm, fn = mean_of(pf, sub, "FETCH_SIZE")
         wm, wn = mean_of(pw, sub, "WRITE_SIZE")
         if fm is None or wm is None or not fetch_unit or not write_unit:
