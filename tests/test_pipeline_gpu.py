@@ -136,3 +136,38 @@ def test_full_size_scenes_size_independent_properties():
     for a, b in zip(base[:3], outp[:3]):
         assert torch.equal(a.cpu()[torch.from_numpy(perm)], b.cpu())
     assert torch.equal(base[3], outp[3]) and torch.equal(base[4], outp[4])
+
+
+def test_scenes_without_any_gp_fit_and_mixed_batches():
+    """Edge cases of the schedule: a scene whose boxes never overlap on a shared superpoint has no GP fit at all
+    (labels come from containment alone, mu / var stay -100), alone and batched with a scene that does."""
+    import torch
+    from gapro_amd import gen_pseudo_label_gaussian_process, gen_pseudo_label_gaussian_process_batch
+
+    rng = np.random.default_rng(4)
+    n = 3000
+    # two well separated blobs, one box each, superpoints never straddle the boxes
+    a = rng.uniform([0, 0, 0.2], [1, 1, 1.2], size=(n // 2, 3))
+    b = rng.uniform([5, 5, 0.2], [6, 6, 1.2], size=(n - n // 2, 3))
+    xyz = np.concatenate([a, b])
+    spp = np.concatenate([rng.integers(0, 20, n // 2), 100 + rng.integers(0, 20, n - n // 2)]).astype(np.int64)
+    boxes = np.array([[0, 0, 0.2, 1, 1, 1.2], [5, 5, 0.2, 6, 6, 1.2]], np.float32)
+    kw = dict(coords_float=xyz, mask_feats=rng.standard_normal((n, 6)).astype(np.float32), spp=spp,
+              instance_cls=np.array([3, 7]), instance_box=boxes,
+              instance_box_volume=np.prod(boxes[:, 3:] - boxes[:, :3], axis=1).astype(np.float32), wall_box=[],
+              wall_box_volume=[], instance_classes=18, ground_h=0.1, training_iter=50, thresh_spp_occu=0.999)
+    ref, dbg = _oracle_outputs(kw)
+    assert len(dbg["results"]) == 0  # no fit in this scene
+    out = gen_pseudo_label_gaussian_process(**kw)
+    for got, want in zip(out, ref):
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert (out[3].numpy() == -100).all() and (out[4].numpy() == -100).all()
+    from conftest import GOLDEN_NAMES, Golden
+
+    g = Golden(GOLDEN_NAMES[0]).api_inputs()
+    both = gen_pseudo_label_gaussian_process_batch([kw, g], training_iter=50)
+    alone = gen_pseudo_label_gaussian_process(**g, device="cuda:0")
+    for x, y in zip(both[0], out):
+        assert torch.equal(x.cpu(), y.cpu())
+    for x, y in zip(both[1], alone):
+        assert torch.equal(x.cpu(), y.cpu())
