@@ -17,6 +17,11 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
                            default 0 = deterministic), --seed seeds it
     --broadcast_mu_var     write mu/var at point length (what the released data loaders index)
     --loader_threads T     threads that read scenes from disk a batch ahead and write the results (default 4)
+    --loader_procs P       read and write in P loader PROCESSES (default -1 = min(16, cores/4); 0 = threads only).
+                           Unpickling a ScanNet .pth holds the GIL, so threads top out near one core; processes
+                           hand the arrays over in POSIX shared memory (through the pipe when /dev/shm is full)
+                           and the loader threads only upload from it.  The pool is started before the worker
+                           touches the GPU.
 
 Differences from the reference, on purpose: output files are written atomically (tmp + rename); a scene
 that fails to load is reported and skipped instead of killing the run; a scene without instances (the
@@ -96,11 +101,117 @@ def save_scene(save_path, outs, spp_inv=None, broadcast_mu_var=False):
     os.replace(tmp, save_path)
 
 
-def run_worker(filenames, args, device_index):
-    """One GPU: scenes are read from disk by a pool of loader threads (a batch ahead), go through the
-    software-pipelined generator batch by batch (Pipeline.run_stream), and are written by the same pool."""
-    import concurrent.futures as cf
+_SHM_KEYS = ("coords_float", "mask_feats", "spp", "semantic_label", "instance_label", "wall_box", "wall_box_volume")
 
+
+def _loader_init():
+    """Loader process start-up: single-threaded BLAS / torch (the pool is the parallelism)."""
+    torch.set_num_threads(1)
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(1)
+    except Exception:  # noqa: BLE001 - optional
+        pass
+
+
+def _read_scene_shm(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
+    """Loader process: read_scene, then the arrays go into ONE POSIX shared-memory block (64-byte aligned
+    fields) and only its name and layout travel back through the pipe."""
+    from multiprocessing import shared_memory
+
+    sc = read_scene(filename, data_root, use_deepfeat, deepfeat_folder)
+    arrs = {k: np.ascontiguousarray(np.asarray(sc[k])) for k in _SHM_KEYS}
+    layout, off = [], 0
+    for k in _SHM_KEYS:
+        a = arrs[k]
+        layout.append((k, a.dtype.str, a.shape, off))
+        off += (a.nbytes + 63) // 64 * 64
+    try:
+        shm = shared_memory.SharedMemory(create=True, size=max(off, 64))
+    except OSError:
+        return dict(scan_name=sc["scan_name"], shm=None, arrays=arrs)
+    try:
+        try:  # reserve the pages now: a full /dev/shm must be an error here, not a SIGBUS in the copy below
+            os.posix_fallocate(shm._fd, 0, max(off, 64))
+        except OSError:  # no room (container with a small /dev/shm): this scene travels through the pipe instead
+            shm.unlink()
+            return dict(scan_name=sc["scan_name"], shm=None, arrays=arrs)
+        for (k, _, _, o) in layout:
+            a = arrs[k]
+            if a.nbytes:
+                np.ndarray(a.shape, a.dtype, buffer=shm.buf, offset=o)[...] = a
+        name = shm.name
+    finally:
+        shm.close()
+    return dict(scan_name=sc["scan_name"], shm=name, layout=layout)
+
+
+def _scene_from_shm(msg, device):
+    """Worker side of _read_scene_shm: map the block, upload the per-point arrays straight from it (one
+    host->device copy each, no intermediate host copy), keep the tiny wall arrays, release the block."""
+    from multiprocessing import shared_memory
+
+    if msg["shm"] is None:  # the pipe fallback of _read_scene_shm
+        sc = dict(msg["arrays"], scan_name=msg["scan_name"])
+        for k in ("wall_box", "wall_box_volume"):
+            if not len(sc[k]):
+                sc[k] = []
+        return scene_to_device(sc, device) if device is not None else sc
+    shm = shared_memory.SharedMemory(name=msg["shm"])
+    sc = dict(scan_name=msg["scan_name"])
+    try:
+        for (k, dt, shape, off) in msg["layout"]:
+            view = np.ndarray(shape, np.dtype(dt), buffer=shm.buf, offset=off)
+            if k in _DEVICE_DTYPES and device is not None:
+                sc[k] = torch.from_numpy(view).to(device=device, dtype=_DEVICE_DTYPES[k])  # synchronous copy
+            else:
+                sc[k] = view.copy() if view.size else []
+            del view
+    finally:
+        shm.close()
+        shm.unlink()
+    return sc
+
+
+_DEVICE_DTYPES = {"coords_float": torch.float64, "mask_feats": torch.float32, "spp": torch.int64,
+                  "semantic_label": torch.float64, "instance_label": torch.float64}
+
+
+def scene_to_device(sc, device):
+    """Upload the per-point arrays of a read_scene dict once; add_instance_info and make_job then share them."""
+    sc = dict(sc)
+    for k, dt in _DEVICE_DTYPES.items():
+        if not isinstance(sc[k], torch.Tensor):
+            sc[k] = torch.from_numpy(np.ascontiguousarray(np.asarray(sc[k]))).to(device=device, dtype=dt)
+    return sc
+
+
+def _save_arrays(save_path, arrays, spp_inv=None):
+    """Loader process: the file write of save_scene from host arrays."""
+    sem, ins, prob, mu, var = arrays
+    if spp_inv is not None:
+        mu, var = mu[spp_inv], var[spp_inv]
+    tmp = save_path + ".tmp.%d" % os.getpid()
+    torch.save((sem, ins, prob, mu, var), tmp)
+    os.replace(tmp, save_path)
+
+
+def run_worker(filenames, args, device_index):
+    """One GPU: scenes are read from disk by a pool of loader threads or processes (two batches ahead), go
+    through the software-pipelined generator batch by batch (Pipeline.run_stream), and are written by the
+    same pool."""
+    import concurrent.futures as cf
+    import threading
+
+    n_procs = int(getattr(args, "loader_procs", 0))
+    if n_procs < 0:  # auto: a quarter of the host's cores, at most 16 (more only adds start-up time)
+        n_procs = min(16, (os.cpu_count() or 1) // 4)
+    procs = None
+    if n_procs:  # start the loader processes BEFORE this process initialises the GPU
+        import multiprocessing as mp
+
+        procs = mp.get_context("spawn").Pool(n_procs, initializer=_loader_init)
     pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
     dev = pipe.device
     done = failed = 0
@@ -109,9 +220,52 @@ def run_worker(filenames, args, device_index):
     chunks = [pending[i:i + args.batch_scenes] for i in range(0, len(pending), args.batch_scenes)]
     pool = cf.ThreadPoolExecutor(max_workers=max(1, args.loader_threads))
     meta = []  # per yielded batch: (scenes, jobs)
+    read_args = (args.data_root, args.use_deepfeat, args.deepfeat_folder)
+    spent = dict(wait=0.0, upload=0.0, boxes=0.0, jobs=0.0, export=0.0)  # main-thread seconds, GAPRO_DRIVER_TIMES=1
+
+    tls = threading.local()
+
+    def side_stream():
+        if not hasattr(tls, "stream"):  # one stream per pool thread: its copies stay off the default stream
+            tls.stream = torch.cuda.Stream(dev)
+        return tls.stream
+
+    def upload(r):
+        """Pool thread: map the loader's block, upload from it, GT boxes of the scene (gapro_instance_info only
+        touches the buffers it is given, so it may run beside the generator)."""
+        msg = r.get()
+        with torch.cuda.stream(side_stream()):
+            return add_instance_info(_scene_from_shm(msg, dev), dev)
+
+    def export(path, job, o, ready):
+        """Pool thread: device -> host on the thread's stream; pickling and the file write go to a loader process."""
+        st = side_stream()
+        with torch.cuda.stream(st):
+            st.wait_event(ready)
+            arrays = (o[0].int().cpu().numpy(), o[1].int().cpu().numpy()) + tuple(t.cpu().numpy() for t in o[2:])
+            inv = job.spp_inv.cpu().numpy() if args.broadcast_mu_var else None
+        return procs.apply_async(_save_arrays, (path, arrays, inv))
 
     def submit(chunk):
-        return [(fn, pool.submit(read_scene, fn, args.data_root, args.use_deepfeat, args.deepfeat_folder)) for fn in chunk]
+        if procs is not None:  # read in a loader process; a pool thread maps the block and uploads from it
+            reads = [(fn, procs.apply_async(_read_scene_shm, (fn,) + read_args)) for fn in chunk]
+            return [(fn, pool.submit(upload, r)) for fn, r in reads]
+        return [(fn, pool.submit(read_scene, fn, *read_args)) for fn in chunk]
+
+    def fetch(fut):
+        t = time.time()
+        got = fut.result()
+        t1 = time.time()
+        if procs is not None:
+            spent["wait"] += t1 - t
+            return got
+        sc = scene_to_device(got, dev)
+        t2 = time.time()
+        sc = add_instance_info(sc, dev)
+        spent["wait"] += t1 - t
+        spent["upload"] += t2 - t1
+        spent["boxes"] += time.time() - t2
+        return sc
 
     def batches():
         nonlocal failed
@@ -123,7 +277,7 @@ def run_worker(filenames, args, device_index):
             scenes = []
             for fn, fut in futs:
                 try:
-                    sc = add_instance_info(fut.result(), dev)
+                    sc = fetch(fut)
                     if sc is None:
                         print("[gen_ps] %s: no instances, skipped" % fn, file=sys.stderr)
                         failed += 1
@@ -134,37 +288,50 @@ def run_worker(filenames, args, device_index):
                     failed += 1
             if not scenes:
                 continue
+            t = time.time()
             jobs = [make_job(s["coords_float"], s["mask_feats"], s["spp"], s["instance_cls"], s["instance_box"],
                              s["instance_box_volume"], s["wall_box"], s["wall_box_volume"],
                              instance_classes=18, ground_h=0.1, thresh_spp_occu=0.999, device=dev)  # :106-110
                     for s in scenes]
+            spent["jobs"] += time.time() - t
             meta.append((scenes, jobs))
             yield jobs
 
     writes = []
     for outs in pipe.run_stream(batches()):
         scenes, jobs = meta.pop(0)
+        t_exp = time.time()
+        ready = torch.cuda.current_stream(dev).record_event()  # run_stream ordered the outputs on this stream
         for s, job, o in zip(scenes, jobs, outs):
             if args.eval_pslabel:
                 from .eval_ps_labels import get_miou_scene
 
-                sem_gt = torch.from_numpy(np.asarray(s["semantic_label"])).to(dev).int()
-                ins_gt = torch.from_numpy(np.asarray(s["instance_label"])).to(dev).int()
+                sem_gt = s["semantic_label"].int()
+                ins_gt = s["instance_label"].int()
                 sem_gt[sem_gt != -100] -= 2  # :119-120
                 sem_gt[(sem_gt == -1) | (sem_gt == -2)] = 18
                 ious = get_miou_scene(sem_gt.long(), ins_gt.long(), o[0].long(), o[1].long())
                 print("miou", ious)
-            host = tuple(t.cpu() for t in o)  # device -> host here; the file write goes to the pool
-            inv = job.spp_inv.cpu() if args.broadcast_mu_var else None
-            writes.append(pool.submit(save_scene, osp.join(args.save_folder, s["scan_name"] + ".pth"), host, inv,
-                                      args.broadcast_mu_var))
+            path = osp.join(args.save_folder, s["scan_name"] + ".pth")
+            if procs is not None:
+                writes.append(pool.submit(export, path, job, o, ready))
+            else:  # device -> host here; the file write goes to the pool
+                host = tuple(t.cpu() for t in o)
+                inv = job.spp_inv.cpu() if args.broadcast_mu_var else None
+                writes.append(pool.submit(save_scene, path, host, inv, args.broadcast_mu_var))
             done += 1
+        spent["export"] += time.time() - t_exp
     for w in writes:
-        w.result()
+        w.result().get() if procs is not None else w.result()
     pool.shutdown()
+    if procs is not None:
+        procs.close()
+        procs.join()
     dt = time.time() - t0
     print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)"
           % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0))
+    if os.environ.get("GAPRO_DRIVER_TIMES"):
+        print("[gen_ps] main-thread seconds: " + ", ".join("%s %.2f" % kv for kv in spent.items()))
     return done, failed
 
 
@@ -183,6 +350,7 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--broadcast_mu_var", action="store_true")
     parser.add_argument("--loader_threads", type=int, default=4)
+    parser.add_argument("--loader_procs", type=int, default=-1)
     parser.add_argument("--worker_rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = parser.parse_args(argv)
 

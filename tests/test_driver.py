@@ -37,6 +37,48 @@ def test_load_scene_follows_reference_preprocessing(tmp_path):
     assert d["mask_feats"].shape == (sc.n_points, 32)
 
 
+def test_shared_memory_hand_over_is_lossless(tmp_path, monkeypatch):
+    """The loader-process path: read_scene -> one shared-memory block -> the same arrays, block released."""
+    from multiprocessing import shared_memory
+
+    from gapro_amd.gen_ps import _read_scene_shm, _save_arrays, _scene_from_shm, read_scene
+
+    root, scenes = _dataset(tmp_path, 2)
+    for sc in scenes:  # scene 0 has wall quads, scene 1 has none (empty fields)
+        fn = os.path.join(root, "train", sc.scan_name + "_inst_nostuff.pth")
+        want = read_scene(fn, root)
+        msg = _read_scene_shm(fn, root)
+        got = _scene_from_shm(msg, None)
+        assert got["scan_name"] == want["scan_name"]
+        for k in ("coords_float", "mask_feats", "spp", "semantic_label", "instance_label"):
+            np.testing.assert_array_equal(got[k], np.asarray(want[k]))
+            assert got[k].dtype == np.asarray(want[k]).dtype
+        assert len(got["wall_box"]) == len(want["wall_box"])
+        if len(want["wall_box"]):
+            np.testing.assert_array_equal(got["wall_box"], want["wall_box"])
+            np.testing.assert_array_equal(got["wall_box_volume"], want["wall_box_volume"])
+        with pytest.raises(FileNotFoundError):
+            shared_memory.SharedMemory(name=msg["shm"])
+    # a full /dev/shm: the scene travels through the pipe instead
+    def no_room(*a):
+        raise OSError(28, "No space left on device")
+
+    monkeypatch.setattr(os, "posix_fallocate", no_room)
+    msg = _read_scene_shm(fn, root)
+    assert msg["shm"] is None
+    got = _scene_from_shm(msg, None)
+    np.testing.assert_array_equal(got["coords_float"], want["coords_float"])
+    assert len(got["wall_box"]) == 0
+    monkeypatch.undo()
+    arrays = (np.arange(5, dtype=np.int32), np.arange(5, dtype=np.int32), np.ones(5, np.float32),
+              np.arange(2, dtype=np.float32), np.arange(2, dtype=np.float32))
+    path = str(tmp_path / "o.pth")
+    _save_arrays(path, arrays, np.array([0, 1, 1, 0, 1]))
+    out = torch.load(path, weights_only=False)
+    np.testing.assert_array_equal(out[3], [0, 1, 1, 0, 1])
+    assert len(out) == 5 and out[0].dtype == np.int32
+
+
 def test_save_scene_writes_the_reference_tuple_atomically(tmp_path):
     from gapro_amd.gen_ps import save_scene
 
@@ -85,8 +127,9 @@ def test_cli_batching_does_not_change_the_files(tmp_path):
 
     root, scenes = _dataset(tmp_path, 5)
     a, b = str(tmp_path / "a"), str(tmp_path / "b")
-    gen_ps.main(["--save_folder", a, "--data_root", root, "--batch_scenes", "2", "--loader_threads", "2"])
-    gen_ps.main(["--save_folder", b, "--data_root", root, "--batch_scenes", "5", "--broadcast_mu_var"])
+    gen_ps.main(["--save_folder", a, "--data_root", root, "--batch_scenes", "2", "--loader_threads", "2",
+                 "--loader_procs", "0"])  # thread loaders
+    gen_ps.main(["--save_folder", b, "--data_root", root, "--batch_scenes", "5", "--broadcast_mu_var"])  # processes
     for s in scenes:
         x = torch.load(os.path.join(a, s.scan_name + ".pth"), weights_only=False)
         y = torch.load(os.path.join(b, s.scan_name + ".pth"), weights_only=False)
@@ -95,3 +138,30 @@ def test_cli_batching_does_not_change_the_files(tmp_path):
         _, inv = np.unique(s.spp, return_inverse=True)
         np.testing.assert_array_equal(x[3][inv], y[3])  # --broadcast_mu_var = superpoint values at point length
         np.testing.assert_array_equal(x[4][inv], y[4])
+
+
+@pytest.mark.gpu
+def test_cli_loader_processes_write_the_same_files(tmp_path):
+    """--loader_procs (shared-memory hand-over, writes in the loader processes) against the thread loader.  The
+    CLI runs as a child process: its loader pool must exist before that process touches the GPU."""
+    import subprocess
+    import sys
+
+    from gapro_amd import gen_ps
+
+    root, scenes = _dataset(tmp_path, 4)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    gen_ps.main(["--save_folder", a, "--data_root", root, "--batch_scenes", "2", "--broadcast_mu_var"])
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", b, "--data_root", root,
+                        "--batch_scenes", "2", "--loader_procs", "2", "--broadcast_mu_var", "--eval_pslabel"],
+                       cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "4 scenes written" in r.stdout and r.stdout.count("miou") == 4
+    for s in scenes:
+        x = torch.load(os.path.join(a, s.scan_name + ".pth"), weights_only=False)
+        y = torch.load(os.path.join(b, s.scan_name + ".pth"), weights_only=False)
+        assert len(x) == len(y) == 5
+        for u, v in zip(x, y):
+            assert u.dtype == v.dtype
+            np.testing.assert_array_equal(u, v)
