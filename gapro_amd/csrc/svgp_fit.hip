@@ -496,6 +496,111 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
   }
 }
 
+// ---- the same factorisation with a one-column look-ahead (strip kernels) ------------------------------
+// In cholesky_fused the other waves idle while wave 0 factors the diagonal block (~4.5 us per block column, more
+// than the whole MFMA update of a column).  Here two LDS panels alternate: while wave 0 factors the diagonal block
+// of column kb, the other waves already build column kb + 1 -- kernel tile minus the contributions of the columns
+// < kb, which are final in L^T -- and once column kb's panel has been scaled, its rank-16 contribution is
+// subtracted straight from LDS (both operands are rows of the scaled panel) while the panel is written to L / L^T.
+// Every accumulator sees the same MFMAs in the same order as in cholesky_fused (the detour of the partial sums
+// through LDS is exact), so the factor is bit-identical.
+inline __host__ __device__ int chol_panel_doubles(int Mp) { return Mp * 17 + 64 * 17; }
+template <int DC>
+__device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* panels, double s, double inv_l2,
+                                                      double jitter) {
+  const Fit& f = g_sh.f;
+  Shared& sh = g_sh;
+  const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D, nb = Mp / 16;
+  gd* L = f.mat[B_L];
+  gd* LT = f.mat[B_LT];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int PS = chol_panel_doubles(Mp);
+  // block (ib, kb) of Kzz + jitter I minus the contributions of the block columns < qb, into panel dst
+  auto build = [&](int ib, int kb, int qb, ldsd* dst_panel) {
+    d4 acc;
+    const int col = 16 * kb + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ib + lq + 4 * r;
+      double v = 0.0;
+      if (row < M && col < M) {
+        v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+        if (row == col) v += jitter;
+      } else if (row == col) {
+        v = 1.0;
+      }
+      acc[r] = v;
+    }
+    const gd* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
+    const gd* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
+#pragma nounroll
+    for (int q = 0; q < 16 * qb; q += 16) {
+      const size_t o = (size_t)q * Mp, st = (size_t)4 * Mp;
+      const double a0 = pa[o], a1 = pa[o + st], a2 = pa[o + 2 * st], a3 = pa[o + 3 * st];
+      const double b0 = pb[o], b1 = pb[o + st], b2 = pb[o + 2 * st], b3 = pb[o + 3 * st];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc, 0, 0, 0);
+    }
+    ldsd* dst = dst_panel + (16 * (ib - kb)) * 17;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
+  };
+  for (int ib = wave; ib < nb; ib += NW) build(ib, 0, 0, panels);
+  __syncthreads();
+  for (int kb = 0; kb < nb; ++kb) {
+    ldsd* cur = panels + (kb & 1) * PS;
+    ldsd* nxt = panels + ((kb + 1) & 1) * PS;
+    // (2) diagonal block on wave 0 | column kb + 1 without the contribution of column kb on the other waves
+    if (wave == 0) {
+      diag_factor_invert(cur, kb);
+    } else {
+      for (int ib = kb + wave; ib < nb; ib += NW - 1) build(ib, kb + 1, kb, nxt);
+    }
+    __syncthreads();
+    prof_stamp(5);
+    // (3) rows below the diagonal block, in LDS: P[i][c] <- sum_{q <= c} S[i][q] Dinv[c][q]
+    const int rows_below = Mp - 16 * (kb + 1);
+    ldsd* pb = cur + 16 * 17;
+    for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {
+      const int i = idx >> 4, c = idx & 15;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += (q <= c) ? pb[i * 17 + q] * sh.dinv[c * 17 + q] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the 16 lanes of a row have all read S before any overwrites it
+      pb[i * 17 + c] = acc;
+    }
+    __syncthreads();
+    // column kb's contribution to column kb + 1, both operands from the scaled panel (block row kb + 1 is its top)
+    for (int ib = kb + 1 + wave; ib < nb; ib += NW) {
+      ldsd* dst = nxt + (16 * (ib - kb - 1)) * 17;
+      const ldsd* la = pb + (16 * (ib - kb - 1) + lr) * 17 + lq;
+      const ldsd* lb = pb + lr * 17 + lq;
+      d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = dst[(lq + 4 * r) * 17 + lr];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * st], lb[4 * st], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
+    }
+    for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L rows: 16 contiguous columns
+      const int i = idx >> 4, c = idx & 15;
+      L[(size_t)(16 * (kb + 1) + i) * Mp + 16 * kb + c] = pb[i * 17 + c];
+    }
+    if (rows_below > 0)
+      for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L^T rows: contiguous in i
+        const int c = idx / rows_below, i = idx - c * rows_below;
+        LT[(size_t)(16 * kb + c) * Mp + 16 * (kb + 1) + i] = pb[i * 17 + c];
+      }
+    __syncthreads();
+    prof_stamp(18);
+  }
+}
+
 // ---- LI = L^-1 (lower) and U = LI^T, one 16-wide block column per wave -----------------------------
 //   LI_kk = Dinv_k;   LI_ik = -Dinv_i * sum_{j=k}^{i-1} L_ij LI_jk   (i > k)
 // Block columns are independent.  For nb <= NBR the blocks of the column stay in registers (an MFMA
@@ -1345,8 +1450,9 @@ constexpr int kStripMaxMp = 128;
 constexpr int kAccTiles = 5;  // lower 16x16 tiles of an 8x8-block matrix: 36 over 8 waves
 
 inline __host__ __device__ int strip_region_doubles(int Mp) {
-  const int a = 3 * Mp * RS, b = scratch_doubles(Mp);
-  return a > b ? a : b;
+  const int a = 3 * Mp * RS, b = scratch_doubles(Mp), c = 2 * (Mp * 17 + 64 * 17);  // c: two Cholesky panels
+  const int m = a > b ? a : b;
+  return m > c ? m : c;
 }
 inline __host__ __device__ long long strip_lds_bytes(int m, int d) {
   const int Mp = gapro_pad_m(m);
@@ -1645,7 +1751,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   };
   auto factorize = [&]() {
     stamp(19);
-    cholesky_fused<DC>(Zt, scratch, sh.s, sh.inv_l2, jitter);
+    cholesky_fused_lookahead<DC>(Zt, scratch, sh.s, sh.inv_l2, jitter);
     stamp(1);
     tri_inverse<8>(scratch);
     __syncthreads();

@@ -82,6 +82,40 @@ def test_fit_large_inducing_sets(m1, m2, t, iters):
     _compare(out, _oracle(feats, b1, b2, it, iters))
 
 
+def test_fit_stress_32_concurrent_large_regions():
+    """BASELINE configs[4] shape: 32 concurrent regions of ~50k points each, i.e. ~1000 inducing and ~1000
+    undetermined superpoints per fit (generic kernel, ~100 MB of workspace per fit).  Four distinct problems, each
+    eight times in the launch: the copies must agree bit for bit whatever ran beside them, one problem is checked
+    against the float64 oracle (5 Adam steps: the oracle's autograd through a 1024^3 Cholesky is the slow side),
+    and the full 50-step launch must stay finite."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    m1, m2, t = 500, 524, 1000
+    assert _lib.load().gapro_fit_route(m1 + m2, 6) == 2
+    feats_list, probs, base = [], [], 0
+    for i in range(4):
+        f, b1, b2, it = make_gp_problem(900 + i, m1, m2, t, 6)
+        feats_list.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(feats_list)
+    launch = [probs[i % 4] for i in range(32)]
+    out = fit_gp_spp_batch(feats, launch, training_iter=5)
+    for i in range(4, 32):
+        for a, b in zip(out[i], out[i % 4]):
+            np.testing.assert_array_equal(a, b)
+    b1, b2, it = probs[0]
+    _compare(out[0], _oracle(feats, b1, b2, it, 5))
+    full = fit_gp_spp_batch(feats, launch, training_iter=50)
+    for i, (probs_, probs_new, labels, mu, var) in enumerate(full):
+        assert np.isfinite(mu).all() and np.isfinite(var).all() and (var > 0).all()
+        assert ((probs_ >= 0) & (probs_ <= 1)).all() and (probs_new >= 0.5).all()
+        for a, b in zip(full[i], full[i % 4]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_fit_ill_conditioned_problems_stay_finite():
     """Perfectly symmetric (1 vs 1) or far-apart (d = 32, unit std) problems have gradients that are pure
     rounding noise, which Adam normalises to full steps: implementations legitimately differ there

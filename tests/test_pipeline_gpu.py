@@ -138,6 +138,30 @@ def test_full_size_scenes_size_independent_properties():
     assert torch.equal(base[3], outp[3]) and torch.equal(base[4], outp[4])
 
 
+def test_s3dis_shaped_scene_matches_oracle():
+    """BASELINE configs[3]: a room-sized scene (1M points, 13 classes, objects of up to several hundred
+    superpoints).  Its 66 fits (M up to 724) span all four fit kernels (small-fit strip, strip, LDS-staged, generic for
+    M > 512) inside one real schedule; everything is compared with the float64 oracle as on the golden scenes."""
+    from gapro_amd import gen_pseudo_label_gaussian_process
+    from gapro_amd._lib import Context
+    from gapro_amd.gen_ps_utils import getInstanceInfo
+    from gapro_amd.synth import make_scene
+
+    sc = make_scene(seed=7, n_points=1_000_000, n_objects=40, with_walls_json=False, obj_patch=60, plane_patch=400)
+    xyz = sc.aligned_xyz()
+    _, cls, box, vol, _ = getInstanceInfo(xyz, sc.inst, sc.sem)
+    kw = dict(coords_float=xyz, mask_feats=sc.default_feats().astype(np.float32), spp=sc.spp,
+              instance_cls=cls.astype(np.int64), instance_box=box.astype(np.float32),
+              instance_box_volume=vol.astype(np.float32), wall_box=[], wall_box_volume=[], instance_classes=13,
+              ground_h=0.1, training_iter=50, thresh_spp_occu=0.999)
+    ref, dbg = _oracle_outputs(kw)
+    lib = Context.get(0).lib
+    routes = {int(lib.gapro_fit_route(len(e.b1_inds) + len(e.b2_inds), 6)) for e in dbg["events"] if e.kind == "fit"}
+    assert routes == {0, 1, 2, 3}, routes  # the scene really exercises every kernel
+    outs = gen_pseudo_label_gaussian_process(**kw)
+    _check(outs, ref, dbg)
+
+
 def test_scenes_without_any_gp_fit_and_mixed_batches():
     """Edge cases of the schedule: a scene whose boxes never overlap on a shared superpoint has no GP fit at all
     (labels come from containment alone, mu / var stay -100), alone and batched with a scene that does."""
