@@ -15,6 +15,15 @@ GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle's small float64 torch ops crawl when OpenMP spreads them over every hardware thread of a big
+    # host (the GPU box shows 256 and grants far fewer): 8 threads are plenty for matrices of a few hundred rows
+    try:
+        import torch
+
+        if (os.cpu_count() or 1) > 8:
+            torch.set_num_threads(8)
+    except ImportError:
+        pass
 
 
 class Golden:
