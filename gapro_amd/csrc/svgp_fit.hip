@@ -555,7 +555,11 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
     ldsd* nxt = panels + ((kb + 1) & 1) * PS;
     // (2) diagonal block on wave 0 | column kb + 1 without the contribution of column kb on the other waves
     if (wave == 0) {
+      // the serial chain everybody waits for.  In the 256-thread build a SIMD hosts one wave of each of the CU's two
+      // fits: the chain goes ahead of the other fit's wave (+2..3 % at M <= 64; with 512 threads it is -0.6 %)
+      if (NW <= 4) __builtin_amdgcn_s_setprio(3);
       diag_factor_invert(cur, kb);
+      if (NW <= 4) __builtin_amdgcn_s_setprio(0);
     } else {
       for (int ib = kb + wave; ib < nb; ib += NW - 1) build(ib, kb + 1, kb, nxt);
     }
