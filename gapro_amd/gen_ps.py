@@ -207,6 +207,8 @@ def run_worker(filenames, args, device_index):
     n_procs = int(getattr(args, "loader_procs", 0))
     if n_procs < 0:  # auto: a quarter of the host's cores, at most 16 (more only adds start-up time)
         n_procs = min(16, (os.cpu_count() or 1) // 4)
+        if n_procs < 2:  # a small host: one loader process is no faster than the threads
+            n_procs = 0
     procs = None
     if n_procs:  # start the loader processes BEFORE this process initialises the GPU
         import multiprocessing as mp
@@ -233,7 +235,7 @@ def run_worker(filenames, args, device_index):
     def upload(r):
         """Pool thread: map the loader's block, upload from it, GT boxes of the scene (gapro_instance_info only
         touches the buffers it is given, so it may run beside the generator)."""
-        msg = r.get()
+        msg = r.get(600)  # a loader that died (e.g. killed for memory) must not hang the run: the scene is skipped
         with torch.cuda.stream(side_stream()):
             return add_instance_info(_scene_from_shm(msg, dev), dev)
 
