@@ -176,8 +176,8 @@ def main():
             if not args.force_staged and m <= 128:
                 names = ["chol:update", "chol:rest", "inv", "s:fill", "s:A", "chol:diag", "post-strips", "s:B",
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
-                         "s:GKX", "adam", "predict", "s:GLacc+store", "misc", "kg:loop", "kg:sums", "x22", "x23",
-                         "x24", "x25", "x26", "x27"]
+                         "s:GKX", "adam", "predict", "s:GLacc+store", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
+                         "(diag:stores", "x25", "x26", "x27"]
             tot = prof.sum()
             print("    phases (us per fit, share): " + "  ".join(
                 "%s %.0f (%.0f%%)" % (nm, v / 100.0, 100 * v / tot) for nm, v in zip(names, prof) if v > 0), flush=True)
