@@ -336,11 +336,11 @@ __device__ inline void store_tile(const d4& v, gd* __restrict__ Cm, gd* __restri
   if (CT) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) tile[(lq + 4 * r) * 17 + lr] = v[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) CT[(size_t)(j0 + lq + 4 * r) * ld + i0 + lr] = tile[lr * 17 + lq + 4 * r];
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -386,7 +386,7 @@ __device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
       for (int c = 0; c < 16; ++c) g_sh.dblk[r * 17 + c] = (c <= r) ? a[c] : 0.0;  // L_kk
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
 #ifdef GAPRO_PROFILE
   const unsigned long long tp1 = wall_clock64();
@@ -412,7 +412,7 @@ __device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
       for (int c = 0; c < 16; ++c) g_sh.dinv[c * 17 + r] = x[c];  // Dinv[c][r]: lane r holds column r
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
 #ifdef GAPRO_PROFILE
   const unsigned long long tp2 = wall_clock64();
@@ -500,7 +500,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
       double acc = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc += (q <= c) ? pb[i * 17 + q] * sh.dinv[c * 17 + q] : 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();  // the 16 lanes of a row have all read S before any overwrites it
       pb[i * 17 + c] = acc;
     }
@@ -596,7 +596,7 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
       double acc = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc += (q <= c) ? pb[i * 17 + q] * sh.dinv[c * 17 + q] : 0.0;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();  // the 16 lanes of a row have all read S before any overwrites it
       pb[i * 17 + c] = acc;
     }
@@ -1923,6 +1923,84 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
     const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
     const double step_size = opt.lr / bc1;
+#if GAPRO_NT < 320
+    // Software-pipelined over the wave's tiles: the loads of tile q+1 are in flight while tile q is updated.  That
+    // only works in STRAIGHT-LINE code: s_waitcnt counts memory operations in issue order, and behind any join of
+    // two paths (a tile guard, a per-element "if active") the compiler can only wait for vmcnt(0), i.e. for every
+    // store of the previous tile to reach memory before the next tile's loads are even consumed.  So: one
+    // instantiation per number of rounds (uniform over the workgroup), no guard inside it.  A slot past the wave's
+    // last tile runs on the wave's first tile with its stores redirected to a buffer that is dead here (Pm, written
+    // in full by the first tail product); inactive elements (upper half of a diagonal tile, padded rows) are loaded
+    // and stored back unchanged instead of being skipped.  Bit-identical to the guarded form below.
+    auto adam_ls = [&](auto rtag) {
+      constexpr int R = decltype(rtag)::value;
+      double lsv[4], m1v[4], m2v[4], lsn[4], m1n[4], m2n[4];
+      auto slot_tile = [&](int q, int* ti, int* tj) {
+        const int t = wave + NW * q;
+        const bool valid = t < nt_acc;
+        lower_tile(valid ? t : wave, ti, tj);
+        return valid;
+      };
+      auto load_tile = [&](int q, double (&l)[4], double (&a1)[4], double (&a2)[4]) {
+        int ti, tj;
+        slot_tile(q, &ti, &tj);
+        const int j = 16 * tj + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t o = (size_t)(16 * ti + lq + 4 * r) * Mp + j;
+          l[r] = LS[o];
+          a1[r] = MLS[o];
+          a2[r] = VLS[o];
+        }
+      };
+      load_tile(0, lsv, m1v, m2v);
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        if (q + 1 < R) load_tile(q + 1, lsn, m1n, m2n);
+        int ti, tj;
+        const bool valid = slot_tile(q, &ti, &tj);
+        gd* wLS = uni_ptr(valid ? LS : Pm);
+        gd* wMLS = uni_ptr(valid ? MLS : Pm);
+        gd* wVLS = uni_ptr(valid ? VLS : Pm);
+        gd* wGL = uni_ptr(valid ? GLb : Pm);
+        gd* wLST = uni_ptr(valid ? LST : Pm);
+        const int j = 16 * tj + lr;
+        d4 newv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * ti + lq + 4 * r;
+          const size_t o = (size_t)i * Mp + j;
+          const bool act = j <= i && i < M;
+          const double l = act ? lsv[r] : 1.0;
+          const double g = gls[q][r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+          const double m1 = b1 * m1v[r] + (1.0 - b1) * g;
+          const double m2 = b2 * m2v[r] + (1.0 - b2) * g * g;
+          const double lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+          wMLS[o] = act ? m1 : m1v[r];
+          wVLS[o] = act ? m2 : m2v[r];
+          wLS[o] = act ? lnew : lsv[r];
+          newv[r] = act ? lnew : 0.0;
+          wGL[o] = (j <= i) ? gl[q][r] : 0.0;
+        }
+        store_tile(newv, nullptr, wLST, Mp, 16 * ti, 16 * tj, tile);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lsv[r] = lsn[r];
+          m1v[r] = m1n[r];
+          m2v[r] = m2n[r];
+        }
+      }
+    };
+    if (wave < nt_acc) {
+      switch ((nt_acc + NW - 1) / NW) {  // M_p <= 64 (the small-fit route) with four waves: at most three rounds
+        case 1: adam_ls(std::integral_constant<int, 1>()); break;
+        case 2: adam_ls(std::integral_constant<int, 2>()); break;
+        default: adam_ls(std::integral_constant<int, 3>()); break;
+      }
+    }
+#else
+    // (512 threads: the straight-line form above makes this phase 19 % faster at M = 128, but the strip phases of the
+    // same kernel get slower and the fit loses 1..4 % at M = 80..128, with five, four or two instantiations alike)
     {
       // software-pipelined over the wave's tiles: the loads of tile q+1 are in flight while tile q is updated
       double lsv[4], m1v[4], m2v[4], lsn[4], m1n[4], m2n[4];
@@ -1981,6 +2059,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         }
       }
     }
+#endif
     __syncthreads();
     stamp(8);
 
