@@ -1717,6 +1717,82 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
 }
 #endif
 
+#if GAPRO_NT >= 320
+// Adam on LS for the wave's lower tiles in straight-line code (see the comment at its twin inside the kernel, used by
+// the 256-thread build): a function of its own so that its registers (a tile in flight, a tile being updated, the
+// division and square-root sequences) are allocated apart from the strip loop, whose accumulator tiles arrive here
+// by value.  R = rounds of the workgroup; a slot past the wave's last tile works on the wave's first tile with
+// its stores redirected to Pm, which is dead until the first tail product rewrites it in full.
+template <int R>
+__device__ __noinline__ void adam_ls_tiles(d4 g0, d4 g1, d4 g2, d4 g3, d4 g4, double Nd, double step_size, double bc2s,
+                                           ldsd* tile) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, M = f.M, nbk = Mp / 16, nt_acc = nbk * (nbk + 1) / 2;
+  gd* LS = f.mat[B_LS];
+  gd* LST = f.mat[B_LST];
+  gd* MLS = f.mat[B_MLS];
+  gd* VLS = f.mat[B_VLS];
+  gd* Pm = f.mat[B_GA];
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
+  const d4 gls[5] = {g0, g1, g2, g3, g4};
+  double lsv[4], m1v[4], m2v[4], lsn[4], m1n[4], m2n[4];
+  auto slot_tile = [&](int q, int* ti, int* tj) {
+    const int t = wave + NW * q;
+    const bool valid = t < nt_acc;
+    lower_tile(valid ? t : wave, ti, tj);
+    return valid;
+  };
+  auto load_tile = [&](int q, double (&l)[4], double (&a1)[4], double (&a2)[4]) {
+    int ti, tj;
+    slot_tile(q, &ti, &tj);
+    const int j = 16 * tj + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t o = (size_t)(16 * ti + lq + 4 * r) * Mp + j;
+      l[r] = LS[o];
+      a1[r] = MLS[o];
+      a2[r] = VLS[o];
+    }
+  };
+  load_tile(0, lsv, m1v, m2v);
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (q + 1 < R) load_tile(q + 1, lsn, m1n, m2n);
+    int ti, tj;
+    const bool valid = slot_tile(q, &ti, &tj);
+    gd* wLS = uni_ptr(valid ? LS : Pm);
+    gd* wMLS = uni_ptr(valid ? MLS : Pm);
+    gd* wVLS = uni_ptr(valid ? VLS : Pm);
+    gd* wLST = uni_ptr(valid ? LST : Pm);
+    const int j = 16 * tj + lr;
+    d4 newv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 16 * ti + lq + 4 * r;
+      const size_t o = (size_t)i * Mp + j;
+      const bool act = j <= i && i < M;
+      const double l = act ? lsv[r] : 1.0;
+      const double g = gls[q][r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+      const double m1 = b1 * m1v[r] + (1.0 - b1) * g;
+      const double m2 = b2 * m2v[r] + (1.0 - b2) * g * g;
+      const double lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+      wMLS[o] = act ? m1 : m1v[r];
+      wVLS[o] = act ? m2 : m2v[r];
+      wLS[o] = act ? lnew : lsv[r];
+      newv[r] = act ? lnew : 0.0;
+    }
+    store_tile(newv, nullptr, wLST, Mp, 16 * ti, 16 * tj, tile);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lsv[r] = lsn[r];
+      m1v[r] = m1n[r];
+      m2v[r] = m2n[r];
+    }
+  }
+}
+#endif
+
 template <int DMAX, int DC>
 __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* region,
                                const gapro_fit_desc& desc, float* __restrict__ o_probs,
@@ -1740,8 +1816,10 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   ldsd* gv_s = gmu_s + SW;
   gd* LS = f.mat[B_LS];
   gd* LST = f.mat[B_LST];
+#if GAPRO_NT < 320
   gd* MLS = f.mat[B_MLS];
   gd* VLS = f.mat[B_VLS];
+#endif
   gd* GLb = f.mat[B_BM];    // G_L (lower) for the tail products
   gd* Pm = f.mat[B_GA];
   gd* T1T = f.mat[B_BMT];
@@ -1999,63 +2077,31 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       }
     }
 #else
-    // (512 threads: the straight-line form above makes this phase 19 % faster at M = 128, but the strip phases of the
-    // same kernel get slower and the fit loses 1..4 % at M = 80..128, with five, four or two instantiations alike)
-    {
-      // software-pipelined over the wave's tiles: the loads of tile q+1 are in flight while tile q is updated
-      double lsv[4], m1v[4], m2v[4], lsn[4], m1n[4], m2n[4];
-      auto load_tile = [&](int q, double (&l)[4], double (&a1)[4], double (&a2)[4]) {
-        const int t = wave + NW * q;
-        if (t < nt_acc) {
-          int ti, tj;
-          lower_tile(t, &ti, &tj);
-          const int j = 16 * tj + lr;
+    // 512 threads: the same straight-line code, but as a function of its own (adam_ls_tiles).  Inlined here it makes
+    // this phase faster and the strip phases slower (-1..-4 % overall, whatever the instantiation count); as a
+    // function it is +3 % fits/s at M = 80, 96 and -0.5..-0.8 % at M = 112, 128 (the stores still in flight delay
+    // the first tail product).  Keeping the guarded loop beside it for four and five rounds costs 2..3 % everywhere.
+    if (wave < nt_acc) {
+      switch ((nt_acc + NW - 1) / NW) {  // 64 < M_p <= 128 with eight waves: two to five rounds
+        case 1:
+        case 2: adam_ls_tiles<2>(gls[0], gls[1], gls[2], gls[3], gls[4], Nd, step_size, bc2s, tile); break;
+        case 3: adam_ls_tiles<3>(gls[0], gls[1], gls[2], gls[3], gls[4], Nd, step_size, bc2s, tile); break;
+        case 4: adam_ls_tiles<4>(gls[0], gls[1], gls[2], gls[3], gls[4], Nd, step_size, bc2s, tile); break;
+        default: adam_ls_tiles<5>(gls[0], gls[1], gls[2], gls[3], gls[4], Nd, step_size, bc2s, tile); break;
+      }
+    }
+    // G_L tiles -> global for the tail products
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ti + lq + 4 * r;
-            const size_t o = (size_t)i * Mp + j;
-            const bool act = j <= i && i < M;
-            l[r] = act ? LS[o] : 1.0;
-            a1[r] = act ? MLS[o] : 0.0;
-            a2[r] = act ? VLS[o] : 0.0;
-          }
-        }
-      };
-      load_tile(0, lsv, m1v, m2v);
-#pragma unroll
-      for (int q = 0; q < kAccTiles; ++q) {
-        const int t = wave + NW * q;
-        if (q + 1 < kAccTiles) load_tile(q + 1, lsn, m1n, m2n);
-        if (t < nt_acc) {
-          int ti, tj;
-          lower_tile(t, &ti, &tj);
-          const int j = 16 * tj + lr;
-          d4 newv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ti + lq + 4 * r;
-            const size_t o = (size_t)i * Mp + j;
-            double lnew = 0.0;
-            if (j <= i && i < M) {
-              const double l = lsv[r];
-              const double g = gls[q][r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
-              const double m1 = b1 * m1v[r] + (1.0 - b1) * g;
-              const double m2 = b2 * m2v[r] + (1.0 - b2) * g * g;
-              MLS[o] = m1;
-              VLS[o] = m2;
-              lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
-              LS[o] = lnew;
-            }
-            newv[r] = lnew;
-            GLb[o] = (j <= i) ? gl[q][r] : 0.0;
-          }
-          store_tile(newv, nullptr, LST, Mp, 16 * ti, 16 * tj, tile);
-        }
+    for (int q = 0; q < kAccTiles; ++q) {
+      const int t = wave + NW * q;
+      if (t < nt_acc) {
+        int ti, tj;
+        lower_tile(t, &ti, &tj);
+        const int j = 16 * tj + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          lsv[r] = lsn[r];
-          m1v[r] = m1n[r];
-          m2v[r] = m2n[r];
+          const int i = 16 * ti + lq + 4 * r;
+          GLb[(size_t)i * Mp + j] = (j <= i) ? gl[q][r] : 0.0;
         }
       }
     }
