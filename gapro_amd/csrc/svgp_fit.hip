@@ -280,41 +280,55 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
     const gd* qbase = Q + (size_t)lq * ld + j0 + lr;
     constexpr int KS = 2;  // k-steps (of 4) per register block; two blocks alternate (one in flight)
     constexpr int KB = 4 * KS;
+    // Two register blocks alternate.  Everything between the issue of a block's loads and its MFMAs is straight-line
+    // code: s_waitcnt counts memory operations in issue order, and behind a join of two paths ("prefetch only if
+    // there is a next block") the compiler falls back to waiting for everything, i.e. for the block it has just
+    // requested -- no load would ever overlap an MFMA.  So the steady-state loop has no guard in its body (the last
+    // one or two blocks are peeled off behind it), and the column scale of the SCALE form is applied when a block
+    // is consumed, not when it is loaded (a multiply at load time is a wait at load time).
     double a0[KS][TU], b0[KS][TU], a1[KS][TU], b1[KS][TU];
-    auto load_block = [&](int k, double (&a)[KS][TU], double (&b)[KS][TU]) {
+    double s0[KS], s1[KS];
+    auto load_block = [&](int k, double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const gd* pr = pbase + (size_t)(k + 4 * s) * ld;
         const gd* qr = qbase + (size_t)(k + 4 * s) * ld;
 #pragma unroll
         for (int u = 0; u < TU; ++u) a[s][u] = pr[16 * u];
-        if (SCALE) {
-          const double sc = qscale[k + 4 * s + lq];
 #pragma unroll
-          for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v] * sc;
-        } else {
-#pragma unroll
-          for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v];
-        }
+        for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v];
+        if (SCALE) sc[s] = qscale[k + 4 * s + lq];
       }
     };
-    auto mma_block = [&](double (&a)[KS][TU], double (&b)[KS][TU]) {
+    auto mma_block = [&](double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
+      for (int s = 0; s < KS; ++s) {
+        double bs[TU];
+#pragma unroll
+        for (int v = 0; v < TU; ++v) bs[v] = SCALE ? b[s][v] * sc[s] : b[s][v];
 #pragma unroll
         for (int u = 0; u < TU; ++u)
 #pragma unroll
           for (int v = 0; v < TU; ++v)
-            acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], b[s][v], acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], bs[v], acc[u][v], 0, 0, 0);
+      }
     };
-    if (klo < khi) load_block(klo, a0, b0);
+    if (klo < khi) {  // khi - klo is a multiple of 16 (tile-aligned ranges), hence of KB
+      load_block(klo, a0, b0, s0);
+      int k = klo;
 #pragma nounroll
-    for (int k = klo; k < khi; k += 2 * KB) {
-      if (k + KB < khi) load_block(k + KB, a1, b1);
-      mma_block(a0, b0);
-      if (k + KB < khi) {
-        if (k + 2 * KB < khi) load_block(k + 2 * KB, a0, b0);
-        mma_block(a1, b1);
+      for (; k + 2 * KB < khi; k += 2 * KB) {  // steady state: both prefetches are real, no guard in the body
+        load_block(k + KB, a1, b1, s1);
+        mma_block(a0, b0, s0);
+        load_block(k + 2 * KB, a0, b0, s0);
+        mma_block(a1, b1, s1);
+      }
+      if (k + KB < khi) {  // two blocks left
+        load_block(k + KB, a1, b1, s1);
+        mma_block(a0, b0, s0);
+        mma_block(a1, b1, s1);
+      } else {  // one block left
+        mma_block(a0, b0, s0);
       }
     }
 #pragma unroll
