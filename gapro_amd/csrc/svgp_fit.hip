@@ -450,6 +450,43 @@ __device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
 #endif
 }
 
+// acc -= sum_{q < Q} L[i][q] L[j][q] for one 16x16 tile of the Cholesky update (operands from L^T, TN form), Q a
+// multiple of 16.  Blocks of four k-steps (eight loads) alternate between two register sets with no guard in the
+// steady-state body, so that the loads of a block are in flight during the MFMAs of the previous one (see gemm_tn).
+__device__ inline void chol_update_tile(d4& acc, const gd* pa, const gd* pb, int Mp, int Q) {
+  const size_t st = (size_t)4 * Mp;
+  auto ld = [&](int q, double (&a)[4], double (&b)[4]) {
+    const size_t o = (size_t)q * Mp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = pa[o + e * st];
+      b[e] = pb[o + e * st];
+    }
+  };
+  auto mm = [&](double (&a)[4], double (&b)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[e], b[e], acc, 0, 0, 0);
+  };
+  if (Q <= 0) return;
+  double a0[4], b0[4], a1[4], b1[4];
+  ld(0, a0, b0);
+  int q = 0;
+#pragma nounroll
+  for (; q + 32 < Q; q += 32) {
+    ld(q + 16, a1, b1);
+    mm(a0, b0);
+    ld(q + 32, a0, b0);
+    mm(a1, b1);
+  }
+  if (q + 16 < Q) {
+    ld(q + 16, a1, b1);
+    mm(a0, b0);
+    mm(a1, b1);
+  } else {
+    mm(a0, b0);
+  }
+}
+
 // ---- Cholesky of Kzz + jitter I, fused with the kernel evaluation -----------------------------------
 // Left-looking, 16-wide block columns.  Block column kb:
 //   (1) S = Kzz[:, kb] - L[:, <kb] L[kb, <kb]^T : the Kzz tile is evaluated from the staged inducing
@@ -486,16 +523,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
       }
       const gd* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
       const gd* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
-#pragma nounroll
-      for (int q = 0; q < 16 * kb; q += 16) {  // blocks of four k-steps: eight loads in flight, then four MFMAs
-        const size_t o = (size_t)q * Mp, st = (size_t)4 * Mp;
-        const double a0 = pa[o], a1 = pa[o + st], a2 = pa[o + 2 * st], a3 = pa[o + 3 * st];
-        const double b0 = pb[o], b1 = pb[o + st], b2 = pb[o + 2 * st], b3 = pb[o + 3 * st];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc, 0, 0, 0);
-      }
+      chol_update_tile(acc, pa, pb, Mp, 16 * kb);
       ldsd* dst = panel + (16 * (ib - kb)) * 17;
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
@@ -571,16 +599,7 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
     }
     const gd* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
     const gd* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
-#pragma nounroll
-    for (int q = 0; q < 16 * qb; q += 16) {
-      const size_t o = (size_t)q * Mp, st = (size_t)4 * Mp;
-      const double a0 = pa[o], a1 = pa[o + st], a2 = pa[o + 2 * st], a3 = pa[o + 3 * st];
-      const double b0 = pb[o], b1 = pb[o + st], b2 = pb[o + 2 * st], b3 = pb[o + 3 * st];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0, b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1, b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a2, b2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a3, b3, acc, 0, 0, 0);
-    }
+    chol_update_tile(acc, pa, pb, Mp, 16 * qb);
     ldsd* dst = dst_panel + (16 * (ib - kb)) * 17;
 #pragma unroll
     for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
