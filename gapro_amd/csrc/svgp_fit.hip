@@ -661,6 +661,85 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
   }
 }
 
+// ---- the strip kernels' triangular inverse: one block column per wave as a straight-line chain ---------------
+// Same products in the same order as tri_inverse<8> (bit-identical), but instantiated per column length so that
+// there is no guard inside the chain: the L operands of block row ii + 1 (and its Dinv^T) are requested before the
+// MFMAs of row ii and are in flight while row ii is computed and stored.  In the guarded form every block waits
+// for its own loads and, s_waitcnt being what it is behind a join, for the stores of the block before.
+template <int CNT>
+__device__ inline void inv_column(int k, ldsd* tile) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp;
+  const gd* LT = f.mat[B_LT];
+  gd* LI = f.mat[B_LI];
+  gd* U = f.mat[B_U];
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  constexpr int MAXR = CNT > 1 ? CNT - 1 : 1;
+  d4 blk[CNT];
+  double A0[MAXR * 4], A1[MAXR * 4], D0[4], D1[4];
+  // operands of block row ii: L[16(k+ii)+lr][16(k+jj)+4s+lq] for jj < ii, and -Dinv_{k+ii}^T
+  auto ldrow = [&](int ii, double (&A)[MAXR * 4], double (&D)[4]) {
+    const int i = k + ii;
+#pragma unroll
+    for (int jj = 0; jj < MAXR; ++jj)
+      if (jj < ii) {
+        const gd* pa = LT + (size_t)(16 * (k + jj) + lq) * Mp + 16 * i + lr;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) A[jj * 4 + st] = pa[(size_t)(4 * st) * Mp];
+      }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) D[st] = f.dinvT[(size_t)i * 256 + (4 * st + lq) * 16 + lr];
+  };
+  d4 dk;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dk[r] = f.dinv[(size_t)k * 256 + (lq + 4 * r) * 16 + lr];
+  if (CNT > 1) ldrow(1, A1, D1);
+  store_tile(dk, LI, U, Mp, 16 * k, 16 * k, tile);
+  blk[0] = dk;
+#pragma unroll
+  for (int ii = 1; ii < CNT; ++ii) {
+    if (ii + 1 < CNT) {
+      if ((ii + 1) & 1) ldrow(ii + 1, A1, D1);
+      else ldrow(ii + 1, A0, D0);
+    }
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int jj = 0; jj < MAXR; ++jj)
+      if (jj < ii) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ii & 1) ? A1[jj * 4 + st] : A0[jj * 4 + st], blk[jj][st], acc, 0, 0, 0);
+      }
+    d4 out = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+      out = __builtin_amdgcn_mfma_f64_16x16x4f64(-((ii & 1) ? D1[st] : D0[st]), acc[st], out, 0, 0, 0);
+    store_tile(out, LI, U, Mp, 16 * (k + ii), 16 * k, tile);
+    blk[ii] = out;
+  }
+}
+__device__ __noinline__ void tri_inverse_strip(ldsd* tiles) {
+  const int nb = g_sh.f.Mp / 16;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  ldsd* tile = tiles + wave * 16 * 17;
+  for (int k = wave; k < nb; k += NW) {
+    switch (nb - k) {
+      case 1: inv_column<1>(k, tile); break;
+      case 2: inv_column<2>(k, tile); break;
+      case 3: inv_column<3>(k, tile); break;
+      case 4: inv_column<4>(k, tile); break;
+#if GAPRO_NT >= 320
+      case 5: inv_column<5>(k, tile); break;
+      case 6: inv_column<6>(k, tile); break;
+      case 7: inv_column<7>(k, tile); break;
+      default: inv_column<8>(k, tile); break;
+#else
+      default: break;  // M_p <= 64 on the small-fit route
+#endif
+    }
+  }
+}
+
 // ---- LI = L^-1 (lower) and U = LI^T, one 16-wide block column per wave -----------------------------
 //   LI_kk = Dinv_k;   LI_ik = -Dinv_i * sum_{j=k}^{i-1} L_ij LI_jk   (i > k)
 // Block columns are independent.  For nb <= NBR the blocks of the column stay in registers (an MFMA
@@ -1891,7 +1970,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
     stamp(19);
     cholesky_fused_lookahead<DC>(Zt, scratch, sh.s, sh.inv_l2, jitter);
     stamp(1);
-    tri_inverse<8>(scratch);
+    tri_inverse_strip(scratch);
     __syncthreads();
     stamp(2);
   };
