@@ -240,7 +240,7 @@ __device__ inline void stage_points_t(ldsd* dst, const gd* src, int n, int D, in
 // 8-deep block are loaded before the MFMAs of the current one are issued.
 // MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3): A[i = l & 15][k = l >> 4],
 // B[k = l >> 4][j = l & 15], C/D register r -> row (l >> 4) + 4 r, col l & 15.
-template <int TU, bool SCALE, typename KRange, typename Epi>
+template <int TU, bool SCALE, int KS = 2, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
@@ -278,7 +278,8 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
       for (int v = 0; v < TU; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
     const gd* pbase = P + (size_t)lq * ld + i0 + lr;
     const gd* qbase = Q + (size_t)lq * ld + j0 + lr;
-    constexpr int KS = 2;  // k-steps (of 4) per register block; two blocks alternate (one in flight)
+    // KS = k-steps (of 4) per register block; two blocks alternate (one in flight).  2 under the 128-VGPR budget of
+    // the LDS-staged kernel, 4 in the strip kernels' tail (256 VGPRs: +1.5 %; in the staged kernel -3..-6 %)
     constexpr int KB = 4 * KS;
     // Two register blocks alternate.  Everything between the issue of a block's loads and its MFMAs is straight-line
     // code: s_waitcnt counts memory operations in issue order, and behind a join of two paths ("prefetch only if
@@ -2226,7 +2227,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       constexpr int TU = decltype(tu_tag)::value;
       constexpr int TS = 16 * TU;
       const int mt = Mp / TS;
-      gemm_tn<TU, false>(mt, mt, true, f.mat[B_L], GLb, Mp, nullptr,
+      gemm_tn<TU, false, 4>(mt, mt, true, f.mat[B_L], GLb, Mp, nullptr,
                          [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                          [=](int i0, int j0, const d4& v) {
                            const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
@@ -2237,16 +2238,16 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
                            }
                          });
       __syncthreads();
-      gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+      gemm_tn<TU, false, 4>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                          [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                          [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
       __syncthreads();
-      gemm_tn<TU, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+      gemm_tn<TU, false, 4>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                          [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                          [=](int i, int j, const d4& v) { store_tile(v, Gb, GTb, Mp, i, j, tile); });
       __syncthreads();
     };
-    if (Mp >= 128)
+    if (Mp >= 64 && Mp % 32 == 0)
       tail(std::integral_constant<int, 2>());
     else
       tail(std::integral_constant<int, 1>());
