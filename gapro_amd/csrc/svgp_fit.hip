@@ -1620,21 +1620,18 @@ __device__ __noinline__ void strip_gemm(const gd* __restrict__ P, int Mp, const 
   nbk = uni(nbk);
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
-  const int t0 = wave, t1 = wave + NW;
-  if (t0 >= 2 * nbk) return;
-  const int rb0 = t0 < nbk ? t0 : 2 * nbk - 1 - t0, ct0 = t0 < nbk ? 0 : 1;
-  const bool two = t1 < 2 * nbk;
-  const int rb1 = two ? (t1 < nbk ? t1 : 2 * nbk - 1 - t1) : 0, ct1 = two ? (t1 < nbk ? 0 : 1) : 0;
-  const int kb0 = MODE == K_LE ? 0 : rb0, n0 = MODE == K_LE ? rb0 + 1 : nbk - rb0;  // first block, block count
-  const int kb1 = MODE == K_LE ? 0 : rb1, n1 = two ? (MODE == K_LE ? rb1 + 1 : nbk - rb1) : 0;
+  // One row block per wave, BOTH column tiles of the strip: every A fragment is fetched once per workgroup (dealing
+  // the 2 nbk tiles out one by one balances the MFMAs better, 9 blocks per wave instead of up to 16, but fetches
+  // every fragment twice, and the strip products wait for their operands, not for the matrix cores).
+  const int rb = wave;
+  if (rb >= nbk) return;
+  const int kb0 = MODE == K_LE ? 0 : rb, n = MODE == K_LE ? rb + 1 : nbk - rb;  // first k-block, block count
   const size_t sa = (size_t)4 * Mp;
   double a[kStripBlocks][4];
 #pragma unroll
   for (int blk = 0; blk < kStripBlocks; ++blk) {
-    if (blk < n0 + n1) {
-      const bool first = blk < n0;
-      const int kb = first ? kb0 + blk : kb1 + (blk - n0);
-      const gd* pa = P + (size_t)(16 * kb + lq) * Mp + 16 * (first ? rb0 : rb1) + lr;
+    if (blk < n) {
+      const gd* pa = P + (size_t)(16 * (kb0 + blk) + lq) * Mp + 16 * rb + lr;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) a[blk][ks] = pa[ks * sa];
     }
@@ -1642,23 +1639,17 @@ __device__ __noinline__ void strip_gemm(const gd* __restrict__ P, int Mp, const 
   d4 acc0 = (d4){0.0, 0.0, 0.0, 0.0}, acc1 = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int blk = 0; blk < kStripBlocks; ++blk) {
-    if (blk < n0 + n1) {
-      const bool first = blk < n0;
-      const int kb = first ? kb0 + blk : kb1 + (blk - n0);
-      const ldsd* pb = Sin + (16 * kb + lq) * RS + 16 * (first ? ct0 : ct1) + lr;
-      if (first) {
+    if (blk < n) {
+      const ldsd* pb = Sin + (16 * (kb0 + blk) + lq) * RS + lr;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[blk][ks], pb[4 * ks * RS], acc0, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[blk][ks], pb[4 * ks * RS], acc1, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[blk][ks], pb[4 * ks * RS], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[blk][ks], pb[4 * ks * RS + 16], acc1, 0, 0, 0);
       }
     }
   }
-  epi(rb0, ct0, acc0);
-  if (two) epi(rb1, ct1, acc1);
+  epi(rb, 0, acc0);
+  epi(rb, 1, acc1);
 }
 
 __device__ inline void lower_tile(int t, int* ti, int* tj) {
