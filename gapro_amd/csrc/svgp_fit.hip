@@ -1604,12 +1604,11 @@ inline __host__ __device__ bool strip_ok(int m, int d) {
 
 enum { K_LE = 0, K_GE = 1 };
 // One strip product: out[16 rb .. ][16 ct ..] = sum_k P[k][16 rb + i] * Sin[k][16 ct + n], k restricted to
-// k < 16 (rb+1) (K_LE: P upper-triangular in (k,i)) or k >= 16 rb (K_GE).  2 nbk tiles over 8 waves, dealt
-// so that a wave's two tiles have complementary k-ranges (nbk + 1 <= 9 blocks of 16 in total).  The A
-// operand streams from global memory (TN rows); the fixed operand matrices of 256 concurrent fits do not
-// stay in L2, so a fetch costs ~1 us under load: ALL of the wave's A fragments (<= 36 loads) are issued up
-// front and the MFMAs consume them in order, paying that latency once per product instead of once per
-// k-block.  The B operand comes from the LDS strip buffer.
+// k < 16 (rb+1) (K_LE: P upper-triangular in (k,i)) or k >= 16 rb (K_GE).  Wave rb owns row block rb and both
+// 16-column tiles of the strip (at most 8 k-blocks, 16 MFMA groups).  The A operand streams from global memory
+// (TN rows); the fixed operand matrices of 256 concurrent fits do not stay in L2, so a fetch costs ~1 us under
+// load: ALL of the wave's A fragments (<= 32 loads) are issued up front and the MFMAs consume them in order,
+// paying that latency once per product instead of once per k-block.  The B operand comes from the LDS strip buffer.
 constexpr int kStripBlocks = kStripMaxMp / 16 + 1;
 template <int MODE, typename Epi>
 __device__ __noinline__ void strip_gemm(const gd* __restrict__ P, int Mp, const ldsd* Sin, int nbk, Epi epi) {
