@@ -229,3 +229,29 @@ def test_fit_reports_non_finite_inputs_instead_of_returning_garbage():
     assert e.value.code in (-4, -5)
     ok = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=5)[0]  # the clean fit alone is fine
     assert np.isfinite(ok[3]).all()
+
+
+def test_small_fit_kernel_and_strip_kernel_agree():
+    """The 256-thread small-fit kernel (M_p <= 64, two fits per CU) and the 512-thread strip kernel are two builds of
+    one source; with the small route switched off (gapro_fit_options.reserved bit 2) the same fits must come out
+    of the other build within float32 rounding, and the route function must report what ran."""
+    import torch
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.gen_ps_utils import _pipeline
+    from gapro_amd.synth import make_gp_problem
+
+    lib = _lib.load()
+    for (m1, m2, t) in [(1, 2, 1), (7, 9, 5), (20, 28, 33), (31, 33, 64), (3, 4, 70)]:
+        assert lib.gapro_fit_route(m1 + m2, 6) == 3
+        f, b1, b2, it = make_gp_problem(500 + m1, m1, m2, t, 6)
+        a = fit_gp_spp_batch(f, [(b1, b2, it)], training_iter=50)[0]
+        pipe = _pipeline(torch.device("cuda", 0), 50)
+        old = pipe.opt.reserved
+        pipe.opt.reserved = old | 4
+        try:
+            b = fit_gp_spp_batch(f, [(b1, b2, it)], training_iter=50)[0]
+        finally:
+            pipe.opt.reserved = old
+        for x, y in zip(a, b):
+            np.testing.assert_allclose(np.asarray(x, np.float64), np.asarray(y, np.float64), rtol=0, atol=2e-6)
