@@ -90,6 +90,7 @@ def make_scene(
     feat_noise: float = 0.05,
     scan_name: Optional[str] = None,
     p_kinds=(0.30, 0.05, 0.02),
+    p_wall: float = 0.0,
 ) -> Scene:
     rng = np.random.default_rng(seed)
     ex, ey, ez = rng.uniform(4.0, 8.0), rng.uniform(3.0, 7.0), rng.uniform(2.4, 3.0)
@@ -137,6 +138,16 @@ def make_scene(
         c = np.clip(c, 0.5 * sz[:2] + 0.1, np.array([ex, ey]) - 0.5 * sz[:2] - 0.1)
         centers[k], sizes[k], z0[k] = c, sz, zb
         yaw[k] = rng.uniform(-0.25, 0.25) if (kind[k] in (0, 1) and rng.random() < 0.5) else 0.0
+        if p_wall > 0.0 and kind[k] in (0, 1) and rng.random() < p_wall:
+            # furniture pushed against a wall: the face towards the nearest wall lies in the wall's plane (within a
+            # few millimetres), so the object's box and the wall box of reference scannet_planes.py:101-159 overlap
+            # and the pair reaches the GP (gen_ps_utils.py:328-345, 401-437).  Drawn only when asked for, so the
+            # random stream of every other scene is unchanged.
+            ax = int(rng.integers(0, 2))
+            lim = (ex, ey)[ax]
+            off = rng.uniform(-0.003, 0.003)
+            centers[k, ax] = (0.5 * sizes[k, ax] + off) if centers[k, ax] < 0.5 * lim else (lim - 0.5 * sizes[k, ax] - off)
+            yaw[k] = 0.0
 
     # ---- surface areas -> point budget ------------------------------------------------
     obj_area = 2 * (sizes[:, 0] + sizes[:, 1]) * sizes[:, 2] + sizes[:, 0] * sizes[:, 1]

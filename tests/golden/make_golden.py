@@ -116,6 +116,10 @@ SCENES = [
                      p_kinds=(0.2, 0.15, 0.3))),
     ("s3_bigspp", dict(seed=42, n_points=12000, n_objects=4, with_walls_json=False, obj_patch=1100,
                        plane_patch=1300)),
+    # furniture flush against the walls and small floor patches: the reference's recorded schedule holds
+    # wall-object and floor-object GP pairs (the reason it adds those boxes, gen_ps_utils.py:328-345, 401-437)
+    ("s5_lean", dict(seed=32, n_points=9000, n_objects=10, with_walls_json=True, obj_patch=20, plane_patch=25,
+                     p_wall=0.6)),
 ]
 
 
@@ -195,9 +199,16 @@ def main():
                 rec["fit%03d_%s" % (i, k)] = v
         np.savez_compressed(os.path.join(outdir, name + ".npz"), **rec)
         ms = [len(f["b1_inds"]) + len(f["b2_inds"]) for f in fits]
-        summary[name] = dict(N=int(len(sem)), S=int(len(mu)), B=int(len(instance_box) + len(wall_box) + 1),
+        n_inst, n_box = len(instance_box), len(instance_box) + len(wall_box) + 1
+        # which boxes a recorded fit pairs: its training superpoints lie in exactly one box each
+        occ = occ_mean >= np.float32(0.999)
+        pairs = [(int(np.argmax(occ[f["b1_inds"][0]])), int(np.argmax(occ[f["b2_inds"][0]]))) for f in fits]
+        n_wall_fits = sum(1 for a, b in pairs if n_inst <= max(a, b) < n_box - 1)
+        n_floor_fits = sum(1 for a, b in pairs if max(a, b) == n_box - 1)
+        summary[name] = dict(N=int(len(sem)), S=int(len(mu)), B=int(n_box),
                              n_fits=len(fits), M_max=int(max(ms) if ms else 0), walls=int(len(wall_box)),
-                             n_gp_labelled=int((mu != -100).sum()))
+                             n_gp_labelled=int((mu != -100).sum()), wall_fits=n_wall_fits,
+                             floor_fits=n_floor_fits)
         print(name, summary[name])
     with open(os.path.join(outdir, "SUMMARY.json"), "w") as f:
         json.dump(summary, f, indent=1)

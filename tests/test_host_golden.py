@@ -147,3 +147,22 @@ def test_get_miou_scene_matches_reference(golden):
     ious = get_miou_scene(gt_sem.long(), gt_ins.long(), torch.from_numpy(golden["out_sem"]).long(),
                           torch.from_numpy(golden["out_inst"]).long())
     np.testing.assert_array_equal(ious.numpy(), golden["ref_ious"])
+
+
+def test_golden_set_holds_wall_and_floor_gp_pairs():
+    """The reference adds the wall boxes and the floor box so that wall-object and floor-object pairs reach the GP
+    (gen_ps_utils.py:328-345, 401-437).  At least one fixture must record such fits, identified from the
+    reference's own occupancy: a fit's training superpoints lie in exactly one box each."""
+    from conftest import GOLDEN_NAMES, Golden
+
+    wall = floor = 0
+    for name in GOLDEN_NAMES:
+        g = Golden(name)
+        occ = g["ref_occ_mean"] >= np.float32(0.999)
+        n_inst, n_box = len(g["gi_box"]), occ.shape[1]
+        for f in g.fits:
+            a, b = int(np.argmax(occ[f["b1_inds"][0]])), int(np.argmax(occ[f["b2_inds"][0]]))
+            assert occ[f["b1_inds"]].sum(1).max() == 1 and occ[f["b2_inds"]].sum(1).max() == 1
+            wall += n_inst <= max(a, b) < n_box - 1
+            floor += max(a, b) == n_box - 1
+    assert wall >= 3 and floor >= 1, (wall, floor)
