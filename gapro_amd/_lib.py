@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgapro_hip.so")
 
 GAPRO_OK = 0
+GAPRO_ERR_NOT_FINITE = -4
+GAPRO_ERR_CHOLESKY = -5
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "OOM", -3: "HIP", -4: "NOT_FINITE", -5: "CHOLESKY", -6: "SPP_RANGE",
                 -7: "WORKSPACE"}
 
@@ -62,7 +64,8 @@ class EvalHeader(C.Structure):
 
 class FitOptions(C.Structure):
     _fields_ = [("training_iter", C.c_int32), ("lr", C.c_double), ("jitter", C.c_double),
-                ("min_variance", C.c_double), ("eval_stale_chol", C.c_int32), ("reserved", C.c_int32)]
+                ("min_variance", C.c_double), ("eval_stale_chol", C.c_int32), ("reserved", C.c_int32),
+                ("psd_retries", C.c_int32), ("precision", C.c_int32), ("psd_jitter", C.c_double)]
 
 
 # name -> (restype, argtypes); every symbol of include/gapro_hip.h
@@ -116,6 +119,7 @@ SIGNATURES = {
     "gapro_fit_timing_read": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "gapro_debug_stream": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
+    "gapro_debug_mfma_peak": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None

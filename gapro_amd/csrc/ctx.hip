@@ -64,6 +64,9 @@ void gapro_fit_options_default(gapro_fit_options* opt) {
   opt->min_variance = 1e-6;
   opt->eval_stale_chol = 0;
   opt->reserved = 0;
+  opt->psd_retries = 3;
+  opt->precision = GAPRO_PRECISION_F64;
+  opt->psd_jitter = 1e-8;
 }
 
 }  // extern "C"

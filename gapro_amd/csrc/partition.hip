@@ -84,12 +84,17 @@ __global__ __launch_bounds__(kThreads) void k_stats(const gapro_scene_task* __re
     mn[0] = fmin(mn[0], x); mx[0] = fmax(mx[0], x);
     mn[1] = fmin(mn[1], y); mx[1] = fmax(mx[1], y);
     mn[2] = fmin(mn[2], z); mx[2] = fmax(mx[2], z);
+    // fmin / fmax drop NaNs: a non-finite coordinate is carried in the feature statistic (+inf = "scene not finite")
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) fa = INFINITY;
     const long long s = spp[i];
     smin = s < smin ? s : smin;
     smax = s > smax ? s : smax;
   }
   const long long nf = n * d;
-  for (long long i = tid; i < nf; i += stride) fa = fmaxf(fa, fabsf(feats[i]));
+  for (long long i = tid; i < nf; i += stride) {
+    const float v = feats[i];
+    fa = fmaxf(fa, isfinite(v) ? fabsf(v) : INFINITY);  // fmaxf would drop a NaN; the reference would propagate it
+  }
 
   __shared__ StatsPartial sh[kThreads / 64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -161,6 +166,9 @@ __global__ __launch_bounds__(kThreads) void k_stats_final(const gapro_scene_task
   h.status = GAPRO_OK;
   const unsigned long long range = (unsigned long long)p.smax - (unsigned long long)p.smin;
   if (range >= (unsigned long long)range_cap) h.status = GAPRO_ERR_SPP_RANGE;
+  // a NaN / Inf coordinate or feature: the reference would propagate it into every pooled mean and kernel matrix of
+  // the scene; here the scene is reported and skipped (k_pool's fixed-point sum would silently turn a NaN into 0)
+  if (!isfinite(p.fabsmax)) h.status = GAPRO_ERR_NOT_FINITE;
   ws->header = h;
   headers[blockIdx.y] = h;
 }

@@ -146,6 +146,7 @@ struct Shared {
   double dinv[16 * 17];
   double c, rho_s, rho_l, s, ell, inv_l2;
   int status;
+  int chol_bad;  // a pivot of the factorisation in progress was not positive (see factorize: the jitter retries)
 };
 __shared__ Shared g_sh;  // one fit per workgroup
 
@@ -395,7 +396,7 @@ __device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
 #pragma unroll
       for (int c = j + 1; c < 16; ++c) a[c] -= lj * lane_bcast(lj, c);  // only rows r >= c are used later
     }
-    if (bad && lane == 0) g_sh.status = GAPRO_ERR_CHOLESKY;
+    if (bad && lane == 0) g_sh.chol_bad = 1;
     if (lane < 16) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) g_sh.dblk[r * 17 + c] = (c <= r) ? a[c] : 0.0;  // L_kk
@@ -659,6 +660,33 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
       }
     __syncthreads();
     prof_stamp(18);
+  }
+}
+
+// ---- gpytorch's psd_safe_cholesky around either factorisation -----------------------------------------------
+// VariationalStrategy._cholesky_factor calls psd_safe_cholesky(K_ZZ.double() + jitter I): when the factorisation meets
+// a non-positive pivot it is repeated on K + j I with j = psd_jitter * 10^i (settings.cholesky_jitter: 1e-8 for
+// float64), i = 0 .. psd_retries - 1 (settings.cholesky_max_tries = 3), and only then gives up (NotPSDError -> here
+// GAPRO_ERR_CHOLESKY for this fit; the other fits of the launch are unaffected).  The extra jitter lives inside the
+// factorisation only: it is not added to the k_xx term of the predictive variance, as in gpytorch.  A function of its
+// own so that the retry state is not live across the step loop of the callers.
+template <int DC, bool LOOKAHEAD>
+__device__ __noinline__ void cholesky_psd_safe(const ldsd* Zt, ldsd* scratch, double s, double inv_l2, double jitter,
+                                               int retries, double psd_jitter) {
+  double extra = 0.0;
+  for (int attempt = 0;; ++attempt) {
+    if (LOOKAHEAD) cholesky_fused_lookahead<DC>(Zt, scratch, s, inv_l2, jitter + extra);
+    else cholesky_fused<DC>(Zt, scratch, s, inv_l2, jitter + extra);
+    const int bad = g_sh.chol_bad;  // both factorisations end with a workgroup barrier
+    if (!bad) return;               // the common case: one LDS read, no extra barrier
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      g_sh.chol_bad = 0;
+      if (attempt >= retries) g_sh.status = GAPRO_ERR_CHOLESKY;
+    }
+    __syncthreads();
+    if (attempt >= retries) return;
+    extra = psd_jitter * pow(10.0, (double)attempt);
   }
 }
 
@@ -1162,7 +1190,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   };
   auto factorize = [&]() {
     stamp(19);
-    cholesky_fused<DC>(Zt, scratch, sh.s, sh.inv_l2, jitter);
+    cholesky_psd_safe<DC, false>(Zt, scratch, sh.s, sh.inv_l2, jitter, opt.psd_retries, opt.psd_jitter);
     stamp(1);
     if (Mp <= 128)
       tri_inverse<8>(scratch);
@@ -1491,6 +1519,7 @@ __device__ inline void fit_setup(const gapro_fit_desc& desc, int D, const float*
     sh.rho_s = 0.0;
     sh.rho_l = 0.0;
     sh.status = GAPRO_OK;
+    sh.chol_bad = 0;
 #ifdef GAPRO_PROFILE
     for (int i = 0; i < kProfSlots; ++i) sh.prof[i] = 0;
     sh.t_last = wall_clock64();
@@ -1959,7 +1988,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   };
   auto factorize = [&]() {
     stamp(19);
-    cholesky_fused_lookahead<DC>(Zt, scratch, sh.s, sh.inv_l2, jitter);
+    cholesky_psd_safe<DC, true>(Zt, scratch, sh.s, sh.inv_l2, jitter, opt.psd_retries, opt.psd_jitter);
     stamp(1);
     tri_inverse_strip(scratch);
     __syncthreads();
@@ -2453,7 +2482,8 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   if (n_fits < 0 || feat_dim <= 0 || !d_feats_spp || !d_idx || !h_descs || !d_descs || !opt || !d_workspace ||
       !d_probs || !d_probs_new || !d_labels || !d_mu || !d_var || !d_fit_status || !d_fit_loss || workspace_bytes == 0)
     return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: bad argument");
-  if (opt->training_iter < 0 || !(opt->lr > 0.0) || !(opt->jitter >= 0.0))
+  if (opt->training_iter < 0 || !(opt->lr > 0.0) || !(opt->jitter >= 0.0) || opt->psd_retries < 0 ||
+      opt->psd_retries > 8 || !(opt->psd_jitter >= 0.0))
     return gapro_fail(ctx, GAPRO_ERR_BAD_ARG, "gapro_svgp_fit_batch: bad options");
   hipStream_t stream = (hipStream_t)stream_;
   // Routing (gapro_fit_route): strip-streaming kernel, LDS-staged kernel, generic kernel (working set beyond

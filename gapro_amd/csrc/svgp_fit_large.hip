@@ -217,7 +217,7 @@ __device__ __noinline__ void cholesky_blocked(const Fit& f, double* sh_d /* 16x1
       for (int j = 0; j < 16; ++j) {
         double d = sh_d[j * 17 + j];
         if (!(d > 0.0)) {  // not positive definite (or NaN): flag it, keep going with a tiny pivot
-          if (lane == 0) *sh_status = GAPRO_ERR_CHOLESKY;
+          if (lane == 0) *sh_status = 1;  // chol_bad: see factorize (psd_safe_cholesky retries)
           d = 1e-30;
         }
         d = sqrt(d);
@@ -460,6 +460,7 @@ struct Shared {
   double part[NT];
   double c, rho_s, rho_l, s, ell, inv_l2;
   int status;
+  int chol_bad;
 };
 
 template <int TU>
@@ -512,10 +513,26 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
   };
   auto factorize = [&]() {
     stamp(19);
-    build_kzz(f, sh.s, sh.inv_l2, jitter);
-    __syncthreads();
-    stamp(0);
-    cholesky_blocked(f, sh.dblk, sh.dinv, &sh.status);
+    // psd_safe_cholesky of gpytorch: repeat on K + psd_jitter 10^i I (i < psd_retries) before giving up; see the
+    // comment at GAPRO_PSD_SAFE_CHOLESKY in svgp_fit.hip
+    double extra = 0.0;
+    for (int attempt = 0;; ++attempt) {
+      build_kzz(f, sh.s, sh.inv_l2, jitter + extra);
+      __syncthreads();
+      stamp(0);
+      cholesky_blocked(f, sh.dblk, sh.dinv, &sh.chol_bad);
+      __syncthreads();
+      const int bad = sh.chol_bad;
+      __syncthreads();
+      if (!bad) break;
+      if (threadIdx.x == 0) {
+        sh.chol_bad = 0;
+        if (attempt >= opt.psd_retries) sh.status = GAPRO_ERR_CHOLESKY;
+      }
+      __syncthreads();
+      if (attempt >= opt.psd_retries) break;
+      extra = opt.psd_jitter * pow(10.0, (double)attempt);
+    }
     stamp(1);
     tri_inverse(f);
     __syncthreads();
@@ -805,6 +822,7 @@ __global__ __launch_bounds__(NT) void k_svgp_fit_large(int n_fits, int D, const 
     sh.rho_s = 0.0;
     sh.rho_l = 0.0;
     sh.status = GAPRO_OK;
+    sh.chol_bad = 0;
 #ifdef GAPRO_PROFILE
     for (int i = 0; i < kProfSlots; ++i) sh.prof[i] = 0;
     sh.t_last = wall_clock64();

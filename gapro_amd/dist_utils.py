@@ -21,6 +21,72 @@ def shard_scenes(filenames: Sequence[str], rank: int, world: int) -> List[str]:
     return list(sorted(filenames))[rank::world]
 
 
+def scene_cost(filename: str) -> float:
+    """Predicted cost of a scene before it is loaded.  The GP fits dominate (sum over pairs of M^3, M = training
+    superpoints of a pair ~ points per object ~ N / K), and the only thing known without reading the file is its
+    size, which is proportional to the point count N: cost ~ N^2 tracks the measured per-scene time of the synthetic
+    stream (N^3 / K^2 summed over ~K pairs) much better than N or a scene count.  Missing file -> 0."""
+    try:
+        return float(os.path.getsize(filename)) ** 2
+    except OSError:
+        return 0.0
+
+
+def shard_scenes_lpt(filenames: Sequence[str], rank: int, world: int, costs: Sequence[float] = None) -> List[str]:
+    """Longest-processing-time-first shard: scenes sorted by decreasing predicted cost (ties by name) are dealt one by
+    one to the rank with the least cost so far.  Deterministic, so every rank computes the same partition by itself;
+    every scene belongs to exactly one rank.  The rank's scenes come back largest first, which also keeps the tail
+    of its last batch short.  Reference behaviour being sharded: the serial scene loop of gapro/gen_ps.py:36-41."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    names = list(sorted(filenames))
+    c = [scene_cost(f) for f in names] if costs is None else [float(v) for v in costs]
+    if costs is not None and len(c) != len(names):
+        raise ValueError("one cost per scene")
+    if costs is not None:  # costs were given in the caller's order
+        by_name = dict(zip(filenames, c))
+        c = [by_name[f] for f in names]
+    order = sorted(range(len(names)), key=lambda i: (-c[i], names[i]))
+    load = [0.0] * world
+    mine = []
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += max(c[i], 1e-30)
+        if r == rank:
+            mine.append(names[i])
+    return mine
+
+
+class ClaimQueue:
+    """Shared work queue over the scene list for the workers of ONE node, without a server: a worker claims a scene
+    by creating `<claim_dir>/<scan>.claim` with O_CREAT | O_EXCL (atomic on a local file system), in the common
+    cost-sorted order, so the expensive scenes start first and a fast worker simply claims more.  A claim directory
+    belongs to one job: the parent creates a fresh one per run and removes it at the end; skip-if-exists on the
+    OUTPUT files is what makes a restarted job redo nothing (reference gen_ps.py:39-41)."""
+
+    def __init__(self, filenames: Sequence[str], claim_dir: str, costs: Sequence[float] = None):
+        names = list(sorted(filenames))
+        c = [scene_cost(f) for f in names] if costs is None else [dict(zip(filenames, costs))[f] for f in names]
+        self.order = [names[i] for i in sorted(range(len(names)), key=lambda i: (-c[i], names[i]))]
+        self.claim_dir = claim_dir
+        self.pos = 0
+        os.makedirs(claim_dir, exist_ok=True)
+
+    def claim(self, n: int) -> List[str]:
+        """Up to n scenes nobody has claimed yet (empty list: the queue is drained)."""
+        got = []
+        while len(got) < n and self.pos < len(self.order):
+            fn = self.order[self.pos]
+            self.pos += 1
+            path = os.path.join(self.claim_dir, fn.split("/")[-1][:12] + ".claim")
+            try:
+                os.close(os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+            except FileExistsError:
+                continue
+            got.append(fn)
+        return got
+
+
 def pending_scenes(filenames: Sequence[str], save_folder: str) -> List[str]:
     """Scenes whose output file does not exist yet (reference gen_ps.py:37-41: scan name = first 12 chars)."""
     out = []

@@ -15,13 +15,16 @@ from .gen_ps_utils import _pick_device, _pipeline
 
 
 def fit_gp_spp_batch(feats_spp, problems, training_iter=50, init_mean=None, device=None, keep_debug=False,
-                     **pipe_kw):
+                     return_status=False, **pipe_kw):
     """Fit many independent GPs in one launch.
 
     feats_spp  f32[S,D] (torch or numpy); problems = list of (b1_inds, b2_inds, intersect_inds).
     init_mean  optional list of per-problem initial variational means (length m1+m2 each).
     Returns a list of 5-tuples of numpy arrays in the reference's order, plus (if keep_debug) the raw
-    result dict as a second value.
+    result dict as a second value.  A fit that fails (non-finite input, K_ZZ not positive definite after the
+    jitter retries of gpytorch's psd_safe_cholesky) raises GaproError, as gpytorch raises there; with
+    ``return_status=True`` nothing is raised and the per-fit gapro_status array (0 = ok) comes back as the last
+    value: a failed fit does not affect the other fits of the launch.
     """
     dev = _pick_device(feats_spp, device)
     pipe = _pipeline(dev, training_iter, **pipe_kw)
@@ -49,12 +52,15 @@ def fit_gp_spp_batch(feats_spp, problems, training_iter=50, init_mean=None, devi
         oo += len(it)
     h_idx = np.ascontiguousarray(np.concatenate(idx)) if idx else np.zeros(1, np.int32)
     h_init = np.concatenate(init) if init else None
-    res = pipe.fit_descs(f, descs, n, h_idx, oo, init_mean=h_init, keep_debug=keep_debug)
+    res = pipe.fit_descs(f, descs, n, h_idx, oo, init_mean=h_init, keep_debug=keep_debug,
+                         raise_on_failure=not return_status)
     outs = []
     for i in range(n):
         a, b = descs[i].out_offset, descs[i].out_offset + descs[i].t
         outs.append((res["probs"][a:b], res["probs_new"][a:b], res["labels"][a:b].astype(bool), res["mu"][a:b],
                      res["var"][a:b]))
+    if return_status:
+        return (outs, res, res["status"]) if keep_debug else (outs, res["status"])
     return (outs, res) if keep_debug else outs
 
 

@@ -10,8 +10,14 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
 
     --data_root DIR        dataset root (default dataset/scannetv2, the reference's relative path)
     --split train|val      which scene list (reference: train)
-    --devices 0,1,..       one worker process per listed GPU; scenes are dealt round-robin over the
-                           workers (independent scenes, no collective); default: this process, cuda:0
+    --devices 0,1,..       one worker process per listed GPU (independent scenes, no collective); default: this
+                           process, cuda:0
+    --farm queue|lpt|roundrobin
+                           how the workers share the scene list.  queue (default with several devices): a shared
+                           work queue -- every worker claims its next batch from the common cost-sorted list
+                           (largest file first) through O_EXCL claim files under <save_folder>/.claims.*, so a fast
+                           GPU takes more; lpt: static longest-processing-time-first partition by file size;
+                           roundrobin: rank r takes scenes r, r+world, .. of the sorted list
     --batch_scenes B       scenes whose GP fits share one launch (default 32)
     --init_mean_std S      std of the random initial variational mean (gpytorch: 1e-3 unseeded;
                            default 0 = deterministic), --seed seeds it
@@ -25,13 +31,16 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
 
 Differences from the reference, on purpose: output files are written atomically (tmp + rename); a scene
 that fails to load is reported and skipped instead of killing the run; a scene without instances (the
-reference crashes unpacking None, gen_ps_utils.py:229-230 / gen_ps.py:72) is skipped; batches are
+reference crashes unpacking None, gen_ps_utils.py:229-230 / gen_ps.py:72) is skipped; a scene with a
+non-finite coordinate / feature or a GP fit that stays non-positive-definite after the jitter retries is
+reported and skipped while the other scenes of its batch are written; batches are
 software-pipelined (the partition of batch i+1 and the merge of batch i-1 run around the GP fits of batch i).
 """
 from __future__ import annotations
 
 import argparse
 import os
+import zlib
 import os.path as osp
 import sys
 import time
@@ -40,7 +49,7 @@ from glob import glob
 import numpy as np
 import torch
 
-from .dist_utils import pending_scenes, shard_scenes
+from .dist_utils import ClaimQueue, pending_scenes, shard_scenes, shard_scenes_lpt
 from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device
 from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
@@ -215,11 +224,26 @@ def run_worker(filenames, args, device_index):
 
         procs = mp.get_context("spawn").Pool(n_procs, initializer=_loader_init)
     pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
+    pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest of its batch is written
     dev = pipe.device
     done = failed = 0
     t0 = time.time()
-    pending = pending_scenes(filenames, args.save_folder)  # :39-41
-    chunks = [pending[i:i + args.batch_scenes] for i in range(0, len(pending), args.batch_scenes)]
+    queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
+
+    def chunk_iter():
+        """Batches of scenes still to do (:39-41): from the shared queue, or this worker's static shard."""
+        if queue is not None:
+            while True:
+                got = queue.claim(args.batch_scenes)
+                if not got:
+                    return
+                got = pending_scenes(got, args.save_folder)
+                if got:
+                    yield got
+        else:
+            pending = pending_scenes(filenames, args.save_folder)
+            for i in range(0, len(pending), args.batch_scenes):
+                yield pending[i:i + args.batch_scenes]
     pool = cf.ThreadPoolExecutor(max_workers=max(1, args.loader_threads))
     meta = []  # per yielded batch: (scenes, jobs)
     read_args = (args.data_root, args.use_deepfeat, args.deepfeat_folder)
@@ -271,11 +295,17 @@ def run_worker(filenames, args, device_index):
 
     def batches():
         nonlocal failed
-        ahead = [submit(c) for c in chunks[:2]]  # the disk reads of two batches are in flight
-        for k in range(len(chunks)):
+        chunks = chunk_iter()
+        ahead = []
+        for _ in range(2):  # the disk reads of two batches are in flight
+            c = next(chunks, None)
+            if c:
+                ahead.append(submit(c))
+        while ahead:
             futs = ahead.pop(0)
-            if k + 2 < len(chunks):
-                ahead.append(submit(chunks[k + 2]))
+            c = next(chunks, None)
+            if c:
+                ahead.append(submit(c))
             scenes = []
             for fn, fut in futs:
                 try:
@@ -293,7 +323,8 @@ def run_worker(filenames, args, device_index):
             t = time.time()
             jobs = [make_job(s["coords_float"], s["mask_feats"], s["spp"], s["instance_cls"], s["instance_box"],
                              s["instance_box_volume"], s["wall_box"], s["wall_box_volume"],
-                             instance_classes=18, ground_h=0.1, thresh_spp_occu=0.999, device=dev)  # :106-110
+                             instance_classes=18, ground_h=0.1, thresh_spp_occu=0.999, device=dev,  # :106-110
+                             scene_key=zlib.crc32(s["scan_name"].encode()))
                     for s in scenes]
             spent["jobs"] += time.time() - t
             meta.append((scenes, jobs))
@@ -305,6 +336,10 @@ def run_worker(filenames, args, device_index):
         t_exp = time.time()
         ready = torch.cuda.current_stream(dev).record_event()  # run_stream ordered the outputs on this stream
         for s, job, o in zip(scenes, jobs, outs):
+            if o is None:  # Pipeline.strict = False: this scene could not be processed, the others could
+                print("[gen_ps] warning: %s skipped: %s" % (s["scan_name"], job.error), file=sys.stderr)
+                failed += 1
+                continue
             if args.eval_pslabel:
                 from .eval_ps_labels import get_miou_scene
 
@@ -323,12 +358,14 @@ def run_worker(filenames, args, device_index):
                 writes.append(pool.submit(save_scene, path, host, inv, args.broadcast_mu_var))
             done += 1
         spent["export"] += time.time() - t_exp
-    for w in writes:
-        w.result().get() if procs is not None else w.result()
-    pool.shutdown()
-    if procs is not None:
-        procs.close()
-        procs.join()
+    try:
+        for w in writes:
+            w.result().get() if procs is not None else w.result()
+    finally:  # queued writes are flushed and the loader processes released whatever happened above
+        pool.shutdown()
+        if procs is not None:
+            procs.close()
+            procs.join()
     dt = time.time() - t0
     print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)"
           % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0))
@@ -353,7 +390,9 @@ def main(argv=None):
     parser.add_argument("--broadcast_mu_var", action="store_true")
     parser.add_argument("--loader_threads", type=int, default=4)
     parser.add_argument("--loader_procs", type=int, default=-1)
+    parser.add_argument("--farm", type=str, default="queue", choices=["queue", "lpt", "roundrobin"])
     parser.add_argument("--worker_rank", type=int, default=-1, help=argparse.SUPPRESS)
+    parser.add_argument("--claim_dir", type=str, default=None, help=argparse.SUPPRESS)
     args = parser.parse_args(argv)
 
     os.makedirs(args.save_folder, exist_ok=True)
@@ -361,17 +400,34 @@ def main(argv=None):
     devices = [int(d) for d in args.devices.split(",") if d != ""]
     if args.worker_rank >= 0 or len(devices) == 1:
         r = max(args.worker_rank, 0)
-        mine = shard_scenes(filenames, r, len(devices))  # independent scenes: round-robin shard, no collective
+        # independent scenes, no collective: the shared queue hands out the common list; the static farms shard it
+        if args.claim_dir or len(devices) == 1:
+            mine = filenames
+        elif args.farm == "roundrobin":
+            mine = shard_scenes(filenames, r, len(devices))
+        else:  # "lpt", or "queue" without a claim directory (a worker started by hand)
+            mine = shard_scenes_lpt(filenames, r, len(devices))
         run_worker(mine, args, devices[r])
     else:
+        import shutil
         import subprocess
 
+        extra = []
+        claim_dir = None
+        if args.farm == "queue":  # a fresh claim directory per job; the OUTPUT files are what a restart skips
+            claim_dir = osp.join(args.save_folder, ".claims.%d.%d" % (os.getpid(), int(time.time())))
+            os.makedirs(claim_dir)
+            extra = ["--claim_dir", claim_dir]
         procs = []
-        for r in range(len(devices)):
-            cmd = [sys.executable, "-m", "gapro_amd.gen_ps"] + (argv if argv is not None else sys.argv[1:]) + \
-                  ["--worker_rank", str(r)]
-            procs.append(subprocess.Popen(cmd))
-        rc = [p.wait() for p in procs]
+        try:
+            for r in range(len(devices)):
+                cmd = [sys.executable, "-m", "gapro_amd.gen_ps"] + (argv if argv is not None else sys.argv[1:]) + \
+                      ["--worker_rank", str(r)] + extra
+                procs.append(subprocess.Popen(cmd))
+            rc = [p.wait() for p in procs]
+        finally:
+            if claim_dir is not None:
+                shutil.rmtree(claim_dir, ignore_errors=True)
         if any(rc):
             raise SystemExit("a worker failed: %r" % rc)
     print("Finish")

@@ -95,6 +95,8 @@ class SceneJob:
     fit_base: int = 0
     out_base: int = 0
     outputs: Optional[tuple] = None
+    error: Optional[Exception] = None  # why the scene could not be processed (Pipeline.strict = False)
+    scene_key: int = 0  # stable id of the scene (e.g. crc32 of the scan name): seeds the optional initial-mean noise
 
     @property
     def spp_inv(self):
@@ -111,7 +113,8 @@ class SceneJob:
 
 
 def make_job(coords_float, mask_feats, spp, instance_cls, instance_box, instance_box_volume, wall_box,
-             wall_box_volume, instance_classes=18, ground_h=0.1, thresh_spp_occu=0.8, device=None) -> SceneJob:
+             wall_box_volume, instance_classes=18, ground_h=0.1, thresh_spp_occu=0.8, device=None,
+             scene_key: int = 0) -> SceneJob:
     device = torch.device(device if device is not None else "cuda:0")
 
     def dev(x, dtype):
@@ -131,7 +134,7 @@ def make_job(coords_float, mask_feats, spp, instance_cls, instance_box, instance
                     _to_np(instance_box_volume, np.float32).reshape(-1),
                     _to_np(wall_box, np.float32).reshape(-1, 6) if has_wall else np.zeros((0, 6), np.float32),
                     _to_np(wall_box_volume, np.float32).reshape(-1) if has_wall else np.zeros((0,), np.float32),
-                    int(instance_classes), float(ground_h), float(thresh_spp_occu))
+                    int(instance_classes), float(ground_h), float(thresh_spp_occu), scene_key=int(scene_key))
 
 
 def _desc_table(descs, n_fits: int) -> np.ndarray:
@@ -196,11 +199,18 @@ class Pipeline:
         self.init_mean_std = float(init_mean_std)
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap
+        # strict: a scene that cannot be processed (non-finite input, id range beyond the rank table, a GP fit that
+        # fails after the jitter retries) raises, as the reference would.  The gen_ps driver clears it: the scene's
+        # outputs come back as None with job.error set, and the other scenes of the batch are unaffected.
+        self.strict = True
         self.last_stats = {}
         self.trace = None  # set to a list to collect (time, batch id, stage) host timestamps
         # optional HIP-event timing of the fit launches (bench.py): list of (start_event, end_event, flops)
         self.profile_fit = False
         self.fit_events = []
+        # with profile_fit: torch events (current stream = the stream the kernels are launched on) around the batched
+        # partition calls: dicts with 'prepare', 'pool', 'broadcast' -> (start, end) and the points they cover
+        self.part_events = []
         self.profile_stages = False  # bench.py --stage-times: synchronising per-stage wall clock
         self.stage_times = {}
         self._pin_cache = {}
@@ -228,11 +238,29 @@ class Pipeline:
             tot += (int(sz) + align - 1) // align * align
         return offs, max(tot, align)
 
+    def _part_event(self, jobs, name):
+        if not self.profile_fit:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        return dict(name=name, start=e0, points=sum(j.n_points for j in jobs), feat_dim=int(jobs[0].feats.shape[1]))
+
+    def _part_event_end(self, ev):
+        if ev is not None:
+            ev["end"] = torch.cuda.Event(enable_timing=True)
+            ev["end"].record(torch.cuda.current_stream(self.device))
+            self.part_events.append(ev)
+
     # ------------------------------------------------------------------ stage A
     def _prepare_finish(self, job: SceneJob, hdr: SceneHeader):
         if hdr.status != 0:
-            raise _lib.GaproError(int(hdr.status), "superpoint id range [%d, %d] exceeds the rank table (%d slots)"
-                                  % (hdr.spp_min, hdr.spp_max, job.host["range_cap"]))
+            msg = "scene has a non-finite coordinate or feature" if hdr.status == _lib.GAPRO_ERR_NOT_FINITE else \
+                "superpoint id range [%d, %d] exceeds the rank table (%d slots)" % (hdr.spp_min, hdr.spp_max,
+                                                                                    job.host["range_cap"])
+            job.error = _lib.GaproError(int(hdr.status), msg)
+            if self.strict:
+                raise job.error
+            return
         job.header = hdr
         job.n_spps = int(hdr.n_spps)
         job.dev.pop("prep_ws", None)
@@ -277,13 +305,22 @@ class Pipeline:
             t.spp_inv = job.dev.spec("spp_inv", spp_inv_all, io, 4 * job.n_points, torch.int32, (job.n_points,))
             dict.__setitem__(job.host, "range_cap", cap)
             t.prepare_ws, t.spp_range_cap = prep_ws.data_ptr() + wo, cap
+        ev = self._part_event(jobs, "prepare")
         self.ctx.check(lib.gapro_partition_prepare_batch(
             self.ctx.handle, _stream_handle(devc), len(jobs), D, C.cast(tasks, C.c_void_p), _ptr(d_tasks),
             _ptr(d_headers), _ptr(pinned)))
+        self._part_event_end(ev)
         torch.cuda.current_stream(devc).synchronize()  # one sync for the whole batch
         raw = pinned.numpy()
         for i, job in enumerate(jobs):
             self._prepare_finish(job, SceneHeader.from_buffer_copy(raw[i * hsz:(i + 1) * hsz].tobytes()))
+        good = [i for i, job in enumerate(jobs) if job.error is None]
+        if len(good) != len(jobs):  # non-strict: the rejected scenes leave the batch here
+            tasks2 = (SceneTask * max(len(good), 1))()
+            for k, i in enumerate(good):
+                tasks2[k] = tasks[i]
+            tasks = tasks2
+            d_tasks = torch.empty(max(len(good), 1) * C.sizeof(SceneTask), dtype=torch.uint8, device=devc)
         return tasks, d_tasks
 
     # ------------------------------------------------------------------ stage B
@@ -339,8 +376,10 @@ class Pipeline:
             h = job.host
             h.spec("occ_bits_pin", stage, to, 8 * S * W, torch.int64, (S, W))
             h.spec("n_bbs_pin", stage, to + 8 * S * W, 4 * S, torch.int32, (S,))
+        ev = self._part_event(jobs, "pool")
         self.ctx.check(lib.gapro_partition_pool_batch(self.ctx.handle, _stream_handle(devc), len(jobs), D,
                                                       C.cast(tasks, C.c_void_p), _ptr(d_tasks)))
+        self._part_event_end(ev)
         stage[:tab_tot].copy_(d_tables, non_blocking=True)
 
     # ------------------------------------------------------------------ stage C
@@ -424,13 +463,16 @@ class Pipeline:
             with torch.cuda.stream(self._streams[i % 2]):
                 return fn(*a)
 
-        cur = next(it, None)
+        # a batch is pulled from the iterator under the pipeline stream that will process it (batch k -> stream
+        # k % 2): whatever device work building its jobs enqueues (a dtype cast, .contiguous() of a strided input in
+        # make_job) is then ordered before its partition kernels, for every batch and not only the first
+        cur = on(0, next, it, None)
         if cur is None:
             return
         i = 0
         cur_state = on(0, self._partition, cur, False)
         on(0, self._schedule_all, cur_state)
-        nxt = next(it, None)
+        nxt = on(1, next, it, None)
         prev_state = None
         while cur_state is not None:
             nxt_state = on(i + 1, self._partition, nxt, False) if nxt is not None else None
@@ -438,7 +480,7 @@ class Pipeline:
             # everything below is host work that runs while the fit just launched occupies the GPU: fetching the
             # batch after next from the iterator (building jobs, reading / uploading scenes), the schedule of the
             # next batch, the merge of the previous one
-            nxt = next(it, None) if nxt is not None else None
+            nxt = on(i, next, it, None) if nxt is not None else None  # batch i + 2 -> stream i % 2
             if nxt_state is not None:
                 on(i + 1, self._schedule_all, nxt_state)
             if prev_state is not None:
@@ -484,8 +526,13 @@ class Pipeline:
         stream = torch.cuda.current_stream(devc)
         slot = "s%x" % int(stream.cuda_stream)
         _mark("start")
+        all_jobs = list(jobs)
         tasks, d_tasks = self._prepare_all(jobs)
+        jobs = [j for j in all_jobs if j.error is None]
         _mark("A prepare")
+        if not jobs:
+            return dict(jobs=[], all_jobs=all_jobs, stream=stream, keep_debug=keep_debug, mark=_mark, slot=slot,
+                        pending=None, n_fits=0, n_out=0, tasks=tasks, d_tasks=d_tasks, feats_spp_all=None)
         D = int(jobs[0].feats.shape[1])
         base = 0
         for job in jobs:
@@ -500,13 +547,15 @@ class Pipeline:
         self._pool_all(jobs, tasks, d_tasks, feats_spp_all, stage)
         stream.synchronize()  # one sync: pooled tables of every scene are on the host
         _mark("B pool")
-        return dict(jobs=jobs, stream=stream, keep_debug=keep_debug, mark=_mark, feats_spp_all=feats_spp_all,
-                    slot=slot, pending=None, n_fits=0, n_out=0, tasks=tasks, d_tasks=d_tasks)
+        return dict(jobs=jobs, all_jobs=all_jobs, stream=stream, keep_debug=keep_debug, mark=_mark,
+                    feats_spp_all=feats_spp_all, slot=slot, pending=None, n_fits=0, n_out=0, tasks=tasks, d_tasks=d_tasks)
 
     def _schedule_all(self, state):
         """Stage C (host only): static pair schedule of every scene, fit descriptors of the whole batch."""
         lib = self.lib
         jobs, _mark = state["jobs"], state["mark"]
+        if not jobs:
+            return
         for job in jobs:
             self._schedule(job)
         _mark("C schedule")
@@ -534,7 +583,8 @@ class Pipeline:
         """Stage D: one (asynchronous) launch for every fit of every scene."""
         if state["n_fits"]:
             state["pending"] = self.fit_launch(state["feats_spp_all"], state["descs"], state["n_fits"], state["h_idx"],
-                                               state["n_out"], keep_debug=state["keep_debug"], slot=state["slot"])
+                                               state["n_out"], keep_debug=state["keep_debug"], slot=state["slot"],
+                                               scene_keys=[j.scene_key for j in state["jobs"]])
         state["mark"]("D launched")
 
     def _finish(self, state, sync: bool = True):
@@ -543,8 +593,21 @@ class Pipeline:
         lib, ctx, devc = self.lib, self.ctx, self.device
         jobs, keep_debug, _mark = state["jobs"], state["keep_debug"], state["mark"]
         _mark("finish")
-        res = self.fit_collect(state["pending"]) if state["pending"] is not None else None
+        if not jobs:  # every scene of the batch was rejected (non-strict mode)
+            self.last_stats = dict(n_fits=0, n_fit_out=0, fit=None)
+            return [None for _ in state["all_jobs"]]
+        res = self.fit_collect(state["pending"], raise_on_failure=False) if state["pending"] is not None else None
         _mark("D fit")
+        if res is not None and (res["status"] != 0).any():
+            # per-fit status -> per-scene failure: only the scenes that own a failed fit are lost
+            for job in jobs:
+                st = res["status"][job.fit_base:job.fit_base + job.counts.n_fits]
+                if (st != 0).any():
+                    k = int(np.nonzero(st)[0][0])
+                    job.error = _lib.GaproError(int(st[k]), "GP fit %d of %d of the scene failed (%d failed in all)"
+                                                % (k, job.counts.n_fits, int((st != 0).sum())))
+            if self.strict:
+                raise next(j.error for j in jobs if j.error is not None)
         tot_s = sum(job.n_spps for job in jobs)
         tables = self._pinned(state["slot"] + "labels", tot_s * 20)
         busy = self._pin_events.pop(state["slot"] + "labels", None)
@@ -593,31 +656,45 @@ class Pipeline:
             if not keep_debug:
                 lib.gapro_schedule_free(job.schedule)
                 job.schedule = None
+        ev = self._part_event(jobs, "broadcast")
         ctx.check(lib.gapro_broadcast_labels_batch(ctx.handle, _stream_handle(devc), len(jobs),
                                                    C.cast(tasks, C.c_void_p), _ptr(d_tasks)))
+        self._part_event_end(ev)
         # the task array must outlive the (possibly delayed) upload enqueued above
         self._keep[state["slot"]] = (tasks, d_tasks)
         if sync:
             torch.cuda.current_stream(devc).synchronize()
         _mark("E+F merge/broadcast")
         self.last_stats = dict(n_fits=state["n_fits"], n_fit_out=state["n_out"], fit=res)
-        return [j.outputs for j in jobs]
+        for j in jobs:
+            if j.error is not None:  # merged from a failed fit's garbage: not a result
+                j.outputs = None
+        return [j.outputs if j.error is None else None for j in state["all_jobs"]]
 
     # ------------------------------------------------------------------ stage D
     def fit_descs(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
-                  init_mean: Optional[np.ndarray] = None, keep_debug: bool = False):
+                  init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, raise_on_failure: bool = True):
         """Launch a batch of fits and wait for the results (numpy arrays)."""
-        return self.fit_collect(self.fit_launch(feats_spp, descs, n_fits, h_idx, n_out, init_mean, keep_debug))
+        return self.fit_collect(self.fit_launch(feats_spp, descs, n_fits, h_idx, n_out, init_mean, keep_debug),
+                                raise_on_failure)
 
     def fit_launch(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
-                   init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, slot: str = "s0"):
+                   init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, slot: str = "s0",
+                   scene_keys: Optional[Sequence[int]] = None):
         lib, ctx, devc = self.lib, self.ctx, self.device
         D = int(feats_spp.shape[1])
         ws_bytes = int(lib.gapro_fit_plan_workspace(C.cast(descs, C.c_void_p), n_fits, D))
         if init_mean is None and self.init_mean_std > 0.0:
-            # gpytorch: variational mean <- 0 + mean_init_std * randn on first call (SURVEY B.1, Q1)
-            rng = np.random.default_rng(self.seed)
-            init_mean = self.init_mean_std * rng.standard_normal(len(h_idx))
+            # gpytorch: variational mean <- 0 + mean_init_std * randn on first call (SURVEY B.1, Q1).  The noise of a
+            # fit is a function of (seed, scene key, box pair) only, so a scene's result depends neither on the
+            # batch it travels in nor on its position there, and a resumed run reproduces it.
+            init_mean = np.zeros(len(h_idx))
+            for k in range(n_fits):
+                d = descs[k]
+                key = int(scene_keys[d.scene]) if scene_keys is not None else int(d.scene)
+                rng = np.random.default_rng([self.seed, key & 0xFFFFFFFF, int(d.b1), int(d.b2)])
+                m = int(d.m1 + d.m2)
+                init_mean[d.idx_offset:d.idx_offset + m] = self.init_mean_std * rng.standard_normal(m)
         d_descs = torch.empty(n_fits * C.sizeof(FitDesc), dtype=torch.uint8, device=devc)
         d_idx = torch.from_numpy(h_idx).to(devc)
         d_init = torch.from_numpy(np.ascontiguousarray(init_mean, dtype=np.float64)).to(devc) \
@@ -669,13 +746,16 @@ class Pipeline:
         return dict(done=done, h_out=h_out, h_stat=h_stat, no=no, n_fits=n_fits, ws_bytes=ws_bytes, keep=keep,
                     ws=ws if keep_debug else None, descs=descs if keep_debug else None)
 
-    def fit_collect(self, p):
+    def fit_collect(self, p, raise_on_failure: bool = True):
+        """Results of a launch.  The library reports a gapro_status per fit and never fails the batch; with
+        raise_on_failure (the fit_gp_spp API: gpytorch raises NotPSDError / NanError there) the first failed fit
+        raises, otherwise the caller reads res["status"]."""
         p["done"].synchronize()
         no, n_fits = p["no"], p["n_fits"]
         raw = p["h_out"].numpy()
         st_raw = p["h_stat"].numpy()
         st = st_raw[8 * n_fits:12 * n_fits].view(np.int32).copy()
-        if (st != 0).any():
+        if raise_on_failure and (st != 0).any():
             bad = int(np.nonzero(st)[0][0])
             raise _lib.GaproError(int(st[bad]), "fit %d of %d failed" % (bad, n_fits))
         res = dict(probs=raw[0:4 * no].view(np.float32).copy(), probs_new=raw[4 * no:8 * no].view(np.float32).copy(),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GAPRO_VERSION 100 /* 0.1.0 */
+#define GAPRO_VERSION 200 /* 0.2.0 */
 
 typedef enum {
   GAPRO_OK = 0,
@@ -312,7 +312,20 @@ typedef struct {
   int32_t reserved;          /* 0; debug bits: 1 = never route a fit to the strip-streaming kernels,
                               * 2 = launch the fit kernels on the caller's stream (not the fit streams),
                               * 4 = no small-fit kernel (M_p <= 64 runs the 512-thread strip kernel) */
+  int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive
+                              *      pivot is repeated on K + psd_jitter 10^i I, i < psd_retries (psd_safe_cholesky,
+                              *      reached from gaussian_process_utils.py:417); 0 = fail at once */
+  int32_t precision;         /* GAPRO_PRECISION_*: arithmetic of the fit (0 = float64 throughout, the default) */
+  double psd_jitter;         /* 1e-8 gpytorch settings.cholesky_jitter for float64 (K_ZZ is factored in double) */
 } gapro_fit_options;
+
+/* gapro_fit_options.precision */
+enum {
+  GAPRO_PRECISION_F64 = 0,   /* everything in float64 (a superset of the reference's split) */
+  GAPRO_PRECISION_MIXED = 1  /* the reference's own split: parameters, kernel matrices, A, B, variances and their
+                              * gradients in float32 (v_mfma_f32), float64 for the Cholesky factor, the L^-1
+                              * products and their backward (gpytorch _cholesky_factor / torch autograd) */
+};
 
 void gapro_fit_options_default(gapro_fit_options* opt);
 
@@ -372,6 +385,12 @@ int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream, const double* d_P, const d
  * partial sum per wave into d_dst[0..4095]; mode 1: copy n doubles. */
 int gapro_debug_stream(gapro_ctx* ctx, void* stream, int64_t n, const double* d_src, double* d_dst,
                        int32_t mode);
+/* Matrix-core peak of this device, measured: every CU runs waves_per_simd waves per SIMD, each a loop of
+ * `iters` x 8 independent 16x16x4 MFMA chains with no memory traffic (kind 0: v_mfma_f64_16x16x4_f64,
+ * kind 1: v_mfma_f32_16x16x4_f32); timed with HIP events on `stream`, blocking.  d_sink: one device double.
+ * The roofline peak the fit kernels are priced against (the local guide has no FP64 row). */
+int gapro_debug_mfma_peak(gapro_ctx* ctx, void* stream, int32_t kind, int32_t iters, int32_t waves_per_simd,
+                          double* d_sink, double* out_tflops);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,27 @@ def _sigmoid(x):
 # ------------------------------------------------------------------------------------------
 # torch autograd restatement
 # ------------------------------------------------------------------------------------------
+PSD_JITTER, PSD_MAX_TRIES = 1e-8, 3  # gpytorch settings.cholesky_jitter (float64), settings.cholesky_max_tries
+
+
+def psd_safe_cholesky(A, jitter=PSD_JITTER, max_tries=PSD_MAX_TRIES):
+    """gpytorch.utils.cholesky.psd_safe_cholesky restated for one float64 matrix (torch): plain Cholesky first; on
+    failure the diagonal gets jitter * 10^i added (cumulatively replacing the previous amount), i < max_tries, then
+    NotPSDError (here RuntimeError).  Differentiable where it succeeds (the jitter is a constant)."""
+    import torch
+
+    L, info = torch.linalg.cholesky_ex(A)
+    if int(info) == 0:
+        return L
+    if torch.isnan(A).any():
+        raise RuntimeError("NanError: cholesky of a matrix with NaNs")
+    for i in range(max_tries):
+        L, info = torch.linalg.cholesky_ex(A + (jitter * 10.0 ** i) * torch.eye(A.shape[-1], dtype=A.dtype))
+        if int(info) == 0:
+            return L
+    raise RuntimeError("NotPSDError: not positive definite after adding jitter of %g" % (jitter * 10.0 ** (max_tries - 1)))
+
+
 def svgp_fit_predict_autograd(train_x, train_y, test_x, training_iter=50, dtype="f64", init_mean=None,
                               jitter=JITTER, eval_chol="fresh", lr=ADAM_LR, return_trace=False):
     import torch
@@ -80,7 +101,7 @@ def svgp_fit_predict_autograd(train_x, train_y, test_x, training_iter=50, dtype=
         ell = torch.nn.functional.softplus(rho_l)
         s = torch.nn.functional.softplus(rho_s)
         Kzz = s * torch.exp(-0.5 * sqdist(Z / ell, Z / ell)) + jitter * torch.eye(M, dtype=T)
-        return torch.linalg.cholesky(Kzz.double())  # _cholesky_factor: psd_safe_cholesky(K.double())
+        return psd_safe_cholesky(Kzz.double())  # _cholesky_factor: psd_safe_cholesky(K.double())
 
     def q_f(x, L):
         ell = torch.nn.functional.softplus(rho_l)
@@ -114,7 +135,8 @@ def svgp_fit_predict_autograd(train_x, train_y, test_x, training_iter=50, dtype=
     out = (mean.double().numpy(), var.double().numpy(), probs.double().numpy())
     if return_trace:
         state = dict(Z=Z.detach().double().numpy(), m=m.detach().double().numpy(),
-                     LS=LS.detach().double().numpy(), c=float(c), rho_s=float(rho_s), rho_l=float(rho_l),
+                     LS=LS.detach().double().numpy(), c=float(c.detach()), rho_s=float(rho_s.detach()),
+                     rho_l=float(rho_l.detach()),
                      loss=trace)
         return out, state
     return out

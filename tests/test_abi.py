@@ -21,14 +21,14 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
         assert n in _lib.SIGNATURES, "binding lacks " + n
-    assert lib.gapro_version() == 100
+    assert lib.gapro_version() == 200
 
 
 def test_struct_layouts_match_the_header():
     # sizes follow the C declarations (natural alignment)
     assert C.sizeof(_lib.SceneHeader) == 3 * 8 + 3 * 8 + 8 + 8 + 4 + 4 + 4 + 4
     assert C.sizeof(_lib.FitDesc) == 8 * 4 + 3 * 8
-    assert C.sizeof(_lib.FitOptions) == 40
+    assert C.sizeof(_lib.FitOptions) == 56  # i32 pad | lr, jitter, min_variance f64 | 4 x i32 | psd_jitter f64
     assert C.sizeof(_lib.SceneTask) == 176
     assert C.sizeof(_lib.ScheduleCounts) == 4 + 4 + 8 + 8 + 8 + 4 + 4
 
@@ -36,6 +36,8 @@ def test_struct_layouts_match_the_header():
 def test_fit_options_default_and_workspace_plan():
     opt = _lib.default_fit_options()
     assert (opt.training_iter, opt.lr, opt.jitter, opt.min_variance, opt.eval_stale_chol) == (50, 0.1, 1e-4, 1e-6, 0)
+    # gpytorch's psd_safe_cholesky: cholesky_max_tries = 3, cholesky_jitter(float64) = 1e-8; float64 arithmetic
+    assert (opt.psd_retries, opt.psd_jitter, opt.precision, opt.reserved) == (3, 1e-8, 0, 0)
     lib = _lib.load()
     descs = (_lib.FitDesc * 3)()
     for i, (m1, m2, t) in enumerate([(3, 4, 5), (40, 60, 20), (100, 120, 300)]):

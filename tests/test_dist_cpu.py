@@ -61,3 +61,88 @@ def test_two_rank_gloo_job(tmp_path):
     owners = {f: (out / f).read_text() for f in files if f != "scene0003_00.pth"}
     assert set(owners.values()) == {"0", "1"}
     assert pending_scenes(["train/scene%04d_00_inst_nostuff.pth" % i for i in range(11)], str(out)) == []
+
+
+def _bench(*argv, env=None, timeout=300):
+    e = dict(os.environ if env is None else env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if env is None:
+            e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True,
+                          text=True, env=e, timeout=timeout)
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment must start two ranks (round 1 parsed --gpus
+    and ran one rank): the control path of the N > 1 bench -- child torch.distributed.run, rendezvous on 127.0.0.1,
+    barrier + MAX over ranks, ONE JSON line from rank 0 -- driven here over gloo with the device pipeline stubbed
+    (--dry-run); ms_per_step is the slower rank's sleep."""
+    import json
+
+    res = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["steps"] == 3 and rec["value"] is None
+    assert rec["ms_per_step"] >= 4.0  # rank 1 sleeps 4 ms per step, rank 0 only 2: the MAX must win
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = _bench("--gpus", "2", "--dry-run", env=env)
+    assert res.returncode == 2 and "WORLD_SIZE=1" in res.stderr
+
+
+def test_lpt_shard_balances_predicted_cost_and_partitions_the_list():
+    import numpy as np
+
+    from gapro_amd.dist_utils import shard_scenes_lpt
+
+    rng = np.random.default_rng(3)
+    names = ["train/scene%04d_00_inst_nostuff.pth" % i for i in range(1201)]
+    # config 3's size distribution: N ~ logN(150k, 0.5) clipped, cost ~ N^2
+    cost = np.clip(150000 * np.exp(0.5 * rng.standard_normal(len(names))), 40000, 450000) ** 2
+    for world in (1, 2, 4, 8):
+        shards = [shard_scenes_lpt(names, r, world, costs=cost) for r in range(world)]
+        assert sorted(sum(shards, [])) == sorted(names)
+        by = dict(zip(names, cost))
+        loads = np.array([sum(by[f] for f in sh) for sh in shards])
+        assert loads.max() / loads.mean() < 1.001  # LPT on 1201 items: essentially perfect
+        rr = np.array([sum(by[f] for f in sorted(names)[r::world]) for r in range(world)])
+        assert loads.max() <= rr.max() + 1e-9  # never worse than the round-robin shard it replaces
+        if world > 1:
+            first = [by[sh[0]] for sh in shards]
+            assert min(first) >= np.sort(cost)[-world]  # every rank starts with one of the `world` largest scenes
+
+
+def test_claim_queue_hands_every_scene_to_exactly_one_worker(tmp_path):
+    """Two processes drain one ClaimQueue concurrently (O_EXCL claim files): disjoint, complete, cost-sorted."""
+    script = tmp_path / "claim.py"
+    script.write_text(textwrap.dedent("""
+        import json, sys, time
+        sys.path.insert(0, %r)
+        from gapro_amd.dist_utils import ClaimQueue
+        names = ["train/scene%%04d_00_inst_nostuff.pth" %% i for i in range(200)]
+        q = ClaimQueue(names, sys.argv[1], costs=[(i * 7919) %% 200 for i in range(200)])
+        got = []
+        while True:
+            c = q.claim(3)
+            if not c:
+                break
+            got += c
+            time.sleep(0.001)
+        print(json.dumps(got))
+    """) % ROOT)
+    cdir = str(tmp_path / "claims")
+    ps = [subprocess.Popen([sys.executable, str(script), cdir], stdout=subprocess.PIPE, text=True) for _ in range(2)]
+    import json
+
+    got = [json.loads(p.communicate(timeout=120)[0]) for p in ps]
+    assert all(p.returncode == 0 for p in ps)
+    assert len(got[0]) + len(got[1]) == 200 and not (set(got[0]) & set(got[1]))
+    assert min(len(got[0]), len(got[1])) > 0
+    cost = {"train/scene%04d_00_inst_nostuff.pth" % i: (i * 7919) % 200 for i in range(200)}
+    for g in got:  # each worker sees the common order: non-increasing cost
+        c = [cost[f] for f in g]
+        assert c == sorted(c, reverse=True)

@@ -165,3 +165,72 @@ def test_cli_loader_processes_write_the_same_files(tmp_path):
         for u, v in zip(x, y):
             assert u.dtype == v.dtype
             np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_cli_a_scene_with_a_nan_feature_is_skipped_and_the_rest_of_its_batch_is_written(tmp_path):
+    """One bad scene must not kill the run (the reference would propagate the NaN into every kernel
+    matrix of the scene and gpytorch would raise): 4 scenes in ONE batch, the second has a NaN colour -> 3 files, exit
+    code 0, one warning, and the 3 files equal those of a run without the bad scene."""
+    import subprocess
+    import sys
+
+    root, scenes = _dataset(tmp_path, 4)
+    bad = scenes[1]
+    fn = os.path.join(root, "train", bad.scan_name + "_inst_nostuff.pth")
+    xyz, rgb, sem, inst = torch.load(fn, weights_only=False)
+    rgb = rgb.copy()
+    rgb[123, 1] = np.nan
+    torch.save((xyz, rgb, sem, inst), fn)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = str(tmp_path / "a")
+    r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", a, "--data_root", root,
+                        "--batch_scenes", "4", "--loader_procs", "2"], cwd=repo, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(os.listdir(a)) == sorted(s.scan_name + ".pth" for s in scenes if s is not bad)
+    warn = [l for l in r.stderr.splitlines() if "warning" in l and bad.scan_name in l]
+    assert len(warn) == 1 and "NOT_FINITE" in warn[0], r.stderr[-2000:]
+    assert "3 scenes written, 1 skipped/failed" in r.stdout
+    os.remove(fn)  # the same run without the bad scene: identical files
+    b = str(tmp_path / "b")
+    r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", b, "--data_root", root,
+                        "--batch_scenes", "4", "--loader_procs", "2"], cwd=repo, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for s in scenes:
+        if s is bad:
+            continue
+        for u, v in zip(torch.load(os.path.join(a, s.scan_name + ".pth"), weights_only=False),
+                        torch.load(os.path.join(b, s.scan_name + ".pth"), weights_only=False)):
+            np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("farm", ["queue", "lpt"])
+def test_cli_two_workers_write_every_scene_exactly_once(tmp_path, farm):
+    """`--devices 0,0`: two worker processes (here on the one GPU of the test box; on a node one per GPU) share the
+    scene list through the claim queue / the static LPT shard.  Every scene is written exactly once and is
+    byte-for-byte the array content of a single-worker run; no claim directory is left behind."""
+    import subprocess
+    import sys
+
+    from gapro_amd import gen_ps
+
+    root, scenes = _dataset(tmp_path, 7)
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    gen_ps.main(["--save_folder", one, "--data_root", root, "--batch_scenes", "2"])
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", two, "--data_root", root,
+                        "--batch_scenes", "2", "--devices", "0,0", "--farm", farm, "--loader_procs", "0"], cwd=repo,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(os.listdir(two)) == sorted(s.scan_name + ".pth" for s in scenes)  # and no .claims.* directory
+    written = [int(l.split("device 0: ")[1].split(" scenes written")[0]) for l in r.stdout.splitlines()
+               if "scenes written" in l]
+    assert len(written) == 2 and sum(written) == len(scenes) and min(written) >= 1
+    for s in scenes:
+        for u, v in zip(torch.load(os.path.join(one, s.scan_name + ".pth"), weights_only=False),
+                        torch.load(os.path.join(two, s.scan_name + ".pth"), weights_only=False)):
+            assert u.dtype == v.dtype
+            np.testing.assert_array_equal(u, v)

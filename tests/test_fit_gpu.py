@@ -255,3 +255,92 @@ def test_small_fit_kernel_and_strip_kernel_agree():
             pipe.opt.reserved = old
         for x, y in zip(a, b):
             np.testing.assert_allclose(np.asarray(x, np.float64), np.asarray(y, np.float64), rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("m1,m2,t,route", [(20, 28, 12, 3), (40, 50, 33, 0), (90, 100, 40, 1), (120, 136, 25, 2)])
+def test_fit_matches_oracle_with_deep_features_on_every_route(m1, m2, t, route):
+    """D = 32 (--use_deepfeat) against the float64 oracle on each kernel: small-fit strip (3), 512-thread strip (0),
+    LDS-staged (1) and generic (2), 50 Adam steps, the tolerances of D = 6."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    assert _lib.load().gapro_fit_route(m1 + m2, 32) == route
+    feats, b1, b2, it = make_gp_problem(70 + m1, m1, m2, t, 32, std=0.3)
+    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=50)[0]
+    _compare(out, _oracle(feats, b1, b2, it, 50))
+
+
+def test_fit_status_is_per_fit_and_a_failed_fit_does_not_touch_its_neighbours():
+    """gapro_svgp_fit_batch reports a gapro_status per fit and never fails the batch: a fit with a NaN feature row is
+    flagged, the other fits of the same launch are bit-identical to a launch without it."""
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    parts, probs, base = [], [], 0
+    for i, (m1, m2, t) in enumerate([(10, 12, 5), (40, 30, 9), (70, 80, 11), (100, 90, 7)]):
+        f, b1, b2, it = make_gp_problem(600 + i, m1, m2, t, 6)
+        parts.append(f.copy())
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    clean = fit_gp_spp_batch(np.concatenate(parts), probs, training_iter=20)
+    parts[1][3, 2] = np.nan
+    outs, status = fit_gp_spp_batch(np.concatenate(parts), probs, training_iter=20, return_status=True)
+    assert status[1] in (-4, -5) and (np.delete(status, 1) == 0).all()
+    for i in (0, 2, 3):
+        for a, b in zip(outs[i], clean[i]):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_psd_safe_cholesky_jitter_retries():
+    """gpytorch's psd_safe_cholesky: K_ZZ with duplicated inducing points and no variational jitter is
+    singular, and whether a pivot of its factorisation comes out <= 0 is decided by the last bit.  Variations of the
+    problem are tried until one fails without retries (GAPRO_ERR_CHOLESKY for that fit ONLY, the clean neighbour of
+    the same launch is untouched); with the default retries (K + 1e-8 * 10^i I, i < 3) the same launch goes
+    through, and at zero training steps its predictive moments are the prior's, as the oracle's restatement of
+    the same rule gives them."""
+    import torch
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.gen_ps_utils import _pipeline
+    from gapro_amd.synth import make_gp_problem
+    from oracle import svgp_oracle as so
+
+    f2, c1, c2, ct = make_gp_problem(34, 20, 25, 4, 6)
+    pipe = _pipeline(torch.device("cuda", 0), 0)
+    old = (pipe.opt.jitter, pipe.opt.psd_retries)
+    found = None
+    try:
+        pipe.opt.jitter = 0.0
+        for seed in range(24):
+            feats, b1, b2, it = make_gp_problem(330 + seed, 12, 14, 6, 6)
+            feats = feats.copy()
+            for k in range(1, 5):  # five copies of one point, three of another
+                feats[b1[k]] = feats[b1[0]]
+            feats[b2[5]] = feats[b2[2]]
+            feats[b2[7]] = feats[b2[2]]
+            allf = np.concatenate([feats, f2])
+            off = len(feats)
+            launch = [(b1, b2, it), (c1 + off, c2 + off, ct + off)]
+            pipe.opt.psd_retries = 0
+            outs0, status0 = fit_gp_spp_batch(allf, launch, training_iter=0, return_status=True)
+            assert status0[1] == 0
+            if status0[0] == 0:
+                continue  # every pivot of this variation happened to round to a positive number
+            assert status0[0] == -5
+            pipe.opt.psd_retries = 3
+            outs, status = fit_gp_spp_batch(allf, launch, training_iter=0, return_status=True)
+            assert (status == 0).all()
+            for a, b in zip(outs0[1], outs[1]):
+                np.testing.assert_array_equal(a, b)
+            found = (feats, b1, b2, it, outs[0])
+            break
+    finally:
+        pipe.opt.jitter, pipe.opt.psd_retries = old
+    assert found is not None, "no variation produced a non-positive pivot"
+    feats, b1, b2, it, out = found
+    X = np.concatenate([feats[b1], feats[b2]]).astype(np.float64)
+    y = np.r_[-np.ones(len(b1)), np.ones(len(b2))]
+    mu_r, var_r, p_r = so.svgp_fit_predict_autograd(X, y, feats[it].astype(np.float64), 0, "f64", jitter=0.0)
+    np.testing.assert_allclose(out[3], mu_r, rtol=0, atol=1e-6)
+    # var = s + |L_S^T A|^2 - |A|^2 with L_S = I cancels only up to the conditioning of the near-singular factor
+    np.testing.assert_allclose(out[4], var_r, rtol=1e-3)

@@ -1,0 +1,110 @@
+"""The float64 GP oracle, frozen and cross-checked (CPU), and the HIP kernels against the frozen vectors (GPU).
+
+PARITY UNPINNED: gpytorch cannot be run here, so these tests pin the oracle -- the target the
+kernels are held to -- not gpytorch itself.  (1) tests/golden/svgp_kat_*.npz (written by make_svgp_kat.py) must be
+reproduced by both oracle implementations, so a later edit cannot move the target silently; (2) the two pieces of
+the ELBO the oracle spells out by hand are checked once against independent code: the KL term against
+torch.distributions.kl_divergence, the 20-point Gauss-Hermite expectation against adaptive quadrature
+(scipy.integrate.quad) of the same integral.
+"""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import svgp_oracle as so
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = sorted(os.path.basename(p)[len("svgp_kat_"):-4] for p in glob.glob(os.path.join(HERE, "golden", "svgp_kat_*.npz")))
+
+
+def _kat(name):
+    z = np.load(os.path.join(HERE, "golden", "svgp_kat_%s.npz" % name))
+    X = np.concatenate([z["feats"][z["b1"]], z["feats"][z["b2"]]]).astype(np.float64)
+    y = np.r_[-np.ones(len(z["b1"])), np.ones(len(z["b2"]))]
+    return z, X, y, z["feats"][z["it"]].astype(np.float64)
+
+
+def test_kat_set_covers_both_feature_widths_and_every_kernel_route():
+    from gapro_amd import _lib
+
+    lib = _lib.load()
+    routes = set()
+    for name in KATS:
+        z = np.load(os.path.join(HERE, "golden", "svgp_kat_%s.npz" % name))
+        routes.add((int(z["feats"].shape[1]), int(lib.gapro_fit_route(len(z["b1"]) + len(z["b2"]), z["feats"].shape[1]))))
+    assert {(6, 3), (6, 0), (6, 1), (32, 3), (32, 0), (32, 1)} <= routes, routes
+
+
+@pytest.mark.parametrize("name", KATS)
+def test_oracle_reproduces_its_frozen_vectors(name):
+    z, X, y, Xt = _kat(name)
+    if len(X) > 160:
+        pytest.skip("the large vectors are compared on the GPU box only (CPU time)")
+    (mu, var, p), st = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64", return_trace=True)
+    np.testing.assert_allclose(st["loss"], z["loss"], rtol=1e-9)
+    np.testing.assert_allclose(var, z["var"], rtol=1e-7)
+    np.testing.assert_allclose(mu, z["mu"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(p, z["p"], rtol=0, atol=1e-8)
+    assert abs(st["c"] - float(z["c"])) < 1e-8 and abs(st["rho_l"] - float(z["rho_l"])) < 1e-8
+    if len(X) <= 60:  # the NumPy implementation with the hand-derived backward (what the kernel does step for step)
+        mu_m, var_m, p_m = so.svgp_fit_predict_manual(X, y, Xt, 50)
+        np.testing.assert_allclose(var_m, z["var"], rtol=1e-6)
+        np.testing.assert_allclose(mu_m, z["mu"], rtol=1e-5, atol=1e-8)
+
+
+def test_elbo_pieces_against_independent_code():
+    """loss = -(sum_i E_i / N - KL / N) at a NON-trivial parameter point (the state after 6 Adam steps), with
+    KL from torch.distributions and E_i from adaptive quadrature of  int log Phi(y f) N(f; mu_i, var_i) df."""
+    import torch
+    from scipy import integrate
+    from scipy.linalg import cholesky, solve_triangular
+    from scipy.special import log_ndtr
+
+    z, X, y, Xt = _kat("m50_d6")
+    _, st = so.svgp_fit_predict_autograd(X, y, Xt, 6, "f64", return_trace=True)
+    Z, m, LS, c = st["Z"], st["m"], np.tril(st["LS"]), st["c"]
+    loss, _ = so.svgp_loss_and_grads(X, y, Z, m, LS, c, st["rho_s"], st["rho_l"])
+    M = len(m)
+    # --- KL(q(u) || N(0, I)), q(u) = N(m, L_S L_S^T)
+    q = torch.distributions.MultivariateNormal(torch.as_tensor(m), scale_tril=torch.as_tensor(LS))
+    prior = torch.distributions.MultivariateNormal(torch.zeros(M, dtype=torch.float64), torch.eye(M, dtype=torch.float64))
+    kl = float(torch.distributions.kl_divergence(q, prior))
+    # --- q(f_i): whitened strategy, written from the definitions (not the oracle's code)
+    s = math.log1p(math.exp(st["rho_s"]))
+    ell = math.log1p(math.exp(st["rho_l"]))
+    def k(a, b):
+        return s * np.exp(-0.5 * ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1) / ell ** 2)
+    L = cholesky(k(Z, Z) + so.JITTER * np.eye(M), lower=True)
+    A = solve_triangular(L, k(Z, X), lower=True)
+    mu = A.T @ m + c
+    var = s + so.JITTER + np.einsum("ij,ij->j", LS.T @ A, LS.T @ A) - np.einsum("ij,ij->j", A, A)
+    assert (var > so.MIN_VARIANCE).all()
+    E = []
+    for i in range(len(y)):
+        sd = math.sqrt(var[i])
+        f = lambda t: log_ndtr(y[i] * (mu[i] + sd * t)) * math.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)  # noqa: E731
+        E.append(integrate.quad(f, -12, 12, epsabs=1e-13, epsrel=1e-13, limit=200)[0])
+    expect = -(sum(E) / len(y) - kl / len(y))
+    assert abs(loss - expect) < 5e-9, (loss, expect)  # what is left is the error of the 20-point rule
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", KATS)
+def test_hip_kernels_match_the_frozen_vectors(name):
+    """Every kernel route, both feature widths, 50 steps, fresh and stale Cholesky at prediction: float32 outputs
+    within 1e-5 (var) / 1e-5 + 1e-7 (mu) / 2e-7 (p) of the frozen float64 vectors."""
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+
+    z = np.load(os.path.join(HERE, "golden", "svgp_kat_%s.npz" % name))
+    launch = [(z["b1"], z["b2"], z["it"])]
+    (probs, probs_new, labels, mu, var), res = fit_gp_spp_batch(z["feats"], launch, training_iter=50, keep_debug=True)
+    np.testing.assert_allclose(var, z["var"], rtol=1e-5)
+    np.testing.assert_allclose(mu, z["mu"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(probs, z["p"], rtol=0, atol=2e-7)
+    assert abs(float(res["loss"][0]) - float(z["loss"][-1])) < 1e-9  # the ELBO of the last training step, float64
+    _, _, _, mu_s, var_s = fit_gp_spp_batch(z["feats"], launch, training_iter=50, eval_stale_chol=True)[0]
+    np.testing.assert_allclose(var_s, z["var_stale"], rtol=1e-5)
+    np.testing.assert_allclose(mu_s, z["mu_stale"], rtol=1e-5, atol=1e-7)
