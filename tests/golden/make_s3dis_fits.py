@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Two GP problems cut out of the S3DIS-shaped scene of tests/test_pipeline_gpu.py::test_s3dis_shaped_scene_matches_oracle
+(BASELINE configs[3]), as data: tests/golden/s3dis_fits.npz.
+
+    python tests/golden/make_s3dis_fits.py      (about a minute: builds the 1M-point scene and its schedule)
+
+Of the scene's 66 fits, exactly one (index 46: M = 144 training / inducing superpoints, T = 183 test superpoints) is
+not reproducible to float32 rounding by ANY two float64 implementations: the oracle's own two (torch autograd and
+the NumPy hand-derived backward, same formulas, different summation order) end 3e-5 apart in sigma^2 after 50 Adam
+steps, against < 3e-8 on each of the other 65 (measured over all 66; `drift` in the file).  The file holds that fit
+and, as a control, the most drifting of the others (index 5), so that tests/test_svgp_oracle.py can show the
+difference on CPU in seconds and the GPU test can tie its tolerance to it instead of to a blanket carve-out.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from gapro_amd.gen_ps_utils import getInstanceInfo  # noqa: E402
+from gapro_amd.synth import make_scene  # noqa: E402
+from oracle import gen_ps_oracle as O  # noqa: E402
+from oracle import svgp_oracle as so  # noqa: E402
+
+
+def main():
+    sc = make_scene(seed=7, n_points=1_000_000, n_objects=40, with_walls_json=False, obj_patch=60, plane_patch=400)
+    xyz = sc.aligned_xyz()
+    _, cls, box, vol, _ = getInstanceInfo(xyz, sc.inst, sc.sem)
+    boxes, bcls, bvol = O.assemble_boxes(xyz, cls.astype(np.int64), box.astype(np.float32), vol.astype(np.float32),
+                                         [], [], 13)
+    part = O.partition(xyz, sc.default_feats().astype(np.float32), sc.spp, boxes, bcls, bvol, 0.999)
+    ev = [e for e in O.enumerate_schedule(boxes, part.occ_spp, part.n_bbs_per_spp) if e.kind == "fit"]
+    assert len(ev) == 66
+    rec = {}
+    for tag, i in (("ill", 46), ("ctl", 5)):
+        e = ev[i]
+        idx = np.concatenate([e.b1_inds, e.b2_inds, e.intersect_inds])
+        rec[tag + "_feats"] = part.feats_spp[idx]
+        rec[tag + "_m1"], rec[tag + "_m2"], rec[tag + "_t"] = len(e.b1_inds), len(e.b2_inds), len(e.intersect_inds)
+        X = part.feats_spp[np.concatenate([e.b1_inds, e.b2_inds])].astype(np.float64)
+        y = np.r_[-np.ones(len(e.b1_inds)), np.ones(len(e.b2_inds))]
+        Xt = part.feats_spp[e.intersect_inds].astype(np.float64)
+        a = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64")
+        m = so.svgp_fit_predict_manual(X, y, Xt, 50)
+        rec[tag + "_drift"] = np.array([np.max(np.abs(a[1] - m[1]) / a[1]), np.max(np.abs(a[2] - m[2]))])
+        print(tag, i, rec[tag + "_m1"] + rec[tag + "_m2"], rec[tag + "_t"], rec[tag + "_drift"])
+    np.savez_compressed(os.path.join(HERE, "s3dis_fits.npz"), **rec)
+
+
+if __name__ == "__main__":
+    main()

@@ -140,20 +140,21 @@ def test_full_size_scenes_size_independent_properties():
 
 def test_s3dis_shaped_scene_matches_oracle():
     """BASELINE configs[3]: a room-sized scene (1M points, 13 classes, objects of up to several hundred
-    superpoints).  Its 66 fits (M up to 724) span all four fit kernels (small-fit strip, strip, LDS-staged, generic
-    for M > 512) inside one real schedule.
+    superpoints).  Its 66 fits (M up to 724) span every fit kernel inside one real schedule.
 
-    With T in the hundreds a few fits are no longer reproducible to float32 rounding by ANY two implementations: a
-    training point whose q(f) variance nearly cancels (s + jitter + sum(B^2 - A^2) ~ 1e-6 from O(1) terms) turns
-    1e-16 of summation-order noise into 1e-5 of the result within a few Adam steps (here: two fits of 66; the
-    oracle's own two implementations drift apart the same way on one of them).  So: at least 90 % of the fits must
-    agree to float32 rounding, every fit within a loose bound, and the integer masks bit for bit wherever the GP
-    probability is not within that bound of a tie."""
+    Tolerance rule (no blanket carve-out): EVERY fit must agree with the float64 autograd oracle to float32 rounding
+    (p within 3e-7, sigma^2 within 1e-5 relative) UNLESS the oracle's own two float64 implementations (autograd and
+    the NumPy hand-derived backward: same formulas, different summation order) drift apart by more than 1e-6 on that
+    very fit -- then no implementation can be held tighter than that drift, and the kernel must stay within 30x of
+    it.  tests/test_svgp_oracle.py::test_the_one_ill_conditioned_s3dis_fit_... shows on CPU that exactly one of the 66
+    fits is of that kind (3e-5 between the oracle's implementations, < 3e-8 on each of the other 65).  Integer masks
+    are compared bit for bit wherever the GP probability is further from a tie than the deviation allowed above."""
     from gapro_amd import gen_pseudo_label_gaussian_process
     from gapro_amd._lib import Context
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
     from gapro_amd.gen_ps_utils import getInstanceInfo
     from gapro_amd.synth import make_scene
+    from oracle import svgp_oracle as so
 
     sc = make_scene(seed=7, n_points=1_000_000, n_objects=40, with_walls_json=False, obj_patch=60, plane_patch=400)
     xyz = sc.aligned_xyz()
@@ -166,29 +167,42 @@ def test_s3dis_shaped_scene_matches_oracle():
     fits = [e for e in dbg["events"] if e.kind == "fit"]
     lib = Context.get(0).lib
     routes = {int(lib.gapro_fit_route(len(e.b1_inds) + len(e.b2_inds), 6)) for e in fits}
-    assert routes == {0, 1, 2, 3}, routes  # the scene really exercises every kernel
+    assert {0, 1, 3} <= routes and (routes & {2, 4}), routes  # the scene really exercises every kernel family
     # fit by fit, on the oracle's pooled features (the partition is compared bit for bit through the masks below)
     got = fit_gp_spp_batch(dbg["part"].feats_spp, [(e.b1_inds, e.b2_inds, e.intersect_inds) for e in fits],
                            training_iter=50)
-    tight = 0
-    for g, r in zip(got, dbg["results"]):
+    loose, worst_p = [], 3e-7
+    for k, (g, r, e) in enumerate(zip(got, dbg["results"], fits)):
         dp = np.max(np.abs(g[0].astype(np.float64) - r[0]))
         dv = np.max(np.abs(g[4].astype(np.float64) - r[4]) / r[4])
-        assert dp < 5e-4 and dv < 5e-3
-        tight += bool(dp < 3e-7 and dv < 1e-5)
-    assert tight >= 0.9 * len(fits), (tight, len(fits))
+        if dp < 3e-7 and dv < 1e-5:
+            continue
+        f = dbg["part"].feats_spp
+        X = np.concatenate([f[e.b1_inds], f[e.b2_inds]]).astype(np.float64)
+        y = np.r_[-np.ones(len(e.b1_inds)), np.ones(len(e.b2_inds))]
+        Xt = f[e.intersect_inds].astype(np.float64)
+        a = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64")
+        m = so.svgp_fit_predict_manual(X, y, Xt, 50)
+        odv, odp = np.max(np.abs(a[1] - m[1]) / a[1]), np.max(np.abs(a[2] - m[2]))
+        assert odv > 1e-6, "fit %d (M=%d): kernel off by dv=%.2e dp=%.2e while the oracle's own implementations " \
+                           "agree to %.2e" % (k, len(X), dv, dp, odv)
+        assert dv < 30 * odv and dp < 30 * max(odp, 1e-7), (k, dv, dp, odv, odp)
+        loose.append(k)
+        worst_p = max(worst_p, dp)
+    assert len(loose) <= 2, loose
     outs = gen_pseudo_label_gaussian_process(**kw)
     sem, ins, prob, mu, var = [o.cpu().numpy() for o in outs]
     r_sem, r_ins, r_prob, r_mu, r_var = ref
-    np.testing.assert_allclose(prob, r_prob, rtol=0, atol=5e-4)
-    safe = np.abs(r_prob.astype(np.float64) - 0.5) > 1e-3
-    assert safe.mean() > 0.99
+    np.testing.assert_allclose(prob, r_prob, rtol=0, atol=max(2 * worst_p, 1e-6))
+    safe = np.abs(r_prob.astype(np.float64) - 0.5) > 2 * worst_p
+    assert safe.mean() > 0.999
     np.testing.assert_array_equal(sem[safe], r_sem[safe])
     np.testing.assert_array_equal(ins[safe], r_ins[safe])
     gp = r_mu != -100
     np.testing.assert_array_equal(mu == -100, ~gp)
-    np.testing.assert_allclose(var[gp], r_var[gp], rtol=5e-3)
-    assert np.mean(np.abs(var[gp] - r_var[gp]) <= 1e-4 * r_var[gp]) > 0.95  # north_star tolerance, bar the above
+    ok = np.abs(var[gp] - r_var[gp]) <= 1e-4 * r_var[gp]  # north_star tolerance ...
+    n_loose_spp = sum(len(fits[k].intersect_inds) for k in loose)
+    assert (~ok).sum() <= n_loose_spp  # ... everywhere but on superpoints labelled by the ill-conditioned fit(s)
 
 
 def test_scenes_without_any_gp_fit_and_mixed_batches():

@@ -70,3 +70,26 @@ def test_precision_and_init_noise_study(m1, m2, t):
     rng = np.random.default_rng(0)
     _, var_r, _ = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64", init_mean=1e-3 * rng.standard_normal(m1 + m2))
     assert np.max(np.abs(var_r - var64) / var64) > 1e-3
+
+
+def test_the_one_ill_conditioned_s3dis_fit_drifts_between_the_oracles_own_implementations():
+    """Evidence for the tolerance of tests/test_pipeline_gpu.py::test_s3dis_shaped_scene_matches_oracle (BASELINE
+    configs[3]).  Of that scene's 66 GP fits exactly one is not reproducible to float32 rounding by any two float64
+    implementations: here the oracle's own two (autograd / hand-derived backward: the same formulas in a different
+    summation order) end > 1e-5 apart in sigma^2 on it after 50 Adam steps and < 1e-7 apart on the control fit, the
+    most drifting of the other 65 (tests/golden/make_s3dis_fits.py measured all 66).  Early steps agree to 1e-11 on
+    both: the gap is amplified rounding noise, not a formula difference."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s3dis_fits.npz"))
+    out = {}
+    for tag in ("ill", "ctl"):
+        f, m1, m2 = z[tag + "_feats"], int(z[tag + "_m1"]), int(z[tag + "_m2"])
+        X, Xt = f[:m1 + m2].astype(np.float64), f[m1 + m2:].astype(np.float64)
+        y = np.r_[-np.ones(m1), np.ones(m2)]
+        (_, va, _), sa = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64", return_trace=True)
+        (_, vm, _), sm = so.svgp_fit_predict_manual(X, y, Xt, 50, return_trace=True)
+        out[tag] = float(np.max(np.abs(va - vm) / va))
+        np.testing.assert_allclose(sm["loss"][:5], sa["loss"][:5], rtol=1e-11)
+    assert out["ctl"] < 1e-7 < 1e-5 < out["ill"], out
+    assert abs(np.log10(out["ill"] / float(z["ill_drift"][0]))) < 1.5  # same order as when the file was written
