@@ -77,7 +77,7 @@ def test_the_one_ill_conditioned_s3dis_fit_drifts_between_the_oracles_own_implem
     configs[3]).  Of that scene's 66 GP fits exactly one is not reproducible to float32 rounding by any two float64
     implementations: here the oracle's own two (autograd / hand-derived backward: the same formulas in a different
     summation order) end > 1e-5 apart in sigma^2 on it after 50 Adam steps and < 1e-7 apart on the control fit, the
-    most drifting of the other 65 (tests/golden/make_s3dis_fits.py measured all 66).  Early steps agree to 1e-11 on
+    most drifting of the other 65 (tests/golden/make_s3dis_fits.py measured all 66).  Early steps agree to 1e-9 on
     both: the gap is amplified rounding noise, not a formula difference."""
     import os
 
@@ -90,6 +90,6 @@ def test_the_one_ill_conditioned_s3dis_fit_drifts_between_the_oracles_own_implem
         (_, va, _), sa = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64", return_trace=True)
         (_, vm, _), sm = so.svgp_fit_predict_manual(X, y, Xt, 50, return_trace=True)
         out[tag] = float(np.max(np.abs(va - vm) / va))
-        np.testing.assert_allclose(sm["loss"][:5], sa["loss"][:5], rtol=1e-11)
+        np.testing.assert_allclose(sm["loss"][:5], sa["loss"][:5], rtol=1e-9)
     assert out["ctl"] < 1e-7 < 1e-5 < out["ill"], out
     assert abs(np.log10(out["ill"] / float(z["ill_drift"][0]))) < 1.5  # same order as when the file was written
