@@ -330,7 +330,7 @@ def run_workload(args, pipe, dev, rank, world, workload, B, distinct, steps, war
     barrier()
     elapsed = barrier_and_max(time.perf_counter() - t0, reduce_dev)  # MAX over ranks
     # device-side duration of every fit launch, from HIP events the library records on the streams its kernels
-    # run on: (staged kernel ms, strip kernel ms, first start -> last end ms, small-fit strip kernel ms)
+    # run on: (staged kernel ms, strip kernel ms, first start -> last end ms, small-fit strip kernel ms, cluster ms)
     fit_ms3 = [ev.read() for ev in pipe.fit_events]
     part = {}
     for ev in pipe.part_events:
@@ -356,6 +356,7 @@ def summarize(args, res, B, world, steps, workload, peak):
         "strip": ("k_svgp_fit_strip<%s> 512 threads (64 < M_p <= 128)", 1, "flops_strip"),
         "staged": ("k_svgp_fit<WPS> LDS-staged (128 < M_p <= 512) + generic beyond", 0, "flops_staged"),
         "small": ("k_svgp_fit_strip<%s> 256 threads, two fits per CU (M_p <= 64)", 3, "flops_small"),
+        "cluster": ("k_svgp_fit_cluster: one fit over 2..32 workgroups (M_p > 384)", 4, "flops_cluster"),
     }
     per = {}
     for key, (name, slot, attr) in kernels.items():
@@ -504,8 +505,8 @@ def main():
                        reduce_dev=None if shared else dev)
     main_keys = summarize(args, res, B, world, args.steps, args.workload, FP64_MFMA_PEAK_TFLOPS) if rank == 0 else None
     if rank == 0:
-        print("fit launch device ms per step (staged, strip, span, small strip): "
-              + "  ".join("%.1f/%.1f/%.1f/%.1f" % t for t in res["fit_ms3"]), file=sys.stderr)
+        print("fit launch device ms per step (staged, strip, span, small strip, cluster): "
+              + "  ".join("%.1f/%.1f/%.1f/%.1f/%.1f" % t for t in res["fit_ms3"]), file=sys.stderr)
         if args.trace and res["trace"]:
             t_first = res["trace"][0][0]
             ids = {}

@@ -15,10 +15,17 @@ struct gapro_ctx {
   int n_cu = 0;
   std::string last_error;
   gapro_scene_header* h_header_pinned = nullptr;  // pinned staging for the blocking prepare call
-  // The fit kernels run on three library-owned streams ([0] staged / generic kernel, [1] strip kernel, [2] the
-  // small-fit strip kernel), so that they share the GPU.
-  hipStream_t fit_stream[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_join[3] = {nullptr, nullptr, nullptr};
+  // The fit kernels run on four library-owned streams ([0] staged / generic kernel, [1] strip kernel, [2] the
+  // small-fit strip kernel, [3] the cluster kernel: large fits spread over several CUs), so that they share the GPU.
+  hipStream_t fit_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // cluster kernel: block table staging (pinned host + device) and the clusters' barrier counters, grown on demand
+  void* h_cl_stage = nullptr;
+  void* d_cl_stage = nullptr;
+  unsigned* d_cl_ctl = nullptr;
+  size_t cl_stage_bytes = 0;
+  size_t cl_ctl_fits = 0;
+  unsigned cl_parity = 0;
   // single-scene partition calls stage their one-task batch through this ring (pinned host + device mirror);
   // a slot is reused after kTaskRing further calls, long after the stream has consumed it
   gapro_scene_task* h_task_ring = nullptr;
@@ -29,9 +36,19 @@ struct gapro_ctx {
 
 // HIP events around the kernels of one fit launch, recorded on the streams the kernels run on.
 struct gapro_fit_timing {
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/end: staged, strip, small strip
-  bool used[3] = {false, false, false};
+  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/end: staged,
+                                                                                                // strip, small, cluster
+  bool used[4] = {false, false, false, false};
 };
+
+// svgp_fit_cluster.hip
+int gapro_cluster_size(int Mp);
+size_t gapro_cluster_stage_bytes(int n_fits);
+int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, const int* fit_mp, const int* fit_g,
+                             int feat_dim, void* h_stage, void* d_stage, unsigned* d_ctl, const float* d_feats_spp,
+                             const int* d_idx, const gapro_fit_desc* d_descs, const double* d_init_mean,
+                             const gapro_fit_options& opt, double* d_workspace, float* d_probs, float* d_probs_new,
+                             unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss);
 
 // Padded size of a fit's M x M matrices: MFMA tiles are 16 wide, so M is rounded up to a multiple of 16 (everything
 // scales with M_p^3: rounding M = 80 to 96 instead of 80 costs 1.7x the work).  The products use 32 x 32 wave tiles

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "common.h"
+#include "fit_layout.h"
 
 void gapro_launch_fit_large(hipStream_t stream, int n_fits, int feat_dim, const float* d_feats_spp, const int* d_idx,
                             const gapro_fit_desc* d_descs, const double* d_init_mean, const gapro_fit_options& opt,
@@ -42,6 +43,7 @@ void gapro_launch_fit_large(hipStream_t stream, int n_fits, int feat_dim, const 
                             float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss);
 
 namespace {
+using namespace gapro_fit;
 
 #ifndef GAPRO_NT
 #define GAPRO_NT 512
@@ -74,35 +76,9 @@ __constant__ double c_gh_w[10] = {0.4622436696006101,     0.28667550536283415,  
                                   7.80255647853206e-06,   1.0860693707692782e-07, 4.3993409922731747e-10,
                                   2.2293936455341447e-13};
 
-inline __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
 // ---- workspace layout (doubles); identical to svgp_fit_large.hip -----------------------------------
-enum MatId {
-  B_LS = 0, B_LST, B_MLS, B_VLS, B_GLS, B_L, B_LT, B_LI, B_U, B_KX, B_A, B_AT, B_BM, B_BMT, B_GA, B_GKX, B_GKXT,
-  B_COUNT
-};
-enum VecId { V_Y = 0, V_M, V_MM, V_VM, V_GM, V_MU, V_VAR, V_GMU, V_GV, V_COUNT };
-constexpr int kScalars = 64;
-
-struct Layout {
-  int Mp, Tp, D;
-  long long mat, vec, xz, xt, dinv, scal, total;
-};
-inline __host__ __device__ Layout make_layout(int m, int t, int d) {
-  Layout L;
-  L.Mp = gapro_pad_m(m);
-  L.Tp = round_up(t > 0 ? t : 1, 32);
-  L.D = d;
-  L.mat = 0;
-  L.vec = L.mat + (long long)B_COUNT * L.Mp * L.Mp;
-  L.xz = L.vec + (long long)V_COUNT * L.Mp;
-  L.xt = L.xz + 5LL * L.Mp * d;  // X, Z, mZ, vZ, gZ
-  L.dinv = L.xt + (long long)L.Tp * d;
-  L.scal = L.dinv + 2LL * L.Mp * 16;  // Dinv and Dinv^T blocks
-  L.total = L.scal + kScalars;
-  L.total = (L.total + 1) / 2 * 2;
-  return L;
-}
+// (enums, Layout and make_layout: fit_layout.h, shared by every fit kernel)
 
 // dynamic LDS of the staged kernel: Zt[D][Mp] | Pt[D][Mp] | scratch
 constexpr int kTileDoubles = NW * 16 * 17;  // per-wave transpose tiles at the start of the scratch
@@ -123,7 +99,6 @@ inline __host__ __device__ bool staged_ok(int m, int d) {
   return gapro_pad_m(m) <= kMaxMpLds && d <= 32 && staged_lds_bytes(m, d) <= kMaxDynLds;
 }
 
-enum ScalId { S_C = 0, S_RS, S_RL, S_MC, S_MRS, S_MRL, S_VC, S_VRS, S_VRL, S_LOSS, S_STATUS };
 
 struct Fit {
   int M, T, D, Mp;
@@ -1472,7 +1447,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
       o_labels[o] = lab ? 1 : 0;
       o_mu[o] = (float)mu;                             // pred_mu               :435
       o_var[o] = (float)var;                           // pred_variance         :436
-      if (!isfinite(mu) || !isfinite(var)) sh.status = GAPRO_ERR_NOT_FINITE;
+      if ((!isfinite(mu) || !isfinite(var)) && sh.status == GAPRO_OK) sh.status = GAPRO_ERR_NOT_FINITE;  // first error wins
     }
     __syncthreads();
   }
@@ -2333,7 +2308,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         o_labels[o] = lab ? 1 : 0;
         o_mu[o] = (float)mu;                             // pred_mu               :435
         o_var[o] = (float)var;                           // pred_variance         :436
-        if (!isfinite(mu) || !isfinite(var)) sh.status = GAPRO_ERR_NOT_FINITE;
+        if ((!isfinite(mu) || !isfinite(var)) && sh.status == GAPRO_OK) sh.status = GAPRO_ERR_NOT_FINITE;  // first error wins
       }
       __syncthreads();
     }
@@ -2436,10 +2411,13 @@ __global__ void k_stream_calib(long long n, const double* __restrict__ src, doub
 }
 
 // 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel, 3 = strip-streaming kernel of the small-fit
-// translation unit (M_p <= 64: 256 threads per fit, two fits per CU).  flags: gapro_fit_options.reserved debug bits
-// (bit 0: never the strip kernels, bit 2: no small-fit kernel).
+// translation unit (M_p <= 64: 256 threads per fit, two fits per CU), 4 = cluster kernel (one fit over several
+// workgroups).  flags: gapro_fit_options.reserved debug bits (bit 0: never the strip kernels, bit 2: no small-fit
+// kernel, bit 3: no cluster kernel).
 constexpr int kSmallFitMp = 64;
 static int fit_route(int m, int feat_dim, int flags) {
+  // large fits: spread over several CUs (svgp_fit_cluster.hip); debug bit 3 keeps them on one workgroup
+  if (!(flags & 8) && gapro_cluster_size(gapro_pad_m(m)) > 1) return 4;
   if (!(flags & 1) && strip_ok(m, feat_dim)) {
     const bool small = gapro_pad_m(m) <= kSmallFitMp && 2 * gapro_fit_strip_small_lds_bytes(m, feat_dim) + 16384 <= 160 * 1024;
     return (small && !(flags & 4)) ? 3 : 0;
@@ -2489,7 +2467,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // Routing (gapro_fit_route): strip-streaming kernel, LDS-staged kernel, generic kernel (working set beyond
   // LDS).  Every group is sorted longest processing time first (cost ~ M^3): workgroups are dispatched in
   // block order, so the expensive fits start first and the tail of a launch stays short.
-  std::vector<gapro_fit_desc> strip, small, staged, large;
+  std::vector<gapro_fit_desc> strip, small, staged, large, clus;
   strip.reserve(n_fits);
   small.reserve(n_fits);
   long long need = 0, max_lds = 0, max_lds_strip = 0, max_lds_small = 0;
@@ -2511,6 +2489,8 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     } else if (route == 1) {
       staged.push_back(d);
       max_lds = std::max(max_lds, staged_lds_bytes(m, feat_dim));
+    } else if (route == 4) {
+      clus.push_back(d);
     } else {
       large.push_back(d);
     }
@@ -2523,10 +2503,32 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   std::stable_sort(small.begin(), small.end(), by_cost);
   std::stable_sort(staged.begin(), staged.end(), by_cost);
   std::stable_sort(large.begin(), large.end(), by_cost);
+  std::stable_sort(clus.begin(), clus.end(), by_cost);
   std::vector<gapro_fit_desc> all(large);
   all.insert(all.end(), staged.begin(), staged.end());
   all.insert(all.end(), strip.begin(), strip.end());
   all.insert(all.end(), small.begin(), small.end());
+  const size_t clus_base = all.size();
+  all.insert(all.end(), clus.begin(), clus.end());
+  if (!clus.empty()) {  // staging of the cluster kernel: block table + one barrier counter line per fit
+    const size_t need_stage = gapro_cluster_stage_bytes((int)clus.size());
+    if (need_stage > ctx->cl_stage_bytes) {
+      if (ctx->h_cl_stage) (void)hipHostFree(ctx->h_cl_stage);
+      if (ctx->d_cl_stage) (void)hipFree(ctx->d_cl_stage);
+      ctx->h_cl_stage = ctx->d_cl_stage = nullptr;
+      ctx->cl_stage_bytes = 0;
+      GAPRO_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_cl_stage, 2 * need_stage, hipHostMallocDefault));
+      GAPRO_HIP_CHECK(ctx, hipMalloc(&ctx->d_cl_stage, 2 * need_stage));
+      ctx->cl_stage_bytes = 2 * need_stage;
+    }
+    if (clus.size() > ctx->cl_ctl_fits) {
+      if (ctx->d_cl_ctl) (void)hipFree(ctx->d_cl_ctl);
+      ctx->d_cl_ctl = nullptr;
+      ctx->cl_ctl_fits = 0;
+      GAPRO_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_cl_ctl, 2 * clus.size() * 128));
+      ctx->cl_ctl_fits = 2 * clus.size();
+    }
+  }
   GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_descs, all.data(), all.size() * sizeof(gapro_fit_desc), hipMemcpyHostToDevice,
                                       stream));
   GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));  // `all` is pageable host memory that dies with this call
@@ -2535,18 +2537,41 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // synchronised, so everything the kernels read is complete (and an event recorded here completes together
   // with the NEXT dispatch of `stream` under this runtime, which would serialise the kernels again).  Both
   // are joined back into `stream` with events.
-  const bool own = !(route_flags & 2) && ctx->fit_stream[0] && ctx->fit_stream[1] && ctx->fit_stream[2];  // debug bit 1
+  const bool own = !(route_flags & 2) && ctx->fit_stream[0] && ctx->fit_stream[1] && ctx->fit_stream[2] &&
+                   ctx->fit_stream[3];  // debug bit 1
   hipStream_t s_staged = own ? ctx->fit_stream[0] : stream;
   hipStream_t s_strip = own ? ctx->fit_stream[1] : stream;
   hipStream_t s_small = own ? ctx->fit_stream[2] : stream;
+  hipStream_t s_clus = own ? ctx->fit_stream[3] : stream;
   gapro_fit_timing* tm = ctx->armed_timing;
   ctx->armed_timing = nullptr;
   if (tm) {
     tm->used[0] = !large.empty() || !staged.empty();
     tm->used[1] = !strip.empty();
     tm->used[2] = !small.empty();
-    if (tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[0], s_staged));
+    tm->used[3] = !clus.empty();
   }
+  if (!clus.empty()) {  // first: the largest fits of the launch, each over several CUs
+    std::vector<int> fi(clus.size()), fmp(clus.size()), fg(clus.size());
+    for (size_t k = 0; k < clus.size(); ++k) {
+      fi[k] = (int)(clus_base + k);
+      fmp[k] = gapro_pad_m(clus[k].m1 + clus[k].m2);
+      fg[k] = gapro_cluster_size(fmp[k]);
+    }
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[6], s_clus));
+    // the block table is built in one half of the context's pinned buffer, the halves alternating per launch: the
+    // copy of launch i - 2 has long been consumed (callers collect a launch before they issue the one after next),
+    // so the host never waits for the previous cluster kernel here
+    char* h_half = (char*)ctx->h_cl_stage + (ctx->cl_parity & 1) * (ctx->cl_stage_bytes / 2);
+    ctx->cl_parity++;
+    const int rc = gapro_launch_fit_cluster(s_clus, (int)clus.size(), fi.data(), fmp.data(), fg.data(), feat_dim,
+                                            h_half, ctx->d_cl_stage, ctx->d_cl_ctl, d_feats_spp, d_idx, d_descs,
+                                            d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var,
+                                            d_fit_status, d_fit_loss);
+    if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: cluster kernel launch failed");
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[7], s_clus));
+  }
+  if (tm && tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[0], s_staged));
   if (!large.empty())
     gapro_launch_fit_large(s_staged, (int)large.size(), feat_dim, d_feats_spp, d_idx, d_descs, d_init_mean, *opt,
                            d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
@@ -2594,6 +2619,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[2], s_small));
       GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[2], 0));
     }
+    if (!clus.empty()) {
+      GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[3], s_clus));
+      GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[3], 0));
+    }
   }
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
@@ -2605,7 +2634,7 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
   if (!ctx || !out) return GAPRO_ERR_BAD_ARG;
   gapro_fit_timing* t = new (std::nothrow) gapro_fit_timing();
   if (!t) return GAPRO_ERR_OOM;
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 8; ++i)
     if (hipEventCreate(&t->ev[i]) != hipSuccess) {
       gapro_fit_timing_destroy(t);
       return gapro_fail(ctx, GAPRO_ERR_HIP, "gapro_fit_timing_create: hipEventCreate failed");
@@ -2616,7 +2645,7 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
 
 void gapro_fit_timing_destroy(gapro_fit_timing* t) {
   if (!t) return;
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < 8; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   delete t;
 }
@@ -2624,22 +2653,22 @@ void gapro_fit_timing_destroy(gapro_fit_timing* t) {
 int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
   ctx->armed_timing = t;
-  if (t) t->used[0] = t->used[1] = t->used[2] = false;
+  if (t) t->used[0] = t->used[1] = t->used[2] = t->used[3] = false;
   return GAPRO_OK;
 }
 
-int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms4) {
-  if (!ctx || !t || !out_ms4) return GAPRO_ERR_BAD_ARG;
-  out_ms4[0] = out_ms4[1] = out_ms4[2] = out_ms4[3] = 0.f;
-  const int slot[3] = {0, 1, 3};  // staged, strip, small-fit strip
-  float start[3] = {0.f, 0.f, 0.f}, end[3] = {0.f, 0.f, 0.f};
+int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5) {
+  if (!ctx || !t || !out_ms5) return GAPRO_ERR_BAD_ARG;
+  for (int i = 0; i < 5; ++i) out_ms5[i] = 0.f;
+  const int slot[4] = {0, 1, 3, 4};  // staged, strip, small-fit strip, cluster
+  float start[4] = {0.f, 0.f, 0.f, 0.f}, end[4] = {0.f, 0.f, 0.f, 0.f};
   int ref = -1;
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < 4; ++k) {
     if (!t->used[k]) continue;
     float ms = 0.f;
     GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[2 * k + 1]));
     GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
-    out_ms4[slot[k]] = ms;
+    out_ms5[slot[k]] = ms;
     if (ref < 0) ref = k;
     float off = 0.f;  // start of kernel k relative to the first used kernel's start
     if (k != ref) GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&off, t->ev[2 * ref], t->ev[2 * k]));
@@ -2648,12 +2677,12 @@ int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms4) {
   }
   if (ref >= 0) {
     float lo = 0.f, hi = 0.f;
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 4; ++k)
       if (t->used[k]) {
         lo = start[k] < lo ? start[k] : lo;
         hi = end[k] > hi ? end[k] : hi;
       }
-    out_ms4[2] = hi - lo;
+    out_ms5[2] = hi - lo;
   }
   return GAPRO_OK;
 }

@@ -1,0 +1,1144 @@
+// Cluster variant of the batched SVGP fit: ONE GP fit spread over G workgroups (G CUs), for the large overlap
+// regions of BASELINE configs[2-4] (M in the hundreds to thousands), where one fit on one CU takes 0.6 s (M = 512)
+// to tens of seconds (M = 2048) and the launch waits for its few largest fits while most of the chip idles.
+//
+// Same algorithm and arithmetic (float64) as svgp_fit_large.hip -- reference gapro/gaussian_process_utils.py:382-445
+// and the gpytorch objects it builds (:11-25); hand-derived backward of SURVEY.md Appendix B.5 -- with every matrix
+// in the fit's global-memory workspace.  What changes is who does the work and how the phases are separated:
+//
+//   * a phase's output tiles / elements are dealt to ALL waves / threads of the cluster (cw = g * 8 + wave of G * 8);
+//   * phases are separated by a CLUSTER barrier (one monotonic counter per cluster; every workgroup: each wave's
+//     vmcnt(0), workgroup barrier, lane 0: agent-scope release, arrive, relaxed sc1 poll, agent-scope acquire,
+//     vmcnt(0), workgroup barrier -- the form of /opt/skills/guides/cdna_hip_programming.md Guideline 16), because
+//     the per-CU L1s are never refreshed by other CUs' stores and the per-XCD L2s are not coherent with each other;
+//   * sums over the data index are two-stage and ordered (partials in the workspace's cluster scratch, summed in a
+//     fixed order after a barrier), so a fit is bitwise reproducible for a given G, and G is a function of M only;
+//   * Cholesky is right-looking with 64-wide panels: the leader workgroup factors the 64 x 64 diagonal block in LDS
+//     (16 x 16 blocks one row per lane in registers, v_readlane pivots) and inverts it, the panel below is one MFMA
+//     product with that inverse and the trailing update is a cluster-wide MFMA product: 3 barriers per panel;
+//   * L^-1 is built from the panels' 64 x 64 inverses by pairwise merging ([A 0; B C]^-1 = [A^-1 0; -C^-1 B A^-1 C^-1]):
+//     log2(M / 64) levels of two cluster-wide MFMA products instead of one serial chain per block column.
+//
+// Workgroups of one cluster are placed on ids b, b + 8, b + 16, ... (blocks b and b + 8 share an XCD under the
+// observed round-robin dispatch, so a cluster's traffic stays in one L2); this is a speed choice only, every
+// hand-off is agent-scope.  Co-residency: the grid is at most a few hundred workgroups of one per CU and the
+// members of a cluster are adjacent in dispatch order, so a cluster's members become resident together as soon
+// as CUs are free; the other fit kernels' workgroups never wait on anything.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "fit_layout.h"
+
+namespace {
+using namespace gapro_fit;
+
+constexpr int NT = kClThreads;  // threads per workgroup
+constexpr int NW = NT / 64;     // waves per workgroup
+constexpr int NB = 64;          // Cholesky panel width
+constexpr int NGH = 20;
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) double gd;
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(3))) double ldsd;
+
+__constant__ double c_gh_t[10] = {0.24534070830090124, 0.7374737285453944, 1.234076215395323,  1.7385377121165861,
+                                  2.2549740020892757,  2.7888060584281305, 3.3478545673832163, 3.944764040115625,
+                                  4.603682449550744,   5.387480890011233};
+__constant__ double c_gh_w[10] = {0.4622436696006101,     0.28667550536283415,    0.1090172060200233,
+                                  0.024810520887463643,   0.0032437733422378567,  0.00022833863601635365,
+                                  7.80255647853206e-06,   1.0860693707692782e-07, 4.3993409922731747e-10,
+                                  2.2293936455341447e-13};
+
+struct Fit {
+  int M, T, D, Mp;
+  gd* mat[B_COUNT];
+  gd* vec[V_COUNT];
+  gd *X, *Z, *mZ, *vZ, *gZ, *Xt, *dinv, *dinvT, *scal, *part, *red;
+};
+
+constexpr int kMaxPairs = 40;
+struct Shared {
+  Fit f;
+  int G, g;
+  unsigned epoch, red_par;
+  gu32* count;
+  double redw[NW];
+  double blk[NB * (NB + 1)];  // Cholesky diagonal block (row stride 65)
+  double dblk[16 * 17];
+  double dinv[16 * 17];
+  double tile[NW * 16 * 17];  // per-wave transpose tiles
+  double c, rho_s, rho_l, s, ell, inv_l2;
+  double mc, vc, mrs, vrs, mrl, vrl;  // Adam moments of the scalars: every workgroup applies the same updates
+  int status, chol_bad;
+  int pr_lo[kMaxPairs], pr_mid[kMaxPairs], pr_hi[kMaxPairs], pr_t0[kMaxPairs + 1];
+};
+__shared__ Shared g_sh;
+
+// ---- small helpers ---------------------------------------------------------------------------------
+__device__ inline double softplus(double x) { return log1p(exp(-fabs(x))) + fmax(x, 0.0); }
+__device__ inline double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
+__device__ inline void log_ndtr_ratio(double z, double* lp, double* r) {
+  const double rs2 = 0.70710678118654752440;
+  if (z < 0.0) {
+    const double ex = erfcx(-z * rs2);
+    *lp = log(0.5 * ex) - 0.5 * z * z;
+    *r = 0.79788456080286535588 / ex;
+  } else {
+    const double tail = 0.5 * erfc(z * rs2);
+    *lp = log1p(-tail);
+    *r = exp(-0.5 * z * z) * 0.39894228040143267794 / (1.0 - tail);
+  }
+}
+__device__ inline double lane_bcast(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ inline T* uni_ptr(T* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ inline double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double block_sum(double v) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) g_sh.redw[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < NW; ++w) t += g_sh.redw[w];
+  return t;
+}
+
+// cluster-wide thread / wave coordinates
+__device__ inline int cl_tid() { return g_sh.g * NT + (int)threadIdx.x; }
+__device__ inline int cl_threads() { return g_sh.G * NT; }
+__device__ inline int cl_wave() { return uni(g_sh.g * NW + (int)(threadIdx.x >> 6)); }
+__device__ inline int cl_waves() { return uni(g_sh.G * NW); }
+
+// ---- cluster barrier (Guideline 16: agent-scope release / acquire around one monotonic counter) ------
+__device__ __noinline__ void cbar() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+  __syncthreads();
+  if (g_sh.G > 1) {
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1: this XCD's dirty lines reach memory
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the arrive must not overtake the write-back
+      const unsigned target = (unsigned)g_sh.G * (++g_sh.epoch);
+      __hip_atomic_fetch_add(g_sh.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(g_sh.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+        __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1: drop this CU's stale L1 lines
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // holds the barrier below until the invalidate is done
+    }
+    __syncthreads();
+  }
+}
+
+// Ordered cluster sum of K per-thread partials; the result is the same on every thread of every workgroup.
+template <int K>
+__device__ __noinline__ void cl_reduce(double (&v)[K]) {
+  const int G = g_sh.G;
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = block_sum(v[k]);
+  if (G == 1) return;
+  gd* red = g_sh.f.red + (size_t)(g_sh.red_par & 1) * 16 * kClMaxG;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[k * kClMaxG + g_sh.g] = v[k];
+    g_sh.red_par++;  // two slot sets alternate: a workgroup can be at most one barrier ahead of the slowest reader
+  }
+  cbar();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = 0.0;
+    for (int q = 0; q < G; ++q) t += red[k * kClMaxG + q];
+    v[k] = t;
+  }
+}
+
+// ---- TN-form MFMA product, tiles dealt to every wave of the cluster ----------------------------------
+//   C[i][j] = sum_{k in [klo,khi)} P[k][i] * Q[k][j] (* qscale[k] if SCALE);  P, Q row-major in k with leading
+//   dimension ld; each wave owns (16 TU) x (16 TU) output tiles; `lower_only` enumerates tiles ti >= tj.
+//   kr(i0, j0, &klo, &khi): contraction range (multiples of 8); epi(i, j, tile): one 16 x 16 result in C layout.
+//   Two register blocks of KS k-steps alternate with no guard in the steady-state body (see svgp_fit.hip).
+template <int TU, bool SCALE, typename KRange, typename Epi>
+__device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
+                                     const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+                                     Epi epi) {
+  mo_tiles = uni(mo_tiles);
+  no_tiles = uni(no_tiles);
+  lower_only = uni((int)lower_only) != 0;
+  ld = uni(ld);
+  P = uni_ptr(P);
+  Q = uni_ptr(Q);
+  qscale = uni_ptr(qscale);
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int cw = cl_wave(), CW = cl_waves();
+  constexpr int TS = 16 * TU;
+  constexpr int KS = 2, KB = 4 * KS;
+  const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
+#pragma nounroll
+  for (int t = cw; t < ntiles; t += CW) {
+    int ti, tj;
+    if (lower_only) {
+      ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      while (ti * (ti + 1) / 2 > t) --ti;
+      tj = t - ti * (ti + 1) / 2;
+    } else {
+      ti = t / no_tiles;
+      tj = t - ti * no_tiles;
+    }
+    const int i0 = ti * TS, j0 = tj * TS;
+    int klo, khi;
+    kr(i0, j0, &klo, &khi);
+    klo = uni(klo);
+    khi = uni(khi);
+    d4 acc[TU][TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int v = 0; v < TU; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
+    const gd* pbase = P + (size_t)lq * ld + i0 + lr;
+    const gd* qbase = Q + (size_t)lq * ld + j0 + lr;
+    double a0[KS][TU], b0[KS][TU], a1[KS][TU], b1[KS][TU];
+    double s0[KS], s1[KS];
+    auto load_block = [&](int k, double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const gd* pr = pbase + (size_t)(k + 4 * s) * ld;
+        const gd* qr = qbase + (size_t)(k + 4 * s) * ld;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) a[s][u] = pr[16 * u];
+#pragma unroll
+        for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v];
+        if (SCALE) sc[s] = qscale[k + 4 * s + lq];
+      }
+    };
+    auto mma_block = [&](double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        double bs[TU];
+#pragma unroll
+        for (int v = 0; v < TU; ++v) bs[v] = SCALE ? b[s][v] * sc[s] : b[s][v];
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int v = 0; v < TU; ++v)
+            acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], bs[v], acc[u][v], 0, 0, 0);
+      }
+    };
+    if (klo < khi) {
+      load_block(klo, a0, b0, s0);
+      int k = klo;
+#pragma nounroll
+      for (; k + 2 * KB < khi; k += 2 * KB) {
+        load_block(k + KB, a1, b1, s1);
+        mma_block(a0, b0, s0);
+        load_block(k + 2 * KB, a0, b0, s0);
+        mma_block(a1, b1, s1);
+      }
+      if (k + KB < khi) {
+        load_block(k + KB, a1, b1, s1);
+        mma_block(a0, b0, s0);
+        mma_block(a1, b1, s1);
+      } else {
+        mma_block(a0, b0, s0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int v = 0; v < TU; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
+  }
+}
+
+// Store a 16x16 accumulator tile (C layout) row-major at Cm[i0.., j0..] and/or transposed at CT[j0.., i0..]; the
+// transposed copy goes through the wave's LDS tile so that its global stores are 128-byte rows too.
+__device__ inline void store_tile(const d4& v, gd* __restrict__ Cm, gd* __restrict__ CT, int ld, int i0, int j0) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  if (Cm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cm[(size_t)(i0 + lq + 4 * r) * ld + j0 + lr] = v[r];
+  }
+  if (CT) {
+    ldsd* tile = (ldsd*)g_sh.tile + (threadIdx.x >> 6) * 16 * 17;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(lq + 4 * r) * 17 + lr] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) CT[(size_t)(j0 + lq + 4 * r) * ld + i0 + lr] = tile[lr * 17 + lq + 4 * r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__device__ inline double sqdist(const gd* a, const gd* b, int D) {
+  double s = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double t = a[d] - b[d];
+    s += t * t;
+  }
+  return s;
+}
+
+// ---- Cholesky ---------------------------------------------------------------------------------------
+// 16 x 16 diagonal block at blk[16 kb.., 16 kb..] (LDS, row stride RS): L_kk in place (upper zeroed) and
+// Dinv = L_kk^-1 in g_sh.dinv; one wave, rows in registers, pivots by v_readlane (as svgp_fit.hip).
+__device__ __noinline__ void diag16(ldsd* blk, int RS, int kb) {
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  ldsd* base = blk + (16 * kb) * RS + 16 * kb;
+  ldsd* dinv = (ldsd*)g_sh.dinv;
+  double rdiag[16];
+  double a[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) a[c] = base[r * RS + c];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double d = lane_bcast(a[j], j);
+    if (!(d > 0.0)) {
+      bad = true;
+      d = 1e-30;
+    }
+    const double rs = rsqrt(d);
+    rdiag[j] = rs;
+    const double lj = (r == j) ? d * rs : a[j] * rs;
+    a[j] = lj;
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) a[c] -= lj * lane_bcast(lj, c);
+  }
+  if (bad && lane == 0) g_sh.chol_bad = 1;
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) base[r * RS + c] = (c <= r) ? a[c] : 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  double x[16], b[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) b[rr] = (rr == r) ? 1.0 : 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    x[q] = (q >= r) ? b[q] * rdiag[q] : 0.0;
+#pragma unroll
+    for (int rr = q + 1; rr < 16; ++rr) b[rr] = fma(-base[rr * RS + q], x[q], b[rr]);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) dinv[c * 17 + r] = x[c];  // Dinv[c][r]: lane r holds column r
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Leader workgroup: factor the w x w (w = 16 nbk <= 64) diagonal block of panel column c0 in LDS, write L_pp, L_pp^T
+// and the Dinv blocks, then W = L_pp^-1 (and W^T) into LI / U through the 16-wide block recursion.
+__device__ __noinline__ void chol_diag_block(int c0, int w) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, nbk = w / 16;
+  constexpr int RS = NB + 1;
+  ldsd* blk = (ldsd*)g_sh.blk;
+  ldsd* dinv = (ldsd*)g_sh.dinv;
+  gd* L = f.mat[B_L];
+  gd* LT = f.mat[B_LT];
+  gd* LI = f.mat[B_LI];
+  gd* U = f.mat[B_U];
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  for (int idx = threadIdx.x; idx < w * w; idx += NT) {
+    const int i = idx / w, j = idx - i * w;
+    blk[i * RS + j] = L[(size_t)(c0 + i) * Mp + c0 + j];
+  }
+  __syncthreads();
+  for (int kb = 0; kb < nbk; ++kb) {
+    if (wave == 0) {
+      diag16(blk, RS, kb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int idx = lane + 64 * e, rr = idx >> 4, cc = idx & 15;
+        const int blkid = c0 / 16 + kb;
+        f.dinv[(size_t)blkid * 256 + idx] = dinv[rr * 17 + cc];
+        f.dinvT[(size_t)blkid * 256 + idx] = dinv[cc * 17 + rr];
+      }
+    }
+    __syncthreads();
+    // rows below inside the block: P[i][c] = sum_{q <= c} S[i][16 kb + q] Dinv[c][q]
+    const int rows = w - 16 * (kb + 1);
+    for (int idx = threadIdx.x; idx < rows * 16; idx += NT) {
+      const int i = 16 * (kb + 1) + (idx >> 4), c = idx & 15;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += (q <= c) ? blk[i * RS + 16 * kb + q] * dinv[c * 17 + q] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();  // the 16 lanes of a row have read S before any overwrites it
+      blk[i * RS + 16 * kb + c] = acc;
+    }
+    __syncthreads();
+    // trailing update inside the block (lower part)
+    for (int idx = threadIdx.x; idx < rows * rows; idx += NT) {
+      const int i = 16 * (kb + 1) + idx / rows, j = 16 * (kb + 1) + idx % rows;
+      if (j <= i) {
+        double acc = blk[i * RS + j];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc = fma(-blk[i * RS + 16 * kb + c], blk[j * RS + 16 * kb + c], acc);
+        blk[i * RS + j] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < w * w; idx += NT) {
+    const int i = idx / w, j = idx - i * w;
+    L[(size_t)(c0 + i) * Mp + c0 + j] = (j <= i) ? blk[i * RS + j] : 0.0;
+    LT[(size_t)(c0 + i) * Mp + c0 + j] = (i <= j) ? blk[j * RS + i] : 0.0;
+  }
+  __syncthreads();
+  // W = L_pp^-1: block column k per wave;  W_kk = Dinv_k,  W_ik = -Dinv_i sum_{j=k}^{i-1} L_ij W_jk
+  const int b0 = c0 / 16;
+  if (wave < nbk) {
+    const int k = wave;
+    d4 blkv[NB / 16];
+    d4 dk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dk[r] = f.dinv[(size_t)(b0 + k) * 256 + (lq + 4 * r) * 16 + lr];
+    store_tile(dk, LI, U, Mp, c0 + 16 * k, c0 + 16 * k);
+    blkv[0] = dk;
+#pragma unroll
+    for (int ii = 1; ii < NB / 16; ++ii) {
+      const int i = k + ii;
+      if (i < nbk) {
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int jj = 0; jj < ii; ++jj) {
+          const ldsd* pa = blk + (16 * i + lr) * RS + 16 * (k + jj) + lq;  // L[16 i + lr][16 (k + jj) + 4 s + lq]
+#pragma unroll
+          for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * st], blkv[jj][st], acc, 0, 0, 0);
+        }
+        d4 out = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const double a = -f.dinvT[(size_t)(b0 + i) * 256 + (4 * st + lq) * 16 + lr];  // -Dinv_i[lr][4 st + lq]
+          out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[st], out, 0, 0, 0);
+        }
+        store_tile(out, LI, U, Mp, c0 + 16 * i, c0 + 16 * k);
+        blkv[ii] = out;
+      }
+    }
+  }
+  // blocks of W above the diagonal are zero in LI (lower) / below the diagonal in U
+  for (int idx = threadIdx.x; idx < w * w; idx += NT) {
+    const int i = idx / w, j = idx - i * w;
+    if ((j >> 4) > (i >> 4)) {
+      LI[(size_t)(c0 + i) * Mp + c0 + j] = 0.0;
+      U[(size_t)(c0 + j) * Mp + c0 + i] = 0.0;
+    }
+  }
+}
+
+// Kzz + jitter I (lower incl. diagonal; identity on the padded tail) into B_L, dealt to the whole cluster
+__device__ __noinline__ void build_kzz(double s, double inv_l2, double jitter) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, M = f.M, D = f.D;
+  gd* L = f.mat[B_L];
+  const long long n = (long long)Mp * Mp;
+  for (long long idx = cl_tid(); idx < n; idx += cl_threads()) {
+    const int i = (int)(idx / Mp), j = (int)(idx - (long long)i * Mp);
+    double v = 0.0;
+    if (i < M && j <= i) {
+      v = s * exp(-0.5 * inv_l2 * sqdist(f.Z + (size_t)i * D, f.Z + (size_t)j * D, D));
+      if (i == j) v += jitter;
+    } else if (i >= M && i == j) {
+      v = 1.0;
+    }
+    L[idx] = v;
+  }
+}
+
+// Right-looking blocked Cholesky of B_L (lower) -> L, L^T, Dinv blocks, and the panels' inverses in LI / U.
+__device__ __noinline__ void cholesky_cluster() {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp;
+  gd* L = f.mat[B_L];
+  gd* LT = f.mat[B_LT];
+  const gd* U = f.mat[B_U];
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  for (int c0 = 0; c0 < Mp; c0 += NB) {
+    const int w = (Mp - c0) < NB ? (Mp - c0) : NB, c1 = c0 + w;
+    // (a) leader: diagonal block
+    if (g_sh.g == 0) chol_diag_block(c0, w);
+    cbar();
+    if (c1 >= Mp) break;
+    // (b) panel below: L[i][c0 + c] = sum_q S[i][c0 + q] W[c][q],  W^T = U (rows q, contiguous in c)
+    {
+      const int cw = cl_wave(), CW = cl_waves();
+      const int row_tiles = (Mp - c1) / 16, wb = w / 16;
+      for (int t = cw; t < row_tiles * wb; t += CW) {
+        const int rt = t / wb, cb = t - rt * wb;
+        const int i0 = c1 + 16 * rt;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        // A operand straight from row-major S: A[i = lr][k = 4 st + lq]
+        const gd* pa = L + (size_t)(i0 + lr) * Mp + c0 + lq;
+        const gd* pb = U + (size_t)(c0 + lq) * Mp + c0 + 16 * cb + lr;
+        for (int q = 0; q <= cb; ++q) {  // W[c][q] = 0 for q-block > c-block
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[16 * q + 4 * st], pb[(size_t)(16 * q + 4 * st) * Mp], acc, 0, 0, 0);
+        }
+        // results go to L^T now and to L after every tile of this row block has read S (barrier below)
+        store_tile(acc, nullptr, LT, Mp, i0, c0 + 16 * cb);
+      }
+    }
+    cbar();
+    // L rows of the panel from L^T (the in-place overwrite of S must wait for all readers of the row block)
+    {
+      const long long n = (long long)(Mp - c1) * w;
+      for (long long idx = cl_tid(); idx < n; idx += cl_threads()) {
+        const int i = c1 + (int)(idx / w), c = c0 + (int)(idx % w);
+        L[(size_t)i * Mp + c] = LT[(size_t)c * Mp + i];
+      }
+    }
+    // (c) trailing update S[i][j] -= sum_{q in panel} L[i][q] L[j][q], lower 32 x 32 tiles (reads L^T only)
+    {
+      const gd* P = LT + c1;
+      gd* S = L + (size_t)c1 * Mp + c1;
+      const int mt = (Mp - c1) / 32;
+      gemm_tn<2, false>(mt, mt, true, P, P, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = c0; *hi = c1; },
+                        [=](int i, int j, const d4& v) {
+                          const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
+#pragma unroll
+                          for (int r = 0; r < 4; ++r) {
+                            gd* p = S + (size_t)(i + g4 + 4 * r) * Mp + j + c;
+                            *p = *p - v[r];
+                          }
+                        });
+    }
+    cbar();
+  }
+}
+
+// LI = L^-1 and U = LI^T from the panels' inverses by pairwise merging; KX serves as the temporary.
+__device__ __noinline__ void tri_inverse_cluster() {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp;
+  const gd* LT = f.mat[B_LT];
+  gd* LI = f.mat[B_LI];
+  gd* U = f.mat[B_U];
+  gd* Tm = f.mat[B_KX];
+  Shared& sh = g_sh;
+  for (int s = NB; s < Mp; s *= 2) {
+    // pairs [lo, mid) + [mid, hi) with lo a multiple of 2 s
+    int np = 0;
+    for (int lo = 0; lo + s < Mp; lo += 2 * s) ++np;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t0 = 0, k = 0;
+      for (int lo = 0; lo + s < Mp; lo += 2 * s, ++k) {
+        const int mid = lo + s, hi = (lo + 2 * s) < Mp ? (lo + 2 * s) : Mp;
+        sh.pr_lo[k] = lo; sh.pr_mid[k] = mid; sh.pr_hi[k] = hi; sh.pr_t0[k] = t0;
+        t0 += ((hi - mid) / 32) * (s / 32);
+      }
+      sh.pr_t0[k] = t0;
+    }
+    __syncthreads();
+    const int ntot = sh.pr_t0[np];
+    const int cw = cl_wave(), CW = cl_waves();
+    const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+    // two passes over the same tile enumeration: T = B A^-1, then X = -C^-1 T
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int t = cw; t < ntot; t += CW) {
+        int k = 0;
+        while (sh.pr_t0[k + 1] <= t) ++k;
+        const int lo = uni(sh.pr_lo[k]), mid = uni(sh.pr_mid[k]), hi = uni(sh.pr_hi[k]);
+        const int tl = t - uni(sh.pr_t0[k]);
+        const int nct = s / 32;
+        const int ti = tl / nct, tj = tl - ti * nct;
+        const int i0 = mid + 32 * ti, j0 = lo + 32 * tj;  // output tile rows in [mid, hi), columns in [lo, mid)
+        int klo, khi;
+        const gd *Pp, *Qp;
+        if (pass == 0) {  // T[i][j] = sum_k B[i][k] Ainv[k][j], k in [lo, mid): P[k][i] = LT[k][i], Q[k][j] = LI[k][j] (k >= j)
+          Pp = LT; Qp = LI; klo = j0; khi = mid;
+        } else {          // X[i][j] = -sum_k Cinv[i][k] T[k][j], k in [mid, hi): P[k][i] = U[k][i] (k <= i), Q = T
+          Pp = U; Qp = Tm; klo = mid; khi = i0 + 32;
+        }
+        d4 acc[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
+        const gd* pb = Pp + (size_t)lq * Mp + i0 + lr;
+        const gd* qb = Qp + (size_t)lq * Mp + j0 + lr;
+#pragma unroll 2
+        for (int kk = klo; kk < khi; kk += 4) {
+          const double a0 = pb[(size_t)kk * Mp], a1 = pb[(size_t)kk * Mp + 16];
+          const double b0 = qb[(size_t)kk * Mp], b1 = qb[(size_t)kk * Mp + 16];
+          acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            if (pass == 0) {
+              store_tile(acc[u][v], Tm, nullptr, Mp, i0 + 16 * u, j0 + 16 * v);
+            } else {
+              d4 neg;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) neg[r] = -acc[u][v][r];
+              store_tile(neg, LI, U, Mp, i0 + 16 * u, j0 + 16 * v);
+            }
+          }
+      }
+      cbar();
+    }
+  }
+}
+
+// KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for k < M, n < ncols, zero elsewhere
+__device__ __noinline__ void build_kx(const gd* pts, int ncols, double s, double inv_l2) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, M = f.M, D = f.D;
+  gd* KX = f.mat[B_KX];
+  const long long n = (long long)Mp * Mp;
+  for (long long idx = cl_tid(); idx < n; idx += cl_threads()) {
+    const int k = (int)(idx / Mp), c = (int)(idx - (long long)k * Mp);
+    double v = 0.0;
+    if (k < M && c < ncols) v = s * exp(-0.5 * inv_l2 * sqdist(f.Z + (size_t)k * D, pts + (size_t)c * D, D));
+    KX[idx] = v;
+  }
+}
+
+// Stage 1 of the ordered column sums: plane p of the scratch gets, for row group rg and column c,
+//   sum over rows r = rg, rg + RG, ... of term(r, c).  RG = max(1, CT / Mp); a column's partials are summed in
+//   row-group order by col_final.  The scratch plane holds RG * Mp <= max(CT, Mp) doubles.
+template <typename Term>
+__device__ inline void col_partials(int plane, int Mp, Term term) {
+  const int CT = cl_threads(), ct = cl_tid();
+  const int RG = CT / Mp > 0 ? CT / Mp : 1;
+  gd* out = g_sh.f.part + (size_t)plane * (Mp > kClMaxThreads ? Mp : kClMaxThreads);
+  if (CT >= Mp) {
+    const int rg = ct / Mp, c = ct - rg * Mp;
+    if (rg < RG) {
+      double acc = 0.0;
+      for (int r = rg; r < Mp; r += RG) acc += term(r, c);
+      out[(size_t)rg * Mp + c] = acc;
+    }
+  } else {
+    for (int c = ct; c < Mp; c += CT) {
+      double acc = 0.0;
+      for (int r = 0; r < Mp; ++r) acc += term(r, c);
+      out[c] = acc;
+    }
+  }
+}
+__device__ inline double col_final(int plane, int Mp, int c) {
+  const int CT = cl_threads();
+  const int RG = CT / Mp > 0 ? CT / Mp : 1;
+  const gd* in = g_sh.f.part + (size_t)plane * (Mp > kClMaxThreads ? Mp : kClMaxThreads);
+  double acc = 0.0;
+  for (int rg = 0; rg < RG; ++rg) acc += in[(size_t)rg * Mp + c];
+  return acc;
+}
+
+// A = LI KX (+ A^T), B^T = A^T LS (+ B) over the first `ncols` columns, then the column partials of mu and var
+__device__ __noinline__ void forward_products(int ncols) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp;
+  const int mt = Mp / 32, nt = (ncols + 31) / 32;
+  gd* A = f.mat[B_A];
+  gd* AT = f.mat[B_AT];
+  gd* BM = f.mat[B_BM];
+  gd* BMT = f.mat[B_BMT];
+  const gd* vm = f.vec[V_M];
+  gemm_tn<2, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+                    [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+                    [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n); });
+  cbar();
+  gemm_tn<2, false>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
+                    [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                    [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j); });
+  cbar();
+  col_partials(0, Mp, [=](int r, int c) { return vm[r] * A[(size_t)r * Mp + c]; });
+  col_partials(1, Mp, [=](int r, int c) {
+    const double a = A[(size_t)r * Mp + c], b = BM[(size_t)r * Mp + c];
+    return b * b - a * a;
+  });
+  cbar();
+}
+
+__device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& desc, float* __restrict__ o_probs,
+                         float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
+                         float* __restrict__ o_mu, float* __restrict__ o_var, double* loss_out) {
+  const Fit& f = g_sh.f;
+  Shared& sh = g_sh;
+  const int M = f.M, Mp = f.Mp, D = f.D, T = f.T;
+  const int mt = Mp / 32;
+  const double Nd = (double)M;
+  const double jitter = opt.jitter;
+  gd* LS = f.mat[B_LS];
+  gd* LST = f.mat[B_LST];
+  gd* MLS = f.mat[B_MLS];
+  gd* VLS = f.mat[B_VLS];
+  gd* GLS = f.mat[B_GLS];
+  gd* A = f.mat[B_A];
+  gd* AT = f.mat[B_AT];
+  gd* BM = f.mat[B_BM];
+  gd* BMT = f.mat[B_BMT];
+  gd* GA = f.mat[B_GA];
+  gd* GKX = f.mat[B_GKX];
+  gd* GKXT = f.mat[B_GKXT];
+  gd* KX = f.mat[B_KX];
+  gd* vm = f.vec[V_M];
+  gd* gmu = f.vec[V_GMU];
+  gd* gv = f.vec[V_GV];
+  const int ct = cl_tid(), CT = cl_threads();
+  double last_loss = 0.0;
+
+  auto refresh_hypers = [&]() {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      sh.s = softplus(sh.rho_s);
+      sh.ell = softplus(sh.rho_l);
+      sh.inv_l2 = 1.0 / (sh.ell * sh.ell);
+    }
+    __syncthreads();
+  };
+  // gpytorch's psd_safe_cholesky around the factorisation (see svgp_fit.hip: cholesky_psd_safe)
+  auto factorize = [&]() {
+    double extra = 0.0;
+    for (int attempt = 0;; ++attempt) {
+      build_kzz(sh.s, sh.inv_l2, jitter + extra);
+      cbar();
+      cholesky_cluster();
+      // the leader's flag -> everybody (one ordered sum)
+      double bad[1] = {(threadIdx.x == 0 && sh.g == 0 && sh.chol_bad) ? 1.0 : 0.0};
+      cl_reduce(bad);
+      if (threadIdx.x == 0) sh.chol_bad = 0;
+      __syncthreads();
+      if (bad[0] == 0.0) break;
+      if (attempt >= opt.psd_retries) {
+        if (threadIdx.x == 0) sh.status = GAPRO_ERR_CHOLESKY;
+        break;
+      }
+      extra = opt.psd_jitter * pow(10.0, (double)attempt);
+    }
+    tri_inverse_cluster();
+  };
+
+  for (int step = 1; step <= opt.training_iter; ++step) {
+    refresh_hypers();
+    const double s = sh.s, ell = sh.ell, inv_l2 = sh.inv_l2, c = sh.c;
+    // ------------------------------- forward -------------------------------
+    factorize();
+    build_kx(f.X, M, s, inv_l2);
+    cbar();
+    forward_products(M);
+    // quadrature: thread per training point (final column sums, then the 20-point rule)
+    double sums[4] = {0.0, 0.0, 0.0, 0.0};  // E, g_c, gv_sum, KL part
+    for (int n = ct; n < Mp; n += CT) {
+      double g1 = 0.0, g2 = 0.0;
+      if (n < M) {
+        const double mu = col_final(0, Mp, n) + c;
+        const double vraw = s + jitter + col_final(1, Mp, n);
+        const bool clamped = vraw < opt.min_variance;
+        const double var = clamped ? opt.min_variance : vraw;
+        const double sd = sqrt(2.0 * var);
+        const double y = f.vec[V_Y][n];
+        double E = 0.0, dmu = 0.0, dvar = 0.0;
+        for (int q = 0; q < NGH / 2; ++q) {
+          const double t = c_gh_t[q], w = c_gh_w[q];
+          double lp, r;
+          log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
+          E += w * lp; dmu += w * r; dvar -= w * t * r;
+          log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
+          E += w * lp; dmu += w * r; dvar += w * t * r;
+        }
+        const double ipi = 0.56418958354775628695;
+        sums[0] += ipi * E;
+        g1 = -(ipi * dmu * y) / Nd;
+        g2 = clamped ? 0.0 : -(ipi * dvar * y / sd) / Nd;
+      }
+      gmu[n] = g1;
+      gv[n] = g2;
+      sums[1] += g1;
+      sums[2] += g2;
+    }
+    {
+      const long long n = (long long)M * M;
+      for (long long idx = ct; idx < n; idx += CT) {
+        const int i = (int)(idx / M), j = (int)(idx - (long long)i * M);
+        if (j <= i) {
+          const double v = LS[(size_t)i * Mp + j];
+          sums[3] += v * v;
+          if (i == j) sums[3] -= log(v * v);
+        }
+      }
+      for (int i = ct; i < M; i += CT) sums[3] += vm[i] * vm[i];
+    }
+    cl_reduce(sums);  // includes a cluster barrier: gmu / gv are visible to everybody behind it
+    const double g_c = sums[1], gv_sum = sums[2];
+    last_loss = -(sums[0] / Nd - 0.5 * (sums[3] - Nd) / Nd);
+
+    // ------------------------------- backward ------------------------------
+    // G_m partials (through A^T), G_A and G_LS are independent: one barrier behind the three
+    col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
+    gemm_tn<2, false>(mt, mt, false, LST, BM, Mp, nullptr,
+                      [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+                      [=](int i0, int n0, const d4& v) {
+                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+                        const int n = n0 + lr;
+                        const double gvn = gv[n], gmn = gmu[n];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                          const int i = i0 + lq + 4 * r;
+                          const double a = A[(size_t)i * Mp + n];
+                          GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
+                        }
+                      });
+    gemm_tn<2, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+                     [=](int i0, int j0, const d4& v) {
+                       const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+                       const int j = j0 + lr;
+#pragma unroll
+                       for (int r = 0; r < 4; ++r) {
+                         const int i = i0 + lq + 4 * r;
+                         double g = 0.0;
+                         if (j <= i && i < M) {
+                           const double l = LS[(size_t)i * Mp + j];
+                           g = 2.0 * v[r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+                         }
+                         GLS[(size_t)i * Mp + j] = g;
+                       }
+                     });
+    cbar();
+    // G_KX = LI^T G_A
+    gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
+                      [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                      [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
+    cbar();
+    // G_L = -tril(G_KX A^T) -> BM buffer
+    gd* GL = BM;
+    gemm_tn<2, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+                      [=](int i0, int j0, const d4& v) {
+                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                          const int i = i0 + lq + 4 * r, j = j0 + lr;
+                          GL[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
+                        }
+                      });
+    cbar();
+    // Pm = Phi(tril(L^T G_L)) -> GA buffer
+    gd* Pm = GA;
+    gemm_tn<2, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
+                      [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                      [=](int i0, int j0, const d4& v) {
+                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                          const int i = i0 + lq + 4 * r, j = j0 + lr;
+                          Pm[(size_t)i * Mp + j] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                        }
+                      });
+    cbar();
+    // T1 = LI^T Pm, stored transposed -> BMT buffer
+    gd* T1T = BMT;
+    gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+                      [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
+                      [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j); });
+    cbar();
+    // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer
+    gd* G = BM;
+    gd* GT = GKXT;
+    gemm_tn<2, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+                      [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                      [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j); });
+    cbar();
+    // kernel weights in place: Wzz = sym(G) o K -> G, Wzx = G_KX o KX -> GKX; scalar sums for d/ds and d/dl
+    double ks[2] = {0.0, 0.0};
+    {
+      const long long n = (long long)M * M;
+      for (long long idx = ct; idx < n; idx += CT) {
+        const int i = (int)(idx / M), j = (int)(idx - (long long)i * M);
+        const size_t o = (size_t)i * Mp + j;
+        const double d2 = sqdist(f.Z + (size_t)i * D, f.Z + (size_t)j * D, D);
+        const double e = exp(-0.5 * inv_l2 * d2);
+        const double gsym = 0.5 * (G[o] + GT[o]);
+        const double w = gsym * s * e;
+        ks[0] += gsym * e;
+        ks[1] += w * d2;
+        const double d2x = sqdist(f.Z + (size_t)i * D, f.X + (size_t)j * D, D);
+        const double kx = KX[o];
+        const double gk = GKX[o];
+        ks[0] += gk * kx / s;
+        ks[1] += gk * kx * d2x;
+        GA[o] = w;        // Wzz -> GA buffer (G and G^T are still being read by other threads)
+        A[o] = gk * kx;   // Wzx -> A buffer
+      }
+    }
+    cl_reduce(ks);
+    const double g_s = ks[0] + gv_sum;
+    const double g_l = ks[1] / (ell * ell * ell);
+    // G_Z[i][d] = -(1/l^2) ( sum_j 2 Wzz[i][j] (Z_i - Z_j)[d] + sum_n Wzx[i][n] (Z_i - X_n)[d] )
+    {
+      const gd* Wzz = GA;
+      const gd* Wzx = A;
+      for (int idx = ct; idx < M * D; idx += CT) {
+        const int i = idx / D, d = idx - i * D;
+        const double zi = f.Z[(size_t)i * D + d];
+        const gd* wz = Wzz + (size_t)i * Mp;
+        const gd* wx = Wzx + (size_t)i * Mp;
+        double acc = 0.0;
+        for (int j = 0; j < M; ++j)
+          acc += 2.0 * wz[j] * (zi - f.Z[(size_t)j * D + d]) + wx[j] * (zi - f.X[(size_t)j * D + d]);
+        f.gZ[idx] = -inv_l2 * acc;
+      }
+    }
+    cbar();  // every G_Z entry is computed from the OLD Z before anybody updates Z
+
+    // ------------------------------- Adam ----------------------------------
+    const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
+    const double step_size = opt.lr / bc1;
+    auto adam = [&](double p, double& m1, double& m2, double g) {
+      m1 = b1 * m1 + (1.0 - b1) * g;
+      m2 = b2 * m2 + (1.0 - b2) * g * g;
+      return p - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+    };
+    for (int idx = ct; idx < M * D; idx += CT) {
+      double m1 = f.mZ[idx], m2 = f.vZ[idx];
+      f.Z[idx] = adam(f.Z[idx], m1, m2, f.gZ[idx]);
+      f.mZ[idx] = m1;
+      f.vZ[idx] = m2;
+    }
+    for (int i = ct; i < M; i += CT) {
+      const double g = col_final(2, Mp, i) + vm[i] / Nd;
+      f.vec[V_GM][i] = g;
+      double m1 = f.vec[V_MM][i], m2 = f.vec[V_VM][i];
+      vm[i] = adam(vm[i], m1, m2, g);
+      f.vec[V_MM][i] = m1;
+      f.vec[V_VM][i] = m2;
+    }
+    {
+      const long long n = (long long)M * M;
+      for (long long idx = ct; idx < n; idx += CT) {
+        const int i = (int)(idx / M), j = (int)(idx - (long long)i * M);
+        if (j <= i) {
+          const size_t o = (size_t)i * Mp + j;
+          double m1 = MLS[o], m2 = VLS[o];
+          const double lnew = adam(LS[o], m1, m2, GLS[o]);
+          MLS[o] = m1;
+          VLS[o] = m2;
+          LS[o] = lnew;
+          LST[(size_t)j * Mp + i] = lnew;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // every workgroup keeps the scalars and applies the same update
+      sh.c = adam(sh.c, sh.mc, sh.vc, g_c);
+      sh.rho_s = adam(sh.rho_s, sh.mrs, sh.vrs, g_s * sigmoid(sh.rho_s));
+      sh.rho_l = adam(sh.rho_l, sh.mrl, sh.vrl, g_l * sigmoid(sh.rho_l));
+    }
+    cbar();
+  }
+
+  // ------------------------------- prediction ------------------------------
+  refresh_hypers();
+  if (!(opt.eval_stale_chol && opt.training_iter > 0)) factorize();
+  const double s = sh.s, inv_l2 = sh.inv_l2, c = sh.c;
+  for (int t0 = 0; t0 < T; t0 += Mp) {
+    const int nc = (T - t0) < Mp ? (T - t0) : Mp;
+    build_kx(f.Xt + (size_t)t0 * D, nc, s, inv_l2);
+    cbar();
+    forward_products(nc);
+    for (int n = ct; n < nc; n += CT) {
+      const double mu = col_final(0, Mp, n) + c;
+      const double var = fmax(s + jitter + col_final(1, Mp, n), opt.min_variance);
+      const double p = 0.5 * erfc(-(mu / sqrt(1.0 + var)) * 0.70710678118654752440);
+      const float pf = (float)p;                       // pred_probs            :432
+      const bool lab = pf >= 0.5f;                     // pred_labels           :433
+      const long long o = desc.out_offset + t0 + n;
+      o_probs[o] = pf;
+      o_probs_new[o] = lab ? pf : 1.0f - pf;           // pred_probs_new        :438
+      o_labels[o] = lab ? 1 : 0;
+      o_mu[o] = (float)mu;                             // pred_mu               :435
+      o_var[o] = (float)var;                           // pred_variance         :436
+      if ((!isfinite(mu) || !isfinite(var)) && sh.status == GAPRO_OK) sh.status = GAPRO_ERR_NOT_FINITE;
+    }
+    cbar();
+  }
+  // status of the cluster = the first error any member saw
+  double st[1] = {(threadIdx.x == 0 && sh.status != GAPRO_OK) ? (double)(-sh.status) : 0.0};
+  {
+    // max over members, through an ordered sum of one-hot encodings would be overkill: errors are rare -> reduce sum
+    cl_reduce(st);
+  }
+  if (sh.g == 0 && threadIdx.x == 0) {
+    if (sh.status == GAPRO_OK && st[0] != 0.0) sh.status = GAPRO_ERR_NOT_FINITE;
+    f.scal[S_C] = sh.c;
+    f.scal[S_RS] = sh.rho_s;
+    f.scal[S_RL] = sh.rho_l;
+    f.scal[S_MC] = sh.mc; f.scal[S_VC] = sh.vc;
+    f.scal[S_MRS] = sh.mrs; f.scal[S_VRS] = sh.vrs;
+    f.scal[S_MRL] = sh.mrl; f.scal[S_VRL] = sh.vrl;
+    f.scal[S_LOSS] = last_loss;
+    *loss_out = last_loss;
+  }
+}
+
+struct ClBlock {
+  int fit;  // index into the launch's descriptor array, -1 = padding block
+  int g, G;
+  int ctl;  // index of the cluster's barrier counter
+};
+
+__global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __restrict__ blocks, int D,
+                                                          const float* __restrict__ feats_spp,
+                                                          const int* __restrict__ idx,
+                                                          const gapro_fit_desc* __restrict__ descs,
+                                                          const double* __restrict__ init_mean, gapro_fit_options opt,
+                                                          double* __restrict__ ws, unsigned* __restrict__ ctl,
+                                                          float* __restrict__ o_probs, float* __restrict__ o_probs_new,
+                                                          unsigned char* __restrict__ o_labels, float* __restrict__ o_mu,
+                                                          float* __restrict__ o_var, int* __restrict__ o_status,
+                                                          double* __restrict__ o_loss) {
+  const ClBlock cb = blocks[blockIdx.x];
+  if (cb.fit < 0) return;
+  const gapro_fit_desc desc = descs[cb.fit];
+  Shared& sh = g_sh;
+  Fit& f = sh.f;
+  const Layout lay = make_layout(desc.m1 + desc.m2, desc.t, D);
+  gd* base = (gd*)(ws + desc.ws_offset);
+  if (threadIdx.x == 0) {
+    f.M = desc.m1 + desc.m2;
+    f.T = desc.t;
+    f.D = D;
+    f.Mp = lay.Mp;
+    for (int b = 0; b < B_COUNT; ++b) f.mat[b] = base + lay.mat + (long long)b * lay.Mp * lay.Mp;
+    for (int v = 0; v < V_COUNT; ++v) f.vec[v] = base + lay.vec + (long long)v * lay.Mp;
+    f.X = base + lay.xz;
+    f.Z = f.X + (long long)lay.Mp * D;
+    f.mZ = f.Z + (long long)lay.Mp * D;
+    f.vZ = f.mZ + (long long)lay.Mp * D;
+    f.gZ = f.vZ + (long long)lay.Mp * D;
+    f.Xt = base + lay.xt;
+    f.dinv = base + lay.dinv;
+    f.dinvT = f.dinv + (long long)lay.Mp * 16;
+    f.scal = base + lay.scal;
+    f.part = base + lay.cl;
+    f.red = f.part + 3LL * (lay.Mp > kClMaxThreads ? lay.Mp : kClMaxThreads);
+    sh.G = cb.G;
+    sh.g = cb.g;
+    sh.epoch = 0;
+    sh.red_par = 0;
+    sh.count = (gu32*)(ctl + (size_t)cb.ctl * 32);
+    sh.c = sh.rho_s = sh.rho_l = 0.0;
+    sh.mc = sh.vc = sh.mrs = sh.vrs = sh.mrl = sh.vrl = 0.0;
+    sh.status = GAPRO_OK;
+    sh.chol_bad = 0;
+  }
+  __syncthreads();
+  const int M = f.M, Mp = f.Mp;
+  const int ct = cl_tid(), CT = cl_threads();
+  // zero everything the kernel reads before writing (parameters / Adam state, padded operand tails)
+  for (long long i = ct; i < lay.total; i += CT) base[i] = 0.0;
+  cbar();
+  const int* my_idx = idx + desc.idx_offset;
+  for (int e = ct; e < M * D; e += CT) {
+    const int i = e / D, d = e - i * D;
+    const double v = (double)feats_spp[(size_t)my_idx[i] * D + d];  // train_x = cat(b1_feats, b2_feats)  :395
+    f.X[e] = v;
+    f.Z[e] = v;  // inducing points initialised to train_x  (:14)
+  }
+  for (int e = ct; e < f.T * D; e += CT) {
+    const int i = e / D, d = e - i * D;
+    f.Xt[e] = (double)feats_spp[(size_t)my_idx[M + i] * D + d];  // intersect_feats  :386
+  }
+  for (int i = ct; i < M; i += CT) {
+    f.vec[V_Y][i] = i < desc.m1 ? -1.0 : 1.0;  // train_y  :396-398
+    f.vec[V_M][i] = init_mean ? init_mean[desc.idx_offset + i] : 0.0;
+    f.mat[B_LS][(size_t)i * Mp + i] = 1.0;  // chol_variational_covar = I
+    f.mat[B_LST][(size_t)i * Mp + i] = 1.0;
+  }
+  cbar();
+  fit_body(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+  __syncthreads();
+  if (sh.g == 0 && threadIdx.x == 0) {
+    int st = sh.status;
+    if (st == GAPRO_OK && !isfinite(o_loss[desc.slot]) && opt.training_iter > 0) st = GAPRO_ERR_NOT_FINITE;
+    o_status[desc.slot] = st;
+    f.scal[S_STATUS] = (double)st;
+  }
+}
+
+}  // namespace
+
+// Workgroups a fit of padded size Mp is spread over: the fit's work grows with Mp^3 while a launch's other fits
+// finish in a fraction of a second, so the largest fits get the most CUs (powers of two, at most kClMaxG).
+int gapro_cluster_size(int Mp) {
+  if (Mp < kClusterMinMp) return 1;
+  const double work = (double)Mp * Mp * Mp / (384.0 * 384.0 * 384.0);  // 1 CU up to ~ M = 384
+  int g = 1;
+  while (g < kClMaxG && (double)g < work) g *= 2;
+  return g;
+}
+
+// Internal launcher used by gapro_svgp_fit_batch (svgp_fit.hip).  `fits` = the n cluster fits' indices into the device
+// descriptor array d_descs (already uploaded), with their padded sizes; h_stage / d_stage: staging for the block
+// table (>= bytes returned by gapro_cluster_stage_bytes), d_ctl: >= 128 bytes per fit, zeroed here.
+size_t gapro_cluster_stage_bytes(int n_fits) { return (size_t)n_fits * kClMaxG * sizeof(ClBlock) + 8 * kClMaxG * sizeof(ClBlock); }
+
+int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, const int* fit_mp, const int* fit_g,
+                             int feat_dim, void* h_stage, void* d_stage, unsigned* d_ctl, const float* d_feats_spp,
+                             const int* d_idx, const gapro_fit_desc* d_descs, const double* d_init_mean,
+                             const gapro_fit_options& opt, double* d_workspace, float* d_probs, float* d_probs_new,
+                             unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss) {
+  if (n <= 0) return GAPRO_OK;
+  // windows of 8 clusters (one per XCD label): block base + 8 j + x is member j of the window's x-th cluster
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return fit_g[a] != fit_g[b] ? fit_g[a] > fit_g[b] : fit_mp[a] > fit_mp[b];
+  });
+  ClBlock* hb = (ClBlock*)h_stage;
+  int nb = 0;
+  for (int w0 = 0; w0 < n; w0 += 8) {
+    const int cnt = std::min(8, n - w0);
+    const int Gw = fit_g[order[w0]];
+    for (int j = 0; j < Gw; ++j)
+      for (int x = 0; x < 8; ++x) {
+        ClBlock b;
+        b.fit = -1; b.g = 0; b.G = 0; b.ctl = 0;
+        if (x < cnt) {
+          const int fi = order[w0 + x];
+          if (j < fit_g[fi]) {
+            b.fit = fit_index[fi];
+            b.g = j;
+            b.G = fit_g[fi];
+            b.ctl = w0 + x;
+          }
+        }
+        hb[nb++] = b;
+      }
+  }
+  if (hipMemsetAsync(d_ctl, 0, (size_t)n * 128, stream) != hipSuccess) return GAPRO_ERR_HIP;
+  if (hipMemcpyAsync(d_stage, h_stage, (size_t)nb * sizeof(ClBlock), hipMemcpyHostToDevice, stream) != hipSuccess)
+    return GAPRO_ERR_HIP;
+  hipLaunchKernelGGL(k_svgp_fit_cluster, dim3(nb), dim3(NT), 0, stream, (const ClBlock*)d_stage, feat_dim, d_feats_spp,
+                     d_idx, d_descs, d_init_mean, opt, d_workspace, d_ctl, d_probs, d_probs_new, d_labels, d_mu, d_var,
+                     d_fit_status, d_fit_loss);
+  return hipGetLastError() == hipSuccess ? GAPRO_OK : GAPRO_ERR_HIP;
+}

@@ -27,8 +27,10 @@
 #include <math.h>
 
 #include "common.h"
+#include "fit_layout.h"
 
 namespace {
+using namespace gapro_fit;
 
 constexpr int NT = 512;       // threads per fit
 constexpr int NW = NT / 64;   // waves per fit
@@ -46,38 +48,10 @@ __constant__ double c_gh_w[10] = {0.4622436696006101,     0.28667550536283415,  
                                   7.80255647853206e-06,   1.0860693707692782e-07, 4.3993409922731747e-10,
                                   2.2293936455341447e-13};
 
-inline __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
 // ---- workspace layout (doubles) -------------------------------------------------------------------
-enum MatId {
-  B_LS = 0, B_LST, B_MLS, B_VLS, B_GLS, B_L, B_LT, B_LI, B_U, B_KX, B_A, B_AT, B_BM, B_BMT, B_GA, B_GKX, B_GKXT,
-  B_COUNT
-};
-enum VecId { V_Y = 0, V_M, V_MM, V_VM, V_GM, V_MU, V_VAR, V_GMU, V_GV, V_COUNT };
-constexpr int kScalars = 64;
+// (enums, Layout and make_layout: fit_layout.h, shared by every fit kernel)
 
-struct Layout {
-  int Mp, Tp, D;
-  long long mat, vec, xz, xt, dinv, scal, total;
-};
-inline __host__ __device__ Layout make_layout(int m, int t, int d) {
-  Layout L;
-  L.Mp = gapro_pad_m(m);
-  L.Tp = round_up(t > 0 ? t : 1, 32);
-  L.D = d;
-  L.mat = 0;
-  L.vec = L.mat + (long long)B_COUNT * L.Mp * L.Mp;
-  L.xz = L.vec + (long long)V_COUNT * L.Mp;
-  L.xt = L.xz + 5LL * L.Mp * d;  // X, Z, mZ, vZ, gZ
-  L.dinv = L.xt + (long long)L.Tp * d;
-  L.scal = L.dinv + 2LL * L.Mp * 16;  // Dinv and Dinv^T blocks
-  L.total = L.scal + kScalars;
-  L.total = (L.total + 1) / 2 * 2;
-  return L;
-}
-
-// scalars kept in the workspace tail (also visible to tests)
-enum ScalId { S_C = 0, S_RS, S_RL, S_MC, S_MRS, S_MRL, S_VC, S_VRS, S_VRL, S_LOSS, S_STATUS };
 
 struct Fit {
   int M, T, D, Mp;
@@ -743,7 +717,7 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
       o_labels[o] = lab ? 1 : 0;
       o_mu[o] = (float)mu;                             // pred_mu               :435
       o_var[o] = (float)var;                           // pred_variance         :436
-      if (!isfinite(mu) || !isfinite(var)) sh.status = GAPRO_ERR_NOT_FINITE;
+      if ((!isfinite(mu) || !isfinite(var)) && sh.status == GAPRO_OK) sh.status = GAPRO_ERR_NOT_FINITE;  // first error wins
     }
     __syncthreads();
   }

@@ -161,21 +161,23 @@ class FitTiming:
     """Device-side timing of one fit launch (gapro_fit_timing): HIP events recorded by the library on the
     streams its kernels run on.  read() blocks until the launch has finished."""
 
-    def __init__(self, ctx, handle, flops_strip, flops_staged, flops_small, m):
+    def __init__(self, ctx, handle, flops_strip, flops_staged, flops_small, m, flops_cluster=0.0):
         self.ctx, self.handle = ctx, handle
         self.flops_strip, self.flops_staged, self.flops_small, self.m = flops_strip, flops_staged, flops_small, m
+        self.flops_cluster = flops_cluster
         self.ms = None
 
     @property
     def flops(self):
-        return self.flops_strip + self.flops_staged + self.flops_small
+        return self.flops_strip + self.flops_staged + self.flops_small + self.flops_cluster
 
     def read(self):
-        """(staged kernel ms, strip kernel ms, first start -> last end ms, small-fit strip kernel ms)"""
+        """(staged kernel ms, strip kernel ms, first start -> last end ms, small-fit strip kernel ms, cluster kernel
+        ms)"""
         if self.ms is None:
-            out = (C.c_float * 4)()
+            out = (C.c_float * 5)()
             self.ctx.check(self.ctx.lib.gapro_fit_timing_read(self.ctx.handle, self.handle, out))
-            self.ms = (float(out[0]), float(out[1]), float(out[2]), float(out[3]))
+            self.ms = (float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]))
             self.ctx.lib.gapro_fit_timing_destroy(self.handle)
             self.handle = None
         return self.ms
@@ -727,13 +729,17 @@ class Pipeline:
             route = {int(v): int(lib.gapro_fit_route(int(v), D)) for v in np.unique(m)}
             flags = int(self.opt.reserved)
             r = np.array([route[int(v)] for v in m])
+            if flags & 8:  # no cluster kernel: those fits run where they ran in round 1
+                for v in np.unique(m[r == 4]):
+                    r[m == v] = 1 if int(v) <= 512 and D <= 32 else 2
             if flags & 4:
                 r[r == 3] = 0
             if flags & 1:
                 r[(r == 0) | (r == 3)] = 1
-            is_strip, is_small = r == 0, r == 3
-            self.fit_events.append(FitTiming(ctx, tm, float(each[is_strip].sum()), float(each[~(is_strip | is_small)].sum()),
-                                             float(each[is_small].sum()), m))
+            is_strip, is_small, is_clus = r == 0, r == 3, r == 4
+            self.fit_events.append(FitTiming(ctx, tm, float(each[is_strip].sum()),
+                                             float(each[~(is_strip | is_small | is_clus)].sum()),
+                                             float(each[is_small].sum()), m, float(each[is_clus].sum())))
             self.last_fit_m = m
         # results travel to pinned host memory on the same stream; nobody waits here
         h_out = self._pinned(slot + "fit_out", no * 17)

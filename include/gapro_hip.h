@@ -311,7 +311,8 @@ typedef struct {
                                 1 = reuse the factor of the last training step */
   int32_t reserved;          /* 0; debug bits: 1 = never route a fit to the strip-streaming kernels,
                               * 2 = launch the fit kernels on the caller's stream (not the fit streams),
-                              * 4 = no small-fit kernel (M_p <= 64 runs the 512-thread strip kernel) */
+                              * 4 = no small-fit kernel (M_p <= 64 runs the 512-thread strip kernel),
+                              * 8 = no cluster kernel (large fits stay on one workgroup) */
   int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive
                               *      pivot is repeated on K + psd_jitter 10^i I, i < psd_retries (psd_safe_cholesky,
                               *      reached from gaussian_process_utils.py:417); 0 = fail at once */
@@ -353,20 +354,21 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t f
 
 /* Which kernel gapro_svgp_fit_batch routes a fit of m = m1 + m2 inducing points to: 0 = strip-streaming
  * kernel (64 < M_p <= 128), 1 = LDS-staged kernel, 2 = generic kernel (working set beyond LDS), 3 = the
- * small-fit strip kernel (M_p <= 64: 256 threads per fit, two fits per CU).  M_p = m padded to the MFMA tile. */
+ * small-fit strip kernel (M_p <= 64: 256 threads per fit, two fits per CU), 4 = the cluster kernel (M_p > 384: one
+ * fit spread over 2..32 workgroups with cluster barriers).  M_p = m padded to the MFMA tile. */
 int gapro_fit_route(int32_t m, int32_t feat_dim);
 
 /* Optional device-side timing of one fit launch (bench.py's roofline figure).  gapro_svgp_fit_batch runs
- * its kernels on streams the context owns (staged, strip and small-fit strip kernel side by side), so events
- * on the caller's stream do not bracket them.  An armed timing object makes the NEXT gapro_svgp_fit_batch
+ * its kernels on streams the context owns (cluster, staged, strip and small-fit strip kernel side by side), so
+ * events on the caller's stream do not bracket them.  An armed timing object makes the NEXT gapro_svgp_fit_batch
  * record HIP events around each kernel on the stream it is launched on.  gapro_fit_timing_read blocks until
- * that launch has finished: out_ms4 = {staged (+ generic) kernel ms, strip kernel ms, first start -> last end
- * ms, small-fit strip kernel ms}; a kernel that was not launched reads 0. */
+ * that launch has finished: out_ms5 = {staged (+ generic) kernel ms, strip kernel ms, first start -> last end
+ * ms, small-fit strip kernel ms, cluster kernel ms}; a kernel that was not launched reads 0. */
 typedef struct gapro_fit_timing gapro_fit_timing;
 int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out);
 void gapro_fit_timing_destroy(gapro_fit_timing* t);
 int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t);
-int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms4);
+int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5);
 
 /* ------------------------------------------------------------------------------------------
  * Debug / test entry points (not needed by a caller of the path).

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two GP problems cut out of the S3DIS-shaped scene of tests/test_pipeline_gpu.py::test_s3dis_shaped_scene_matches_oracle
-(BASELINE configs[3]), as data: tests/golden/s3dis_fits.npz.
+(BASELINE configs[3]), as data: tests/golden/fits_s3dis.npz.
 
     python tests/golden/make_s3dis_fits.py      (about a minute: builds the 1M-point scene and its schedule)
 
@@ -47,7 +47,7 @@ def main():
         m = so.svgp_fit_predict_manual(X, y, Xt, 50)
         rec[tag + "_drift"] = np.array([np.max(np.abs(a[1] - m[1]) / a[1]), np.max(np.abs(a[2] - m[2]))])
         print(tag, i, rec[tag + "_m1"] + rec[tag + "_m2"], rec[tag + "_t"], rec[tag + "_drift"])
-    np.savez_compressed(os.path.join(HERE, "s3dis_fits.npz"), **rec)
+    np.savez_compressed(os.path.join(HERE, "fits_s3dis.npz"), **rec)
 
 
 if __name__ == "__main__":

@@ -67,33 +67,73 @@ def test_fit_matches_oracle(m1, m2, t, d, iters):
     _compare(out, _oracle(feats, b1, b2, it, iters))
 
 
-@pytest.mark.parametrize("m1,m2,t,iters", [(150, 170, 60, 50), (260, 270, 90, 5)])
-def test_fit_large_inducing_sets(m1, m2, t, iters):
-    """BASELINE configs[3] territory (large overlap regions): M_p = 320 runs the LDS-staged kernel, M_p = 544 is
-    beyond it and runs the generic (all-in-global-memory) kernel."""
-    import ctypes as C
+@pytest.mark.parametrize("m1,m2,t,iters,route", [(150, 170, 60, 50, 1), (200, 210, 90, 50, 4), (260, 270, 90, 50, 4),
+                                                  (340, 360, 50, 50, 4), (260, 270, 90, 5, 2)])
+def test_fit_large_inducing_sets(m1, m2, t, iters, route):
+    """BASELINE configs[3] territory (large overlap regions): M_p = 320 runs the LDS-staged kernel on one CU; from
+    M_p > 384 on a fit is spread over 2, 4, 8, ... workgroups by the cluster kernel (route 4; here G = 2, 4, 8), checked
+    against the float64 oracle at the full 50 Adam steps; route 2 = the same fit kept on one workgroup in the generic
+    kernel (debug bit 3 of gapro_fit_options.reserved)."""
+    import torch
     from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.gen_ps_utils import _pipeline
+    from gapro_amd.synth import make_gp_problem
+
+    want = route if route != 2 else 4
+    assert _lib.load().gapro_fit_route(m1 + m2, 6) == want
+    feats, b1, b2, it = make_gp_problem(40 + m1, m1, m2, t, 6)
+    pipe = _pipeline(torch.device("cuda", 0), iters)
+    old = pipe.opt.reserved
+    if route == 2:
+        pipe.opt.reserved = old | 8
+    try:
+        out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=iters)[0]
+    finally:
+        pipe.opt.reserved = old
+    _compare(out, _oracle(feats, b1, b2, it, iters))
+
+
+def test_cluster_kernel_is_deterministic_and_independent_of_its_neighbours():
+    """A fit spread over several workgroups must not depend on what runs beside it or on where its workgroups land:
+    the same problem alone, twice in one launch among other cluster fits of different sizes, and in a second launch
+    gives bit-identical outputs (ordered two-stage sums; the cluster size is a function of M only)."""
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
     from gapro_amd.synth import make_gp_problem
 
-    assert _lib.load().gapro_fit_route(m1 + m2, 6) == (1 if m1 + m2 <= 512 else 2)
-    feats, b1, b2, it = make_gp_problem(40 + m1, m1, m2, t, 6)
-    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=iters)[0]
-    _compare(out, _oracle(feats, b1, b2, it, iters))
+    parts, probs, base = [], [], 0
+    for i, (m1, m2, t) in enumerate([(200, 215, 40), (250, 300, 10), (330, 330, 25), (30, 40, 5), (100, 90, 7)]):
+        f, b1, b2, it = make_gp_problem(800 + i, m1, m2, t, 6)
+        parts.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(parts)
+    launch = [probs[0], probs[1], probs[2], probs[3], probs[0], probs[4], probs[1]]
+    a = fit_gp_spp_batch(feats, launch, training_iter=12)
+    b = fit_gp_spp_batch(feats, launch[::-1], training_iter=12)[::-1]
+    alone = fit_gp_spp_batch(feats, [probs[0]], training_iter=12)[0]
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            np.testing.assert_array_equal(u, v)
+    for k in (0, 4):
+        for u, v in zip(a[k], alone):
+            np.testing.assert_array_equal(u, v)
+    for u, v in zip(a[1], a[6]):
+        np.testing.assert_array_equal(u, v)
 
 
 def test_fit_stress_32_concurrent_large_regions():
     """BASELINE configs[4] shape: 32 concurrent regions of ~50k points each, i.e. ~1000 inducing and ~1000
-    undetermined superpoints per fit (generic kernel, ~100 MB of workspace per fit).  Four distinct problems, each
-    eight times in the launch: the copies must agree bit for bit whatever ran beside them, one problem is checked
-    against the float64 oracle (5 Adam steps: the oracle's autograd through a 1024^3 Cholesky is the slow side),
-    and the full 50-step launch must stay finite."""
+    undetermined superpoints per fit (cluster kernel, ~140 MB of workspace per fit, 1024 workgroups in the launch: four
+    times the chip, so clusters also wait for each other's CUs).  Four distinct problems, each eight times in the
+    launch: the copies must agree bit for bit whatever ran beside them, and one problem of the full 50-step launch is
+    checked against the float64 oracle."""
     from gapro_amd import _lib
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
     from gapro_amd.synth import make_gp_problem
 
     m1, m2, t = 500, 524, 1000
-    assert _lib.load().gapro_fit_route(m1 + m2, 6) == 2
+    assert _lib.load().gapro_fit_route(m1 + m2, 6) == 4  # cluster kernel: every fit over 32 workgroups
     feats_list, probs, base = [], [], 0
     for i in range(4):
         f, b1, b2, it = make_gp_problem(900 + i, m1, m2, t, 6)
@@ -102,13 +142,9 @@ def test_fit_stress_32_concurrent_large_regions():
         base += len(f)
     feats = np.concatenate(feats_list)
     launch = [probs[i % 4] for i in range(32)]
-    out = fit_gp_spp_batch(feats, launch, training_iter=5)
-    for i in range(4, 32):
-        for a, b in zip(out[i], out[i % 4]):
-            np.testing.assert_array_equal(a, b)
-    b1, b2, it = probs[0]
-    _compare(out[0], _oracle(feats, b1, b2, it, 5))
     full = fit_gp_spp_batch(feats, launch, training_iter=50)
+    b1, b2, it = probs[0]
+    _compare(full[0], _oracle(feats, b1, b2, it, 50))
     for i, (probs_, probs_new, labels, mu, var) in enumerate(full):
         assert np.isfinite(mu).all() and np.isfinite(var).all() and (var > 0).all()
         assert ((probs_ >= 0) & (probs_ <= 1)).all() and (probs_new >= 0.5).all()

@@ -81,7 +81,7 @@ def test_the_one_ill_conditioned_s3dis_fit_drifts_between_the_oracles_own_implem
     both: the gap is amplified rounding noise, not a formula difference."""
     import os
 
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s3dis_fits.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fits_s3dis.npz"))
     out = {}
     for tag in ("ill", "ctl"):
         f, m1, m2 = z[tag + "_feats"], int(z[tag + "_m1"]), int(z[tag + "_m2"])
