@@ -149,10 +149,11 @@ __device__ __noinline__ void cbar() {
 template <int K>
 __device__ __noinline__ void cl_reduce(double (&v)[K]) {
   const int G = g_sh.G;
+  // the slot set is read by every thread BEFORE the workgroup barriers of block_sum; thread 0 flips it behind them
+  gd* red = g_sh.f.red + (size_t)(g_sh.red_par & 1) * 16 * kClMaxG;
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = block_sum(v[k]);
   if (G == 1) return;
-  gd* red = g_sh.f.red + (size_t)(g_sh.red_par & 1) * 16 * kClMaxG;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < K; ++k) red[k * kClMaxG + g_sh.g] = v[k];
