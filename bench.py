@@ -338,7 +338,20 @@ def run_workload(args, pipe, dev, rank, world, workload, B, distinct, steps, war
         d["ms"] += ev["start"].elapsed_time(ev["end"])
         d["points"] += ev["points"]
         d["n"] += 1
-    return dict(elapsed=elapsed, fit_ms3=fit_ms3, fit_events=list(pipe.fit_events), part=part,
+    # the integer half alone on the GPU: one un-pipelined step (prepare, pool | fits | broadcast, each synchronised)
+    fit_events = list(pipe.fit_events)
+    pipe.part_events = []
+    torch.cuda.synchronize(dev)
+    pipe.run(make_jobs())
+    torch.cuda.synchronize(dev)
+    probe = {}
+    for ev in pipe.part_events:
+        d = probe.setdefault(ev["name"], dict(ms=0.0, points=0, n=0))
+        d["ms"] += ev["start"].elapsed_time(ev["end"])
+        d["points"] += ev["points"]
+        d["n"] += 1
+    pipe.fit_events = fit_events
+    return dict(elapsed=elapsed, fit_ms3=fit_ms3, fit_events=fit_events, part=part, part_probe=probe,
                 stats=dict(pipe.last_stats), last_fit_m=getattr(pipe, "last_fit_m", None), scene_kws=scene_kws,
                 points_per_step=sum(int(resident[i % n_distinct]["coords_float"].shape[0]) for i in range(B)),
                 n_distinct=n_distinct, trace=pipe.trace, stage_times=dict(pipe.stage_times))
@@ -364,24 +377,30 @@ def summarize(args, res, B, world, steps, workload, peak):
         fl = float(np.mean([getattr(ev, attr) for ev in evs])) if evs else 0.0
         per[key] = dict(kernel=name.replace("%s", "%d,%d" % ((args.feat_dim, args.feat_dim) if args.feat_dim in (6, 32) else (32, 0))),
                         avg_ms=ms, flops=fl, tflops=(fl / (ms * 1e-3) / 1e12) if ms > 0 else 0.0)
-    dom = max(per, key=lambda k: per[k]["avg_ms"])  # the kernel the launch waits for
     stats = res["stats"]
     out = {"value": B * steps * world / elapsed, "ms_per_step": 1e3 * elapsed / steps,
            "fits_per_step": int(stats.get("n_fits", 0)), "points_per_step": int(res["points_per_step"]),
            "distinct_scenes": int(res["n_distinct"])}
     traffic, src = pmc_traffic(workload, B, args.points, args.feat_dim, res["n_distinct"])
-    d = per[dom]
-    out["roofline"] = {"bound": "mfma", "kernel": d["kernel"] + "; f64 MFMA 16x16x4", "achieved": d["tflops"],
-                       "peak": peak, "unit": "TFLOP/s", "frac": d["tflops"] / peak, "traffic": traffic,
-                       "traffic_source": src, "avg_launch_ms": d["avg_ms"], "flops_per_launch": d["flops"],
-                       "timing": "HIP events recorded by the library on the stream the kernel is launched on"}
+    # The fit kernels of one gapro_svgp_fit_batch launch run SIDE BY SIDE on the library's streams and share the CUs, so
+    # a single kernel's own duration is inflated by its neighbours; the figure that can be priced against the MFMA
+    # peak is the launch: algorithmic FLOPs of all its fits / (first kernel start -> last kernel end).
+    out["roofline"] = {"bound": "mfma",
+                       "kernel": "gapro_svgp_fit_batch launch = " + " + ".join(
+                           k for k in ("cluster", "staged", "strip", "small") if per[k]["flops"] > 0)
+                                 + " fit kernels side by side; f64 MFMA 16x16x4",
+                       "achieved": launch_tflops, "peak": peak, "unit": "TFLOP/s", "frac": launch_tflops / peak,
+                       "traffic": traffic, "traffic_source": src, "avg_launch_ms": avg_ms,
+                       "flops_per_launch": float(np.mean(fit_fl)) if fit_fl else 0.0,
+                       "timing": "HIP events recorded by the library on the streams the kernels are launched on: first "
+                                 "kernel start -> last kernel end"}
     out["fit_launch"] = {"avg_ms_first_start_to_last_end": avg_ms, "flops": float(np.mean(fit_fl)) if fit_fl else 0.0,
                          "tflops": launch_tflops, "frac_of_fp64_mfma_peak": launch_tflops / peak,
                          "fits_per_s": (stats.get("n_fits", 0) / (avg_ms * 1e-3)) if avg_ms > 0 else 0.0,
                          "kernels": per, "share_of_step": (sum(fit_ms) / (1e3 * elapsed)) if elapsed > 0 else None}
     # HBM-bound half: SURVEY 8d algorithmic bytes per point = 24 (xyz f64) + 4 D (feats f32) + 8 (spp i64) + 12 (out)
     bpp = 24 + 4 * args.feat_dim + 8 + 12
-    part = res["part"]
+    part = res.get("part_probe") or res["part"]
     tot_ms = sum(v["ms"] for v in part.values())
     pts = part.get("pool", {}).get("points", 0)
     out["partition"] = {
@@ -392,7 +411,9 @@ def summarize(args, res, B, world, steps, workload, peak):
         "GB/s": (bpp * pts / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else 0.0,
         "frac_of_hbm": (bpp * pts / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot_ms > 0 else 0.0,
         "pool_only_GB/s": (bpp * pts / (part["pool"]["ms"] * 1e-3) / 1e9) if part.get("pool", {}).get("ms", 0) > 0 else 0.0,
-        "timing": "torch events on the stream the kernels are launched on, summed over the timed steps"}
+        "timing": "torch events on the stream the kernels are launched on, one extra un-pipelined step after the timed "
+                  "region (inside the pipelined steps these short kernels queue behind the fit kernels, which an event "
+                  "pair would count as kernel time)"}
     m = res["last_fit_m"]
     if m is not None and len(m):
         edges = [0, 32, 64, 96, 128, 192, 256, 384, 512, 1 << 30]

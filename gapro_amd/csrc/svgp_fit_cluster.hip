@@ -75,8 +75,26 @@ struct Shared {
   double mc, vc, mrs, vrs, mrl, vrl;  // Adam moments of the scalars: every workgroup applies the same updates
   int status, chol_bad;
   int pr_lo[kMaxPairs], pr_mid[kMaxPairs], pr_hi[kMaxPairs], pr_t0[kMaxPairs + 1];
+#ifdef GAPRO_PROFILE
+  unsigned long long prof[28];
+  unsigned long long t_last;
+#endif
 };
 __shared__ Shared g_sh;
+
+// diagnostic build only: wall-clock (100 MHz ticks) per phase on the leader, barrier waits included; placed right
+// behind cluster barriers, adds no synchronisation of its own
+#ifdef GAPRO_PROFILE
+__device__ inline void stamp(int id) {
+  if (g_sh.g == 0 && threadIdx.x == 0) {
+    const unsigned long long t = wall_clock64();
+    g_sh.prof[id] += t - g_sh.t_last;
+    g_sh.t_last = t;
+  }
+}
+#else
+__device__ inline void stamp(int) {}
+#endif
 
 // ---- small helpers ---------------------------------------------------------------------------------
 __device__ inline double softplus(double x) { return log1p(exp(-fabs(x))) + fmax(x, 0.0); }
@@ -479,6 +497,7 @@ __device__ __noinline__ void cholesky_cluster() {
     // (a) leader: diagonal block
     if (g_sh.g == 0) chol_diag_block(c0, w);
     cbar();
+    stamp(1);
     if (c1 >= Mp) break;
     // (b) panel below: L[i][c0 + c] = sum_q S[i][c0 + q] W[c][q],  W^T = U (rows q, contiguous in c)
     {
@@ -501,6 +520,7 @@ __device__ __noinline__ void cholesky_cluster() {
       }
     }
     cbar();
+    stamp(2);
     // L rows of the panel from L^T (the in-place overwrite of S must wait for all readers of the row block)
     {
       const long long n = (long long)(Mp - c1) * w;
@@ -525,6 +545,7 @@ __device__ __noinline__ void cholesky_cluster() {
                         });
     }
     cbar();
+    stamp(3);
   }
 }
 
@@ -667,10 +688,12 @@ __device__ __noinline__ void forward_products(int ncols) {
                     [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
                     [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n); });
   cbar();
+  stamp(20);
   gemm_tn<2, false>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
                     [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                     [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j); });
   cbar();
+  stamp(21);
   col_partials(0, Mp, [=](int r, int c) { return vm[r] * A[(size_t)r * Mp + c]; });
   col_partials(1, Mp, [=](int r, int c) {
     const double a = A[(size_t)r * Mp + c], b = BM[(size_t)r * Mp + c];
@@ -722,6 +745,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     for (int attempt = 0;; ++attempt) {
       build_kzz(sh.s, sh.inv_l2, jitter + extra);
       cbar();
+      stamp(0);
       cholesky_cluster();
       // the leader's flag -> everybody (one ordered sum)
       double bad[1] = {(threadIdx.x == 0 && sh.g == 0 && sh.chol_bad) ? 1.0 : 0.0};
@@ -735,7 +759,9 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
       }
       extra = opt.psd_jitter * pow(10.0, (double)attempt);
     }
+    stamp(8);
     tri_inverse_cluster();
+    stamp(4);
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
@@ -745,7 +771,9 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     factorize();
     build_kx(f.X, M, s, inv_l2);
     cbar();
+    stamp(5);
     forward_products(M);
+    stamp(6);
     // quadrature: thread per training point (final column sums, then the 20-point rule)
     double sums[4] = {0.0, 0.0, 0.0, 0.0};  // E, g_c, gv_sum, KL part
     for (int n = ct; n < Mp; n += CT) {
@@ -791,6 +819,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     cl_reduce(sums);  // includes a cluster barrier: gmu / gv are visible to everybody behind it
     const double g_c = sums[1], gv_sum = sums[2];
     last_loss = -(sums[0] / Nd - 0.5 * (sums[3] - Nd) / Nd);
+    stamp(9);
 
     // ------------------------------- backward ------------------------------
     // G_m partials (through A^T), G_A and G_LS are independent: one barrier behind the three
@@ -824,11 +853,13 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
                        }
                      });
     cbar();
+    stamp(10);
     // G_KX = LI^T G_A
     gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                       [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
     cbar();
+    stamp(11);
     // G_L = -tril(G_KX A^T) -> BM buffer
     gd* GL = BM;
     gemm_tn<2, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
@@ -841,6 +872,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
                         }
                       });
     cbar();
+    stamp(12);
     // Pm = Phi(tril(L^T G_L)) -> GA buffer
     gd* Pm = GA;
     gemm_tn<2, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
@@ -854,12 +886,14 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
                         }
                       });
     cbar();
+    stamp(13);
     // T1 = LI^T Pm, stored transposed -> BMT buffer
     gd* T1T = BMT;
     gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j); });
     cbar();
+    stamp(14);
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer
     gd* G = BM;
     gd* GT = GKXT;
@@ -867,6 +901,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j); });
     cbar();
+    stamp(15);
     // kernel weights in place: Wzz = sym(G) o K -> G, Wzx = G_KX o KX -> GKX; scalar sums for d/ds and d/dl
     double ks[2] = {0.0, 0.0};
     {
@@ -890,6 +925,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
       }
     }
     cl_reduce(ks);
+    stamp(16);
     const double g_s = ks[0] + gv_sum;
     const double g_l = ks[1] / (ell * ell * ell);
     // G_Z[i][d] = -(1/l^2) ( sum_j 2 Wzz[i][j] (Z_i - Z_j)[d] + sum_n Wzx[i][n] (Z_i - X_n)[d] )
@@ -908,6 +944,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
       }
     }
     cbar();  // every G_Z entry is computed from the OLD Z before anybody updates Z
+    stamp(17);
 
     // ------------------------------- Adam ----------------------------------
     const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
@@ -954,6 +991,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
       sh.rho_l = adam(sh.rho_l, sh.mrl, sh.vrl, g_l * sigmoid(sh.rho_l));
     }
     cbar();
+    stamp(18);
   }
 
   // ------------------------------- prediction ------------------------------
@@ -987,6 +1025,11 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     // max over members, through an ordered sum of one-hot encodings would be overkill: errors are rare -> reduce sum
     cl_reduce(st);
   }
+  stamp(19);
+#ifdef GAPRO_PROFILE
+  if (sh.g == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 28; ++i) f.scal[24 + i] = (double)sh.prof[i];
+#endif
   if (sh.g == 0 && threadIdx.x == 0) {
     if (sh.status == GAPRO_OK && st[0] != 0.0) sh.status = GAPRO_ERR_NOT_FINITE;
     f.scal[S_C] = sh.c;
@@ -1050,6 +1093,10 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     sh.mc = sh.vc = sh.mrs = sh.vrs = sh.mrl = sh.vrl = 0.0;
     sh.status = GAPRO_OK;
     sh.chol_bad = 0;
+#ifdef GAPRO_PROFILE
+    for (int i = 0; i < 28; ++i) sh.prof[i] = 0;
+    sh.t_last = wall_clock64();
+#endif
   }
   __syncthreads();
   const int M = f.M, Mp = f.Mp;

@@ -100,7 +100,8 @@ def test_hip_kernels_match_the_frozen_vectors(name):
 
     z = np.load(os.path.join(HERE, "golden", "svgp_kat_%s.npz" % name))
     launch = [(z["b1"], z["b2"], z["it"])]
-    (probs, probs_new, labels, mu, var), res = fit_gp_spp_batch(z["feats"], launch, training_iter=50, keep_debug=True)
+    outs, res = fit_gp_spp_batch(z["feats"], launch, training_iter=50, keep_debug=True)
+    probs, probs_new, labels, mu, var = outs[0]
     np.testing.assert_allclose(var, z["var"], rtol=1e-5)
     np.testing.assert_allclose(mu, z["mu"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(probs, z["p"], rtol=0, atol=2e-7)

@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-fork", action="store_true", help="both fit kernels on one stream")
     ap.add_argument("--own-stream", action="store_true", help="launch from a non-default torch stream")
     ap.add_argument("--no-small", action="store_true", help="M_p <= 64 on the 512-thread strip kernel (A/B)")
+    ap.add_argument("--no-cluster", action="store_true", help="large fits stay on one workgroup (A/B)")
     args = ap.parse_args()
     if args.profile:
         import os
@@ -118,6 +119,8 @@ def main():
         pipe.opt.reserved |= 2
     if args.no_small:
         pipe.opt.reserved |= 4
+    if args.no_cluster:
+        pipe.opt.reserved |= 8
     if args.mix:
         run_mix(pipe, args)
         return
@@ -178,6 +181,11 @@ def main():
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
                          "s:GKX", "adam", "predict", "s:GLacc+store", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
                          "(diag:stores", "x25", "x26", "x27"]
+            from gapro_amd import _lib as _l
+            if _l.load().gapro_fit_route(m, args.d) == 4 and not args.no_cluster:
+                names = ["kzz", "chol:diag(leader)", "chol:panel", "chol:trailing", "inverse", "kx", "fwd:colpart",
+                         "-", "chol:flag", "quad+kl", "Gm+GA+GLS", "GKX", "GL", "Pm", "T1", "G", "kweights", "GZ",
+                         "adam", "predict", "fwd:A", "fwd:B", "-", "-", "-", "-", "-", "-"]
             tot = prof.sum()
             print("    phases (us per fit, share): " + "  ".join(
                 "%s %.0f (%.0f%%)" % (nm, v / 100.0, 100 * v / tot) for nm, v in zip(names, prof) if v > 0), flush=True)
