@@ -16,15 +16,19 @@ enum ScalId { S_C = 0, S_RS, S_RL, S_MC, S_MRS, S_MRL, S_VC, S_VRS, S_VRL, S_LOS
 inline __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
 // Fits spread over several workgroups (svgp_fit_cluster.hip) exchange partial sums through a scratch region at the
-// end of their workspace: 3 column-partial planes of max(kClMaxThreads, Mp) doubles + 2 x 16 scalar slots per member.
+// end of their workspace: 3 column-partial planes of max(kClMaxThreads, Mp) doubles + 2 x 16 scalar slots per member,
+// then the transposed copies Zt[D][Mp], Xt[D][Mp] of the inducing / training points (coalesced kernel evaluation).
 constexpr int kClMaxG = 32;                      // largest cluster (workgroups per fit)
 constexpr int kClThreads = 512;                  // threads per cluster workgroup
 constexpr int kClMaxThreads = kClMaxG * kClThreads;
 constexpr int kClusterMinMp = 272;               // smallest padded M that may be routed to the cluster kernel
-inline __host__ __device__ long long cluster_scratch_doubles(int Mp) {
-  if (Mp < kClusterMinMp) return 0;
+inline __host__ __device__ long long cluster_part_doubles(int Mp) {
   const long long w = Mp > kClMaxThreads ? Mp : kClMaxThreads;
   return 3 * w + 2 * 16 * kClMaxG;
+}
+inline __host__ __device__ long long cluster_scratch_doubles(int Mp, int d) {
+  if (Mp < kClusterMinMp) return 0;
+  return cluster_part_doubles(Mp) + 2LL * Mp * d;
 }
 
 struct Layout {
@@ -43,7 +47,7 @@ inline __host__ __device__ Layout make_layout(int m, int t, int d) {
   L.dinv = L.xt + (long long)L.Tp * d;
   L.scal = L.dinv + 2LL * L.Mp * 16;  // Dinv and Dinv^T blocks
   L.cl = L.scal + kScalars;
-  L.total = L.cl + cluster_scratch_doubles(L.Mp);
+  L.total = L.cl + cluster_scratch_doubles(L.Mp, d);
   L.total = (L.total + 1) / 2 * 2;
   return L;
 }

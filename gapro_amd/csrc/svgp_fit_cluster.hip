@@ -58,6 +58,7 @@ struct Fit {
   gd* mat[B_COUNT];
   gd* vec[V_COUNT];
   gd *X, *Z, *mZ, *vZ, *gZ, *Xt, *dinv, *dinvT, *scal, *part, *red;
+  gd *Zt, *XtT;  // transposed copies [D][Mp] of Z and X
 };
 
 constexpr int kMaxPairs = 40;
@@ -465,6 +466,17 @@ __device__ __noinline__ void chol_diag_block(int c0, int w) {
   }
 }
 
+// squared distance between column i of At[D][Mp] and column j of Bt[D][Mp]; with i wave-uniform the At loads are
+// broadcasts and the Bt loads are coalesced over the lanes' consecutive j
+__device__ inline double sqdist_t(const gd* At, int i, const gd* Bt, int j, int D, int Mp) {
+  double s = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double t = At[(size_t)d * Mp + i] - Bt[(size_t)d * Mp + j];
+    s += t * t;
+  }
+  return s;
+}
+
 // Kzz + jitter I (lower incl. diagonal; identity on the padded tail) into B_L, dealt to the whole cluster
 __device__ __noinline__ void build_kzz(double s, double inv_l2, double jitter) {
   const Fit& f = g_sh.f;
@@ -475,7 +487,7 @@ __device__ __noinline__ void build_kzz(double s, double inv_l2, double jitter) {
     const int i = (int)(idx / Mp), j = (int)(idx - (long long)i * Mp);
     double v = 0.0;
     if (i < M && j <= i) {
-      v = s * exp(-0.5 * inv_l2 * sqdist(f.Z + (size_t)i * D, f.Z + (size_t)j * D, D));
+      v = s * exp(-0.5 * inv_l2 * sqdist_t(f.Zt, i, f.Zt, j, D, Mp));
       if (i == j) v += jitter;
     } else if (i >= M && i == j) {
       v = 1.0;
@@ -581,7 +593,7 @@ __device__ __noinline__ void tri_inverse_cluster() {
       for (int t = cw; t < ntot; t += CW) {
         int k = 0;
         while (sh.pr_t0[k + 1] <= t) ++k;
-        const int lo = uni(sh.pr_lo[k]), mid = uni(sh.pr_mid[k]), hi = uni(sh.pr_hi[k]);
+        const int lo = uni(sh.pr_lo[k]), mid = uni(sh.pr_mid[k]);
         const int tl = t - uni(sh.pr_t0[k]);
         const int nct = s / 32;
         const int ti = tl / nct, tj = tl - ti * nct;
@@ -628,8 +640,8 @@ __device__ __noinline__ void tri_inverse_cluster() {
   }
 }
 
-// KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for k < M, n < ncols, zero elsewhere
-__device__ __noinline__ void build_kx(const gd* pts, int ncols, double s, double inv_l2) {
+// KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for k < M, n < ncols, zero elsewhere; Pt = the points transposed [D][ldp]
+__device__ __noinline__ void build_kx(const gd* Pt, int ldp, int ncols, double s, double inv_l2) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   gd* KX = f.mat[B_KX];
@@ -637,7 +649,14 @@ __device__ __noinline__ void build_kx(const gd* pts, int ncols, double s, double
   for (long long idx = cl_tid(); idx < n; idx += cl_threads()) {
     const int k = (int)(idx / Mp), c = (int)(idx - (long long)k * Mp);
     double v = 0.0;
-    if (k < M && c < ncols) v = s * exp(-0.5 * inv_l2 * sqdist(f.Z + (size_t)k * D, pts + (size_t)c * D, D));
+    if (k < M && c < ncols) {
+      double d2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double t = f.Zt[(size_t)d * Mp + k] - Pt[(size_t)d * ldp + c];
+        d2 += t * t;
+      }
+      v = s * exp(-0.5 * inv_l2 * d2);
+    }
     KX[idx] = v;
   }
 }
@@ -702,6 +721,81 @@ __device__ __noinline__ void forward_products(int ncols) {
   cbar();
 }
 
+// Kernel gradients of one Adam step; see the call site.  A function of its own: its per-row accumulators must not
+// live in the registers of the step loop.
+template <int DMAX>
+__device__ __noinline__ void kernel_grads(const gd* __restrict__ G, const gd* __restrict__ GT,
+                                          const gd* __restrict__ GKX, const gd* __restrict__ KX, double s,
+                                          double inv_l2, double (&ks)[2]) {
+  const Fit& f = g_sh.f;
+  const int M = f.M, Mp = f.Mp, D = f.D;
+  const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
+  const gd* Zt = f.Zt;
+  const gd* Xc = f.XtT;
+  double k0 = 0.0, k1 = 0.0;
+  for (int i = cw; i < M; i += CW) {
+    double acc[DMAX], zi[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      acc[d] = 0.0;
+      zi[d] = d < D ? Zt[(size_t)d * Mp + i] : 0.0;
+    }
+    double wsum = 0.0;
+    for (int j = lane; j < M; j += 64) {
+      const size_t o = (size_t)i * Mp + j;
+      const double gsym = 0.5 * (G[o] + GT[o]);
+      const double gk = GKX[o], kx = KX[o];
+      double d2 = 0.0, d2x = 0.0;
+      if (DMAX <= 8) {  // narrow features: the column's points stay in registers between the two uses
+        double zj[DMAX], xj[DMAX];
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+          zj[d] = d < D ? Zt[(size_t)d * Mp + j] : 0.0;
+          xj[d] = d < D ? Xc[(size_t)d * Mp + j] : 0.0;
+          const double a = zi[d] - zj[d], bx = zi[d] - xj[d];
+          d2 += a * a;
+          d2x += bx * bx;
+        }
+        const double e = exp(-0.5 * inv_l2 * d2);
+        const double w = gsym * s * e, wx = gk * kx;
+        k0 += gsym * e + gk * kx / s;
+        k1 += w * d2 + wx * d2x;
+        // sum_j w_j (Z_i - P_j) = Z_i sum_j w_j - sum_j w_j P_j : only the weighted point sums are accumulated
+        wsum += 2.0 * w + wx;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) acc[d] += 2.0 * w * zj[d] + wx * xj[d];
+      } else {  // deep features (D = 32): re-read the column's points (L1 hits) instead of holding 64 more doubles
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+          if (d < D) {
+            const double a = zi[d] - Zt[(size_t)d * Mp + j], bx = zi[d] - Xc[(size_t)d * Mp + j];
+            d2 += a * a;
+            d2x += bx * bx;
+          }
+        }
+        const double e = exp(-0.5 * inv_l2 * d2);
+        const double w = gsym * s * e, wx = gk * kx;
+        k0 += gsym * e + gk * kx / s;
+        k1 += w * d2 + wx * d2x;
+        wsum += 2.0 * w + wx;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+          if (d < D) acc[d] += 2.0 * w * Zt[(size_t)d * Mp + j] + wx * Xc[(size_t)d * Mp + j];
+      }
+    }
+    wsum = wave_sum(wsum);
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      if (d < D) {
+        const double a = wave_sum(acc[d]);
+        if (lane == 0) f.gZ[(size_t)i * D + d] = -inv_l2 * (wsum * zi[d] - a);
+      }
+    }
+  }
+  ks[0] = k0;
+  ks[1] = k1;
+}
+
 __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& desc, float* __restrict__ o_probs,
                          float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
                          float* __restrict__ o_mu, float* __restrict__ o_var, double* loss_out) {
@@ -715,7 +809,6 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
   gd* LST = f.mat[B_LST];
   gd* MLS = f.mat[B_MLS];
   gd* VLS = f.mat[B_VLS];
-  gd* GLS = f.mat[B_GLS];
   gd* A = f.mat[B_A];
   gd* AT = f.mat[B_AT];
   gd* BM = f.mat[B_BM];
@@ -769,40 +862,57 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     const double s = sh.s, ell = sh.ell, inv_l2 = sh.inv_l2, c = sh.c;
     // ------------------------------- forward -------------------------------
     factorize();
-    build_kx(f.X, M, s, inv_l2);
+    build_kx(f.XtT, Mp, M, s, inv_l2);
     cbar();
     stamp(5);
     forward_products(M);
     stamp(6);
-    // quadrature: thread per training point (final column sums, then the 20-point rule)
+    // quadrature: 16 lanes per training point, lane q < 10 evaluates the symmetric node pair +-t_q of the 20-point
+    // Gauss-Hermite rule (BernoulliLikelihood.expected_log_prob), the 16 lanes are summed by xor-shuffles
     double sums[4] = {0.0, 0.0, 0.0, 0.0};  // E, g_c, gv_sum, KL part
-    for (int n = ct; n < Mp; n += CT) {
-      double g1 = 0.0, g2 = 0.0;
-      if (n < M) {
-        const double mu = col_final(0, Mp, n) + c;
-        const double vraw = s + jitter + col_final(1, Mp, n);
-        const bool clamped = vraw < opt.min_variance;
-        const double var = clamped ? opt.min_variance : vraw;
-        const double sd = sqrt(2.0 * var);
-        const double y = f.vec[V_Y][n];
-        double E = 0.0, dmu = 0.0, dvar = 0.0;
-        for (int q = 0; q < NGH / 2; ++q) {
-          const double t = c_gh_t[q], w = c_gh_w[q];
-          double lp, r;
-          log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
-          E += w * lp; dmu += w * r; dvar -= w * t * r;
-          log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
-          E += w * lp; dmu += w * r; dvar += w * t * r;
+    {
+      const int q = ct & 15, per_pass = CT >> 4;
+      for (int n0 = 0; n0 < Mp; n0 += per_pass) {
+        const int n = n0 + (ct >> 4);
+        double E = 0.0, dmu = 0.0, dvar = 0.0, y = 0.0, sd = 1.0;
+        bool clamped = false;
+        const bool on = n < M;
+        if (on) {
+          const double mu = col_final(0, Mp, n) + c;
+          const double vraw = s + jitter + col_final(1, Mp, n);
+          clamped = vraw < opt.min_variance;
+          const double var = clamped ? opt.min_variance : vraw;
+          sd = sqrt(2.0 * var);
+          y = f.vec[V_Y][n];
+          if (q < NGH / 2) {
+            const double t = c_gh_t[q], w = c_gh_w[q];
+            double lp, r;
+            log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
+            E += w * lp; dmu += w * r; dvar -= w * t * r;
+            log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
+            E += w * lp; dmu += w * r; dvar += w * t * r;
+          }
         }
-        const double ipi = 0.56418958354775628695;
-        sums[0] += ipi * E;
-        g1 = -(ipi * dmu * y) / Nd;
-        g2 = clamped ? 0.0 : -(ipi * dvar * y / sd) / Nd;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          E += __shfl_xor(E, o, 64);
+          dmu += __shfl_xor(dmu, o, 64);
+          dvar += __shfl_xor(dvar, o, 64);
+        }
+        if (q == 0 && n < Mp) {
+          double g1 = 0.0, g2 = 0.0;
+          if (on) {
+            const double ipi = 0.56418958354775628695;
+            sums[0] += ipi * E;
+            g1 = -(ipi * dmu * y) / Nd;
+            g2 = clamped ? 0.0 : -(ipi * dvar * y / sd) / Nd;
+          }
+          gmu[n] = g1;
+          gv[n] = g2;
+          sums[1] += g1;
+          sums[2] += g2;
+        }
       }
-      gmu[n] = g1;
-      gv[n] = g2;
-      sums[1] += g1;
-      sums[2] += g2;
     }
     {
       const long long n = (long long)M * M;
@@ -822,7 +932,11 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     stamp(9);
 
     // ------------------------------- backward ------------------------------
-    // G_m partials (through A^T), G_A and G_LS are independent: one barrier behind the three
+    const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
+    const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
+    const double step_size = opt.lr / bc1;
+    // G_m partials (through A^T) and G_A read L_S; the Adam update of L_S is fused into the G_LS product of the
+    // NEXT phase, which runs beside G_KX = LI^T G_A
     col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
     gemm_tn<2, false>(mt, mt, false, LST, BM, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
@@ -837,23 +951,34 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
                           GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
                         }
                       });
+    cbar();
+    stamp(10);
+    // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] B[j][n] (lower) + KL', Adam on L_S in the epilogue (L_S^T through the
+    // wave's transpose tile: 128-byte rows)
     gemm_tn<2, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                      [=](int i0, int j0, const d4& v) {
                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                        const int j = j0 + lr;
+                       d4 newv;
 #pragma unroll
                        for (int r = 0; r < 4; ++r) {
                          const int i = i0 + lq + 4 * r;
-                         double g = 0.0;
+                         const size_t o = (size_t)i * Mp + j;
+                         double lnew = 0.0;
                          if (j <= i && i < M) {
-                           const double l = LS[(size_t)i * Mp + j];
-                           g = 2.0 * v[r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+                           const double l = LS[o];
+                           const double g = 2.0 * v[r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
+                           const double m1 = b1 * MLS[o] + (1.0 - b1) * g;
+                           const double m2 = b2 * VLS[o] + (1.0 - b2) * g * g;
+                           MLS[o] = m1;
+                           VLS[o] = m2;
+                           lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+                           LS[o] = lnew;
                          }
-                         GLS[(size_t)i * Mp + j] = g;
+                         newv[r] = lnew;
                        }
+                       store_tile(newv, nullptr, LST, Mp, i0, j0);  // LST[j][i]; zeros above the diagonal
                      });
-    cbar();
-    stamp(10);
     // G_KX = LI^T G_A
     gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
@@ -902,62 +1027,31 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j); });
     cbar();
     stamp(15);
-    // kernel weights in place: Wzz = sym(G) o K -> G, Wzx = G_KX o KX -> GKX; scalar sums for d/ds and d/dl
+    // kernel gradients in one pass (kernel_grads): a wave owns row i and walks its columns j 64 at a time (Z_i in
+    // registers, Z_j / X_j: coalesced loads from the transposed copies):
+    //   w  = sym(G)[i][j] s E_ij  ->  G_s += sym(G) E,  G_l += w d2,   G_Z[i] += 2 w (Z_i - Z_j)
+    //   wx = G_KX[i][j] KX_ij     ->  G_s += G_KX KX / s, G_l += wx d2x, G_Z[i] += wx (Z_i - X_j)
     double ks[2] = {0.0, 0.0};
-    {
-      const long long n = (long long)M * M;
-      for (long long idx = ct; idx < n; idx += CT) {
-        const int i = (int)(idx / M), j = (int)(idx - (long long)i * M);
-        const size_t o = (size_t)i * Mp + j;
-        const double d2 = sqdist(f.Z + (size_t)i * D, f.Z + (size_t)j * D, D);
-        const double e = exp(-0.5 * inv_l2 * d2);
-        const double gsym = 0.5 * (G[o] + GT[o]);
-        const double w = gsym * s * e;
-        ks[0] += gsym * e;
-        ks[1] += w * d2;
-        const double d2x = sqdist(f.Z + (size_t)i * D, f.X + (size_t)j * D, D);
-        const double kx = KX[o];
-        const double gk = GKX[o];
-        ks[0] += gk * kx / s;
-        ks[1] += gk * kx * d2x;
-        GA[o] = w;        // Wzz -> GA buffer (G and G^T are still being read by other threads)
-        A[o] = gk * kx;   // Wzx -> A buffer
-      }
-    }
-    cl_reduce(ks);
+    if (D <= 8) kernel_grads<8>(G, GT, GKX, KX, s, inv_l2, ks);
+    else kernel_grads<32>(G, GT, GKX, KX, s, inv_l2, ks);
+    cl_reduce(ks);  // its barrier also publishes G_Z: every entry was computed from the OLD Z
     stamp(16);
     const double g_s = ks[0] + gv_sum;
     const double g_l = ks[1] / (ell * ell * ell);
-    // G_Z[i][d] = -(1/l^2) ( sum_j 2 Wzz[i][j] (Z_i - Z_j)[d] + sum_n Wzx[i][n] (Z_i - X_n)[d] )
-    {
-      const gd* Wzz = GA;
-      const gd* Wzx = A;
-      for (int idx = ct; idx < M * D; idx += CT) {
-        const int i = idx / D, d = idx - i * D;
-        const double zi = f.Z[(size_t)i * D + d];
-        const gd* wz = Wzz + (size_t)i * Mp;
-        const gd* wx = Wzx + (size_t)i * Mp;
-        double acc = 0.0;
-        for (int j = 0; j < M; ++j)
-          acc += 2.0 * wz[j] * (zi - f.Z[(size_t)j * D + d]) + wx[j] * (zi - f.X[(size_t)j * D + d]);
-        f.gZ[idx] = -inv_l2 * acc;
-      }
-    }
-    cbar();  // every G_Z entry is computed from the OLD Z before anybody updates Z
     stamp(17);
 
-    // ------------------------------- Adam ----------------------------------
-    const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
-    const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
-    const double step_size = opt.lr / bc1;
+    // ------------------------------- Adam (Z, m, scalars; L_S was updated in the G_LS epilogue) --------------
     auto adam = [&](double p, double& m1, double& m2, double g) {
       m1 = b1 * m1 + (1.0 - b1) * g;
       m2 = b2 * m2 + (1.0 - b2) * g * g;
       return p - step_size * m1 / (sqrt(m2) / bc2s + aeps);
     };
     for (int idx = ct; idx < M * D; idx += CT) {
+      const int i = idx / D, d = idx - i * D;
       double m1 = f.mZ[idx], m2 = f.vZ[idx];
-      f.Z[idx] = adam(f.Z[idx], m1, m2, f.gZ[idx]);
+      const double znew = adam(f.Z[idx], m1, m2, f.gZ[idx]);
+      f.Z[idx] = znew;
+      f.Zt[(size_t)d * Mp + i] = znew;
       f.mZ[idx] = m1;
       f.vZ[idx] = m2;
     }
@@ -968,21 +1062,6 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
       vm[i] = adam(vm[i], m1, m2, g);
       f.vec[V_MM][i] = m1;
       f.vec[V_VM][i] = m2;
-    }
-    {
-      const long long n = (long long)M * M;
-      for (long long idx = ct; idx < n; idx += CT) {
-        const int i = (int)(idx / M), j = (int)(idx - (long long)i * M);
-        if (j <= i) {
-          const size_t o = (size_t)i * Mp + j;
-          double m1 = MLS[o], m2 = VLS[o];
-          const double lnew = adam(LS[o], m1, m2, GLS[o]);
-          MLS[o] = m1;
-          VLS[o] = m2;
-          LS[o] = lnew;
-          LST[(size_t)j * Mp + i] = lnew;
-        }
-      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {  // every workgroup keeps the scalars and applies the same update
@@ -1000,7 +1079,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
   const double s = sh.s, inv_l2 = sh.inv_l2, c = sh.c;
   for (int t0 = 0; t0 < T; t0 += Mp) {
     const int nc = (T - t0) < Mp ? (T - t0) : Mp;
-    build_kx(f.Xt + (size_t)t0 * D, nc, s, inv_l2);
+    build_kx(f.Xt + t0, round_up(T > 0 ? T : 1, 32), nc, s, inv_l2);
     cbar();
     forward_products(nc);
     for (int n = ct; n < nc; n += CT) {
@@ -1084,6 +1163,8 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     f.scal = base + lay.scal;
     f.part = base + lay.cl;
     f.red = f.part + 3LL * (lay.Mp > kClMaxThreads ? lay.Mp : kClMaxThreads);
+    f.Zt = base + lay.cl + cluster_part_doubles(lay.Mp);
+    f.XtT = f.Zt + (long long)lay.Mp * D;
     sh.G = cb.G;
     sh.g = cb.g;
     sh.epoch = 0;
@@ -1110,10 +1191,12 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     const double v = (double)feats_spp[(size_t)my_idx[i] * D + d];  // train_x = cat(b1_feats, b2_feats)  :395
     f.X[e] = v;
     f.Z[e] = v;  // inducing points initialised to train_x  (:14)
+    f.Zt[(size_t)d * Mp + i] = v;
+    f.XtT[(size_t)d * Mp + i] = v;
   }
   for (int e = ct; e < f.T * D; e += CT) {
     const int i = e / D, d = e - i * D;
-    f.Xt[e] = (double)feats_spp[(size_t)my_idx[M + i] * D + d];  // intersect_feats  :386
+    f.Xt[(size_t)d * lay.Tp + i] = (double)feats_spp[(size_t)my_idx[M + i] * D + d];  // intersect_feats :386, [D][Tp]
   }
   for (int i = ct; i < M; i += CT) {
     f.vec[V_Y][i] = i < desc.m1 ? -1.0 : 1.0;  // train_y  :396-398

@@ -184,7 +184,7 @@ def main():
             from gapro_amd import _lib as _l
             if _l.load().gapro_fit_route(m, args.d) == 4 and not args.no_cluster:
                 names = ["kzz", "chol:diag(leader)", "chol:panel", "chol:trailing", "inverse", "kx", "fwd:colpart",
-                         "-", "chol:flag", "quad+kl", "Gm+GA+GLS", "GKX", "GL", "Pm", "T1", "G", "kweights", "GZ",
+                         "-", "chol:flag", "quad+kl", "Gm+GA", "GLS+adamLS+GKX", "GL", "Pm", "T1", "G", "kgrads(fused)", "-",
                          "adam", "predict", "fwd:A", "fwd:B", "-", "-", "-", "-", "-", "-"]
             tot = prof.sum()
             print("    phases (us per fit, share): " + "  ".join(
