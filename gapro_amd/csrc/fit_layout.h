@@ -21,7 +21,9 @@ inline __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a *
 constexpr int kClMaxG = 32;                      // largest cluster (workgroups per fit)
 constexpr int kClThreads = 512;                  // threads per cluster workgroup
 constexpr int kClMaxThreads = kClMaxG * kClThreads;
-constexpr int kClusterMinMp = 272;               // smallest padded M that may be routed to the cluster kernel
+constexpr int kClusterMinMp = 192;               // smallest padded M that may be routed to the cluster kernel (its
+                                                 // scratch exists from here on; tiles are 32 wide: M_p % 32 == 0)
+constexpr int kClusterDefaultMinMp = 416;        // default routing threshold (gapro_cluster_min_mp)
 inline __host__ __device__ long long cluster_part_doubles(int Mp) {
   const long long w = Mp > kClMaxThreads ? Mp : kClMaxThreads;
   return 3 * w + 2 * 16 * kClMaxG;

@@ -2417,7 +2417,7 @@ __global__ void k_stream_calib(long long n, const double* __restrict__ src, doub
 constexpr int kSmallFitMp = 64;
 static int fit_route(int m, int feat_dim, int flags) {
   // large fits: spread over several CUs (svgp_fit_cluster.hip); debug bit 3 keeps them on one workgroup
-  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m)) > 1) return 4;
+  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m)) > 0) return 4;
   if (!(flags & 1) && strip_ok(m, feat_dim)) {
     const bool small = gapro_pad_m(m) <= kSmallFitMp && 2 * gapro_fit_strip_small_lds_bytes(m, feat_dim) + 16384 <= 160 * 1024;
     return (small && !(flags & 4)) ? 3 : 0;

@@ -25,6 +25,7 @@
 // members of a cluster are adjacent in dispatch order, so a cluster's members become resident together as soon
 // as CUs are free; the other fit kernels' workgroups never wait on anything.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -477,22 +478,31 @@ __device__ inline double sqdist_t(const gd* At, int i, const gd* Bt, int j, int 
   return s;
 }
 
-// Kzz + jitter I (lower incl. diagonal; identity on the padded tail) into B_L, dealt to the whole cluster
+// Kzz + jitter I (lower incl. diagonal; identity on the padded tail; zero above) into B_L.  A wave owns row i (its
+// point: broadcast loads) and walks the columns 64 at a time (coalesced loads of the transposed points).
 __device__ __noinline__ void build_kzz(double s, double inv_l2, double jitter) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   gd* L = f.mat[B_L];
-  const long long n = (long long)Mp * Mp;
-  for (long long idx = cl_tid(); idx < n; idx += cl_threads()) {
-    const int i = (int)(idx / Mp), j = (int)(idx - (long long)i * Mp);
-    double v = 0.0;
-    if (i < M && j <= i) {
-      v = s * exp(-0.5 * inv_l2 * sqdist_t(f.Zt, i, f.Zt, j, D, Mp));
-      if (i == j) v += jitter;
-    } else if (i >= M && i == j) {
-      v = 1.0;
+  const gd* Zt = f.Zt;
+  const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
+  for (int i = cw; i < Mp; i += CW) {
+    gd* row = L + (size_t)i * Mp;
+    for (int j = lane; j < Mp; j += 64) {
+      double v = 0.0;
+      if (i < M && j <= i) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double t = Zt[(size_t)d * Mp + i] - Zt[(size_t)d * Mp + j];
+          d2 += t * t;
+        }
+        v = s * exp(-0.5 * inv_l2 * d2);
+        if (i == j) v += jitter;
+      } else if (i >= M && i == j) {
+        v = 1.0;
+      }
+      row[j] = v;
     }
-    L[idx] = v;
   }
 }
 
@@ -645,19 +655,22 @@ __device__ __noinline__ void build_kx(const gd* Pt, int ldp, int ncols, double s
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   gd* KX = f.mat[B_KX];
-  const long long n = (long long)Mp * Mp;
-  for (long long idx = cl_tid(); idx < n; idx += cl_threads()) {
-    const int k = (int)(idx / Mp), c = (int)(idx - (long long)k * Mp);
-    double v = 0.0;
-    if (k < M && c < ncols) {
-      double d2 = 0.0;
-      for (int d = 0; d < D; ++d) {
-        const double t = f.Zt[(size_t)d * Mp + k] - Pt[(size_t)d * ldp + c];
-        d2 += t * t;
+  const gd* Zt = f.Zt;
+  const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
+  for (int k = cw; k < Mp; k += CW) {
+    gd* row = KX + (size_t)k * Mp;
+    for (int c = lane; c < Mp; c += 64) {
+      double v = 0.0;
+      if (k < M && c < ncols) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double t = Zt[(size_t)d * Mp + k] - Pt[(size_t)d * ldp + c];
+          d2 += t * t;
+        }
+        v = s * exp(-0.5 * inv_l2 * d2);
       }
-      v = s * exp(-0.5 * inv_l2 * d2);
+      row[c] = v;
     }
-    KX[idx] = v;
   }
 }
 
@@ -1217,11 +1230,24 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
 
 }  // namespace
 
-// Workgroups a fit of padded size Mp is spread over: the fit's work grows with Mp^3 while a launch's other fits
-// finish in a fraction of a second, so the largest fits get the most CUs (powers of two, at most kClMaxG).
+// Smallest padded M routed to this kernel (a fit below stays on one workgroup of the LDS-staged kernel).  Tunable for
+// A/B runs through GAPRO_CLUSTER_MIN_MP (read once).
+int gapro_cluster_min_mp() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GAPRO_CLUSTER_MIN_MP");
+    v = e ? atoi(e) : kClusterDefaultMinMp;
+    if (v < kClusterMinMp) v = kClusterMinMp;
+  }
+  return v;
+}
+
+// Workgroups a fit of padded size Mp is spread over (0 = not a cluster fit): the fit's work grows with Mp^3 while a
+// launch's other fits finish in a fraction of a second, so the largest fits get the most CUs (powers of two, at
+// most kClMaxG; one CU up to Mp = 384).
 int gapro_cluster_size(int Mp) {
-  if (Mp < kClusterMinMp) return 1;
-  const double work = (double)Mp * Mp * Mp / (384.0 * 384.0 * 384.0);  // 1 CU up to ~ M = 384
+  if (Mp < gapro_cluster_min_mp()) return 0;
+  const double work = (double)Mp * Mp * Mp / (384.0 * 384.0 * 384.0);
   int g = 1;
   while (g < kClMaxG && (double)g < work) g *= 2;
   return g;
