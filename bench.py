@@ -443,6 +443,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="ranks beyond the device count share GPUs (gloo control plane; test of the N>1 path on one GPU)")
     ap.add_argument("--force-staged", action="store_true", help="never use the strip-streaming fit kernel (A/B)")
+    ap.add_argument("--serial-kernels", action="store_true",
+                    help="diagnostic: the fit kernels of a launch one after the other on one stream (each kernel's own rate)")
     ap.add_argument("--stage-times", action="store_true", help="print per-stage wall clock to stderr (adds syncs)")
     ap.add_argument("--trace", action="store_true", help="print the host-side stage timeline of the timed steps to stderr")
     args = ap.parse_args()
@@ -504,6 +506,8 @@ def main():
 
     B = args.scenes_per_step
     pipe = Pipeline(device=dev_index, training_iter=50, force_staged=args.force_staged)
+    if args.serial_kernels:
+        pipe.opt.reserved |= 2
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -2525,7 +2525,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       if (ctx->d_cl_ctl) (void)hipFree(ctx->d_cl_ctl);
       ctx->d_cl_ctl = nullptr;
       ctx->cl_ctl_fits = 0;
-      GAPRO_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_cl_ctl, 2 * clus.size() * 128));
+      GAPRO_HIP_CHECK(ctx, hipMalloc((void**)&ctx->d_cl_ctl, 2 * 2 * clus.size() * 128));  // two halves
       ctx->cl_ctl_fits = 2 * clus.size();
     }
   }
@@ -2562,10 +2562,15 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     // the block table is built in one half of the context's pinned buffer, the halves alternating per launch: the
     // copy of launch i - 2 has long been consumed (callers collect a launch before they issue the one after next),
     // so the host never waits for the previous cluster kernel here
-    char* h_half = (char*)ctx->h_cl_stage + (ctx->cl_parity & 1) * (ctx->cl_stage_bytes / 2);
+    // (the device copies alternate the same way, so that two launches issued from different streams -- debug bit 1
+    // puts the kernels on the caller's stream -- never share a block table or a barrier counter)
+    const size_t par = ctx->cl_parity & 1;
+    char* h_half = (char*)ctx->h_cl_stage + par * (ctx->cl_stage_bytes / 2);
+    char* d_half = (char*)ctx->d_cl_stage + par * (ctx->cl_stage_bytes / 2);
+    unsigned* ctl_half = ctx->d_cl_ctl + par * ctx->cl_ctl_fits * 32;
     ctx->cl_parity++;
     const int rc = gapro_launch_fit_cluster(s_clus, (int)clus.size(), fi.data(), fmp.data(), fg.data(), feat_dim,
-                                            h_half, ctx->d_cl_stage, ctx->d_cl_ctl, d_feats_spp, d_idx, d_descs,
+                                            h_half, d_half, ctl_half, d_feats_spp, d_idx, d_descs,
                                             d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var,
                                             d_fit_status, d_fit_loss);
     if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: cluster kernel launch failed");
