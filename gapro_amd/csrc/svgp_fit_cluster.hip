@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -45,6 +46,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) double gd;
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(3))) double ldsd;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) float gf;  // float32 matrices of the mixed-precision mode
 
 __constant__ double c_gh_t[10] = {0.24534070830090124, 0.7374737285453944, 1.234076215395323,  1.7385377121165861,
                                   2.2549740020892757,  2.7888060584281305, 3.3478545673832163, 3.944764040115625,
@@ -193,9 +196,11 @@ __device__ __noinline__ void cl_reduce(double (&v)[K]) {
 //   dimension ld; each wave owns (16 TU) x (16 TU) output tiles; `lower_only` enumerates tiles ti >= tj.
 //   kr(i0, j0, &klo, &khi): contraction range (multiples of 8); epi(i, j, tile): one 16 x 16 result in C layout.
 //   Two register blocks of KS k-steps alternate with no guard in the steady-state body (see svgp_fit.hip).
-template <int TU, bool SCALE, typename KRange, typename Epi>
-__device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
-                                     const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+//   EP / EQ: element types of P and Q in memory (gd = float64, gf = float32: the mixed-precision mode's float32
+//   matrices feeding a float64 product are converted when a fragment is consumed, not when it is loaded).
+template <int TU, bool SCALE, typename EP = gd, typename EQ = gd, typename KRange, typename Epi>
+__device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const EP* __restrict__ P,
+                                     const EQ* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
   mo_tiles = uni(mo_tiles);
   no_tiles = uni(no_tiles);
@@ -231,15 +236,18 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
     for (int u = 0; u < TU; ++u)
 #pragma unroll
       for (int v = 0; v < TU; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
-    const gd* pbase = P + (size_t)lq * ld + i0 + lr;
-    const gd* qbase = Q + (size_t)lq * ld + j0 + lr;
-    double a0[KS][TU], b0[KS][TU], a1[KS][TU], b1[KS][TU];
+    const EP* pbase = P + (size_t)lq * ld + i0 + lr;
+    const EQ* qbase = Q + (size_t)lq * ld + j0 + lr;
+    typedef typename std::conditional<std::is_same<EP, gf>::value, float, double>::type VP;
+    typedef typename std::conditional<std::is_same<EQ, gf>::value, float, double>::type VQ;
+    VP a0[KS][TU], a1[KS][TU];
+    VQ b0[KS][TU], b1[KS][TU];
     double s0[KS], s1[KS];
-    auto load_block = [&](int k, double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
+    auto load_block = [&](int k, VP (&a)[KS][TU], VQ (&b)[KS][TU], double (&sc)[KS]) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const gd* pr = pbase + (size_t)(k + 4 * s) * ld;
-        const gd* qr = qbase + (size_t)(k + 4 * s) * ld;
+        const EP* pr = pbase + (size_t)(k + 4 * s) * ld;
+        const EQ* qr = qbase + (size_t)(k + 4 * s) * ld;
 #pragma unroll
         for (int u = 0; u < TU; ++u) a[s][u] = pr[16 * u];
 #pragma unroll
@@ -247,17 +255,114 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
         if (SCALE) sc[s] = qscale[k + 4 * s + lq];
       }
     };
-    auto mma_block = [&](double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
+    auto mma_block = [&](VP (&a)[KS][TU], VQ (&b)[KS][TU], double (&sc)[KS]) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         double bs[TU];
+#pragma unroll
+        for (int v = 0; v < TU; ++v) bs[v] = SCALE ? (double)b[s][v] * sc[s] : (double)b[s][v];
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int v = 0; v < TU; ++v)
+            acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a[s][u], bs[v], acc[u][v], 0, 0, 0);
+      }
+    };
+    if (klo < khi) {
+      load_block(klo, a0, b0, s0);
+      int k = klo;
+#pragma nounroll
+      for (; k + 2 * KB < khi; k += 2 * KB) {
+        load_block(k + KB, a1, b1, s1);
+        mma_block(a0, b0, s0);
+        load_block(k + 2 * KB, a0, b0, s0);
+        mma_block(a1, b1, s1);
+      }
+      if (k + KB < khi) {
+        load_block(k + KB, a1, b1, s1);
+        mma_block(a0, b0, s0);
+        mma_block(a1, b1, s1);
+      } else {
+        mma_block(a0, b0, s0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int v = 0; v < TU; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
+  }
+}
+
+// The same product on float32 operands with v_mfma_f32_16x16x4_f32 (the mixed-precision mode's L_S^T A, dA and dL_S
+// products): float32 accumulators in the standard C layout, register r -> row 4 (l >> 4) + r, column l & 15.
+template <int TU, bool SCALE, typename KRange, typename Epi>
+__device__ __noinline__ void gemm_tn_f32(int mo_tiles, int no_tiles, bool lower_only, const gf* __restrict__ P,
+                                         const gf* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+                                         Epi epi) {
+  mo_tiles = uni(mo_tiles);
+  no_tiles = uni(no_tiles);
+  lower_only = uni((int)lower_only) != 0;
+  ld = uni(ld);
+  P = uni_ptr(P);
+  Q = uni_ptr(Q);
+  qscale = uni_ptr(qscale);
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int cw = cl_wave(), CW = cl_waves();
+  constexpr int TS = 16 * TU;
+  constexpr int KS = 2, KB = 4 * KS;
+  const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
+#pragma nounroll
+  for (int t = cw; t < ntiles; t += CW) {
+    int ti, tj;
+    if (lower_only) {
+      ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      while (ti * (ti + 1) / 2 > t) --ti;
+      tj = t - ti * (ti + 1) / 2;
+    } else {
+      ti = t / no_tiles;
+      tj = t - ti * no_tiles;
+    }
+    const int i0 = ti * TS, j0 = tj * TS;
+    int klo, khi;
+    kr(i0, j0, &klo, &khi);
+    klo = uni(klo);
+    khi = uni(khi);
+    f4 acc[TU][TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int v = 0; v < TU; ++v) acc[u][v] = (f4){0.f, 0.f, 0.f, 0.f};
+    const gf* pbase = P + (size_t)lq * ld + i0 + lr;
+    const gf* qbase = Q + (size_t)lq * ld + j0 + lr;
+    typedef float VP;
+    typedef float VQ;
+    VP a0[KS][TU], a1[KS][TU];
+    VQ b0[KS][TU], b1[KS][TU];
+    float s0[KS], s1[KS];
+    auto load_block = [&](int k, VP (&a)[KS][TU], VQ (&b)[KS][TU], float (&sc)[KS]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const gf* pr = pbase + (size_t)(k + 4 * s) * ld;
+        const gf* qr = qbase + (size_t)(k + 4 * s) * ld;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) a[s][u] = pr[16 * u];
+#pragma unroll
+        for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v];
+        if (SCALE) sc[s] = (float)qscale[k + 4 * s + lq];
+      }
+    };
+    auto mma_block = [&](VP (&a)[KS][TU], VQ (&b)[KS][TU], float (&sc)[KS]) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float bs[TU];
 #pragma unroll
         for (int v = 0; v < TU; ++v) bs[v] = SCALE ? b[s][v] * sc[s] : b[s][v];
 #pragma unroll
         for (int u = 0; u < TU; ++u)
 #pragma unroll
           for (int v = 0; v < TU; ++v)
-            acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], bs[v], acc[u][v], 0, 0, 0);
+            acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][u], bs[v], acc[u][v], 0, 0, 0);
       }
     };
     if (klo < khi) {
@@ -286,8 +391,10 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 }
 
 // Store a 16x16 accumulator tile (C layout) row-major at Cm[i0.., j0..] and/or transposed at CT[j0.., i0..]; the
-// transposed copy goes through the wave's LDS tile so that its global stores are 128-byte rows too.
-__device__ inline void store_tile(const d4& v, gd* __restrict__ Cm, gd* __restrict__ CT, int ld, int i0, int j0) {
+// transposed copy goes through the wave's LDS tile so that its global stores are contiguous rows too.  EO: element
+// type of the destination (float32 destinations round here).
+template <typename EO = gd>
+__device__ inline void store_tile(const d4& v, EO* __restrict__ Cm, EO* __restrict__ CT, int ld, int i0, int j0) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   if (Cm) {
 #pragma unroll
@@ -301,6 +408,25 @@ __device__ inline void store_tile(const d4& v, gd* __restrict__ Cm, gd* __restri
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) CT[(size_t)(j0 + lq + 4 * r) * ld + i0 + lr] = tile[lr * 17 + lq + 4 * r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+// the same for a float32 MFMA result (register r -> row 4 (l >> 4) + r)
+__device__ inline void store_tile_f32(const f4& v, gf* __restrict__ Cm, gf* __restrict__ CT, int ld, int i0, int j0) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  if (Cm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cm[(size_t)(i0 + 4 * lq + r) * ld + j0 + lr] = v[r];
+  }
+  if (CT) {
+    ldsd* tile = (ldsd*)g_sh.tile + (threadIdx.x >> 6) * 16 * 17;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[(4 * lq + r) * 17 + lr] = (double)v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) CT[(size_t)(j0 + lq + 4 * r) * ld + i0 + lr] = (float)tile[lr * 17 + lq + 4 * r];
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
   }
@@ -480,24 +606,40 @@ __device__ inline double sqdist_t(const gd* At, int i, const gd* Bt, int j, int 
 
 // Kzz + jitter I (lower incl. diagonal; identity on the padded tail; zero above) into B_L.  A wave owns row i (its
 // point: broadcast loads) and walks the columns 64 at a time (coalesced loads of the transposed points).
-__device__ __noinline__ void build_kzz(double s, double inv_l2, double jitter) {
+// MX (mixed precision, the reference's split): the kernel matrix is evaluated in float32 arithmetic, as gpytorch
+// evaluates it, and handed to the float64 factorisation (K.double()).
+template <bool MX>
+__device__ __noinline__ void build_kzz(double s, double inv_l2, double jitter, double extra) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   gd* L = f.mat[B_L];
   const gd* Zt = f.Zt;
   const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
+  const float sf = (float)s, hf = -0.5f * (float)inv_l2, jf = (float)jitter;
   for (int i = cw; i < Mp; i += CW) {
     gd* row = L + (size_t)i * Mp;
     for (int j = lane; j < Mp; j += 64) {
       double v = 0.0;
       if (i < M && j <= i) {
-        double d2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-          const double t = Zt[(size_t)d * Mp + i] - Zt[(size_t)d * Mp + j];
-          d2 += t * t;
+        if (MX) {
+          float d2 = 0.f;
+          for (int d = 0; d < D; ++d) {
+            const float t = (float)Zt[(size_t)d * Mp + i] - (float)Zt[(size_t)d * Mp + j];
+            d2 += t * t;
+          }
+          float kv = sf * expf(hf * d2);
+          if (i == j) kv += jf;  // the variational jitter is added to the float32 matrix ...
+          v = (double)kv;
+          if (i == j) v += extra;  // ... psd_safe_cholesky's retry jitter to its float64 copy
+        } else {
+          double d2 = 0.0;
+          for (int d = 0; d < D; ++d) {
+            const double t = Zt[(size_t)d * Mp + i] - Zt[(size_t)d * Mp + j];
+            d2 += t * t;
+          }
+          v = s * exp(-0.5 * inv_l2 * d2);
+          if (i == j) v += jitter + extra;
         }
-        v = s * exp(-0.5 * inv_l2 * d2);
-        if (i == j) v += jitter;
       } else if (i >= M && i == j) {
         v = 1.0;
       }
@@ -538,7 +680,7 @@ __device__ __noinline__ void cholesky_cluster() {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[16 * q + 4 * st], pb[(size_t)(16 * q + 4 * st) * Mp], acc, 0, 0, 0);
         }
         // results go to L^T now and to L after every tile of this row block has read S (barrier below)
-        store_tile(acc, nullptr, LT, Mp, i0, c0 + 16 * cb);
+        store_tile(acc, (gd*)nullptr, LT, Mp, i0, c0 + 16 * cb);
       }
     }
     cbar();
@@ -636,7 +778,7 @@ __device__ __noinline__ void tri_inverse_cluster() {
 #pragma unroll
           for (int v = 0; v < 2; ++v) {
             if (pass == 0) {
-              store_tile(acc[u][v], Tm, nullptr, Mp, i0 + 16 * u, j0 + 16 * v);
+              store_tile(acc[u][v], Tm, (gd*)nullptr, Mp, i0 + 16 * u, j0 + 16 * v);
             } else {
               d4 neg;
 #pragma unroll
@@ -650,26 +792,42 @@ __device__ __noinline__ void tri_inverse_cluster() {
   }
 }
 
-// KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for k < M, n < ncols, zero elsewhere; Pt = the points transposed [D][ldp]
+// KX[k][n] = s exp(-|Z_k - P_n|^2 / (2 l^2)) for k < M, n < ncols, zero elsewhere; Pt = the points transposed [D][ldp].
+// MX: float32 arithmetic, float32 storage.
+template <bool MX>
 __device__ __noinline__ void build_kx(const gd* Pt, int ldp, int ncols, double s, double inv_l2) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   gd* KX = f.mat[B_KX];
+  gf* KXf = (gf*)f.mat[B_KX];
   const gd* Zt = f.Zt;
   const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
+  const float sf = (float)s, hf = -0.5f * (float)inv_l2;
   for (int k = cw; k < Mp; k += CW) {
-    gd* row = KX + (size_t)k * Mp;
     for (int c = lane; c < Mp; c += 64) {
-      double v = 0.0;
-      if (k < M && c < ncols) {
-        double d2 = 0.0;
-        for (int d = 0; d < D; ++d) {
-          const double t = Zt[(size_t)d * Mp + k] - Pt[(size_t)d * ldp + c];
-          d2 += t * t;
+      if (MX) {
+        float v = 0.f;
+        if (k < M && c < ncols) {
+          float d2 = 0.f;
+          for (int d = 0; d < D; ++d) {
+            const float t = (float)Zt[(size_t)d * Mp + k] - (float)Pt[(size_t)d * ldp + c];
+            d2 += t * t;
+          }
+          v = sf * expf(hf * d2);
         }
-        v = s * exp(-0.5 * inv_l2 * d2);
+        KXf[(size_t)k * Mp + c] = v;
+      } else {
+        double v = 0.0;
+        if (k < M && c < ncols) {
+          double d2 = 0.0;
+          for (int d = 0; d < D; ++d) {
+            const double t = Zt[(size_t)d * Mp + k] - Pt[(size_t)d * ldp + c];
+            d2 += t * t;
+          }
+          v = s * exp(-0.5 * inv_l2 * d2);
+        }
+        KX[(size_t)k * Mp + c] = v;
       }
-      row[c] = v;
     }
   }
 }
@@ -706,102 +864,135 @@ __device__ inline double col_final(int plane, int Mp, int c) {
   return acc;
 }
 
-// A = LI KX (+ A^T), B^T = A^T LS (+ B) over the first `ncols` columns, then the column partials of mu and var
+// A = LI KX (+ A^T), B^T = A^T LS (+ B) over the first `ncols` columns, then the column partials of mu and var.
+// MX: A = (L^-1 K_ZX in float64) rounded to float32 (gpytorch: interp_term ... .to(float32)); B in float32 on
+// v_mfma_f32 from the float32 A and L_S; the column sums read the float32 matrices and accumulate in float64.
+template <bool MX>
 __device__ __noinline__ void forward_products(int ncols) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp;
   const int mt = Mp / 32, nt = (ncols + 31) / 32;
-  gd* A = f.mat[B_A];
-  gd* AT = f.mat[B_AT];
-  gd* BM = f.mat[B_BM];
-  gd* BMT = f.mat[B_BMT];
   const gd* vm = f.vec[V_M];
-  gemm_tn<2, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
-                    [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
-                    [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n); });
-  cbar();
-  stamp(20);
-  gemm_tn<2, false>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
-                    [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
-                    [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j); });
-  cbar();
-  stamp(21);
-  col_partials(0, Mp, [=](int r, int c) { return vm[r] * A[(size_t)r * Mp + c]; });
-  col_partials(1, Mp, [=](int r, int c) {
-    const double a = A[(size_t)r * Mp + c], b = BM[(size_t)r * Mp + c];
-    return b * b - a * a;
-  });
+  if (MX) {
+    gf* A = (gf*)f.mat[B_A];
+    gf* AT = (gf*)f.mat[B_AT];
+    gf* BM = (gf*)f.mat[B_BM];
+    gf* BMT = (gf*)f.mat[B_BMT];
+    gemm_tn<2, false, gd, gf>(mt, nt, false, f.mat[B_U], (const gf*)f.mat[B_KX], Mp, nullptr,
+                              [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+                              [=](int i, int n, const d4& v) { store_tile<gf>(v, A, AT, Mp, i, n); });
+    cbar();
+    stamp(20);
+    gemm_tn_f32<2, false>(nt, mt, false, A, (const gf*)f.mat[B_LS], Mp, nullptr,
+                          [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                          [=](int n, int j, const f4& v) { store_tile_f32(v, BMT, BM, Mp, n, j); });
+    cbar();
+    stamp(21);
+    col_partials(0, Mp, [=](int r, int c) { return vm[r] * (double)A[(size_t)r * Mp + c]; });
+    col_partials(1, Mp, [=](int r, int c) {
+      const double a = A[(size_t)r * Mp + c], b = BM[(size_t)r * Mp + c];
+      return b * b - a * a;
+    });
+  } else {
+    gd* A = f.mat[B_A];
+    gd* AT = f.mat[B_AT];
+    gd* BM = f.mat[B_BM];
+    gd* BMT = f.mat[B_BMT];
+    gemm_tn<2, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+                      [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+                      [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n); });
+    cbar();
+    stamp(20);
+    gemm_tn<2, false>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
+                      [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                      [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j); });
+    cbar();
+    stamp(21);
+    col_partials(0, Mp, [=](int r, int c) { return vm[r] * A[(size_t)r * Mp + c]; });
+    col_partials(1, Mp, [=](int r, int c) {
+      const double a = A[(size_t)r * Mp + c], b = BM[(size_t)r * Mp + c];
+      return b * b - a * a;
+    });
+  }
   cbar();
 }
 
 // Kernel gradients of one Adam step; see the call site.  A function of its own: its per-row accumulators must not
-// live in the registers of the step loop.
-template <int DMAX>
+// live in the registers of the step loop.  MX: float32 arithmetic (the kernel's backward runs in float32 in the
+// reference: G_Kzz and G_KX arrive through .float()), KX is a float32 matrix, sums of the float32 terms in float64.
+template <int DMAX, bool MX>
 __device__ __noinline__ void kernel_grads(const gd* __restrict__ G, const gd* __restrict__ GT,
                                           const gd* __restrict__ GKX, const gd* __restrict__ KX, double s,
                                           double inv_l2, double (&ks)[2]) {
+  typedef typename std::conditional<MX, float, double>::type R;
   const Fit& f = g_sh.f;
   const int M = f.M, Mp = f.Mp, D = f.D;
   const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
   const gd* Zt = f.Zt;
   const gd* Xc = f.XtT;
+  const gf* KXf = (const gf*)KX;
+  const R sr = (R)s, hr = (R)(-0.5) * (R)inv_l2;
   double k0 = 0.0, k1 = 0.0;
   for (int i = cw; i < M; i += CW) {
-    double acc[DMAX], zi[DMAX];
+    R acc[DMAX], zi[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
-      acc[d] = 0.0;
-      zi[d] = d < D ? Zt[(size_t)d * Mp + i] : 0.0;
+      acc[d] = (R)0;
+      zi[d] = d < D ? (R)Zt[(size_t)d * Mp + i] : (R)0;
     }
-    double wsum = 0.0;
+    R wsum = (R)0;
     for (int j = lane; j < M; j += 64) {
       const size_t o = (size_t)i * Mp + j;
-      const double gsym = 0.5 * (G[o] + GT[o]);
-      const double gk = GKX[o], kx = KX[o];
-      double d2 = 0.0, d2x = 0.0;
+      const R gsym = (R)(0.5 * (G[o] + GT[o]));
+      const R gk = (R)GKX[o];
+      const R kx = MX ? (R)KXf[o] : (R)KX[o];
+      R d2 = (R)0, d2x = (R)0;
       if (DMAX <= 8) {  // narrow features: the column's points stay in registers between the two uses
-        double zj[DMAX], xj[DMAX];
+        R zj[DMAX], xj[DMAX];
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
-          zj[d] = d < D ? Zt[(size_t)d * Mp + j] : 0.0;
-          xj[d] = d < D ? Xc[(size_t)d * Mp + j] : 0.0;
-          const double a = zi[d] - zj[d], bx = zi[d] - xj[d];
+          zj[d] = d < D ? (R)Zt[(size_t)d * Mp + j] : (R)0;
+          xj[d] = d < D ? (R)Xc[(size_t)d * Mp + j] : (R)0;
+          const R a = zi[d] - zj[d], bx = zi[d] - xj[d];
           d2 += a * a;
           d2x += bx * bx;
         }
-        const double e = exp(-0.5 * inv_l2 * d2);
-        const double w = gsym * s * e, wx = gk * kx;
-        k0 += gsym * e + gk * kx / s;
-        k1 += w * d2 + wx * d2x;
+        const R e = MX ? (R)expf((float)(hr * d2)) : (R)exp((double)(hr * d2));
+        const R w = gsym * sr * e, wx = gk * kx;
+        k0 += (double)(gsym * e + gk * kx / sr);
+        k1 += (double)(w * d2 + wx * d2x);
         // sum_j w_j (Z_i - P_j) = Z_i sum_j w_j - sum_j w_j P_j : only the weighted point sums are accumulated
-        wsum += 2.0 * w + wx;
+        wsum += (R)2 * w + wx;
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) acc[d] += 2.0 * w * zj[d] + wx * xj[d];
-      } else {  // deep features (D = 32): re-read the column's points (L1 hits) instead of holding 64 more doubles
+        for (int d = 0; d < DMAX; ++d) acc[d] += (R)2 * w * zj[d] + wx * xj[d];
+      } else {  // deep features (D = 32): re-read the column's points (L1 hits) instead of holding 64 more values
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
           if (d < D) {
-            const double a = zi[d] - Zt[(size_t)d * Mp + j], bx = zi[d] - Xc[(size_t)d * Mp + j];
+            const R a = zi[d] - (R)Zt[(size_t)d * Mp + j], bx = zi[d] - (R)Xc[(size_t)d * Mp + j];
             d2 += a * a;
             d2x += bx * bx;
           }
         }
-        const double e = exp(-0.5 * inv_l2 * d2);
-        const double w = gsym * s * e, wx = gk * kx;
-        k0 += gsym * e + gk * kx / s;
-        k1 += w * d2 + wx * d2x;
-        wsum += 2.0 * w + wx;
+        const R e = MX ? (R)expf((float)(hr * d2)) : (R)exp((double)(hr * d2));
+        const R w = gsym * sr * e, wx = gk * kx;
+        k0 += (double)(gsym * e + gk * kx / sr);
+        k1 += (double)(w * d2 + wx * d2x);
+        wsum += (R)2 * w + wx;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d)
-          if (d < D) acc[d] += 2.0 * w * Zt[(size_t)d * Mp + j] + wx * Xc[(size_t)d * Mp + j];
+          if (d < D) acc[d] += (R)2 * w * (R)Zt[(size_t)d * Mp + j] + wx * (R)Xc[(size_t)d * Mp + j];
       }
     }
-    wsum = wave_sum(wsum);
+    const double wsum_d = wave_sum((double)wsum);
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
       if (d < D) {
-        const double a = wave_sum(acc[d]);
-        if (lane == 0) f.gZ[(size_t)i * D + d] = -inv_l2 * (wsum * zi[d] - a);
+        const double a = wave_sum((double)acc[d]);
+        if (lane == 0) {
+          const double gz = -inv_l2 * (wsum_d * (double)zi[d] - a);
+          f.gZ[(size_t)i * D + d] = MX ? (double)(float)gz : gz;
+        }
       }
     }
   }
@@ -809,6 +1000,7 @@ __device__ __noinline__ void kernel_grads(const gd* __restrict__ G, const gd* __
   ks[1] = k1;
 }
 
+template <bool MX>
 __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& desc, float* __restrict__ o_probs,
                          float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
                          float* __restrict__ o_mu, float* __restrict__ o_var, double* loss_out) {
@@ -833,15 +1025,33 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
   gd* vm = f.vec[V_M];
   gd* gmu = f.vec[V_GMU];
   gd* gv = f.vec[V_GV];
+  // mixed precision: the float32 matrices live in the first half of their float64 slot (leading dimension Mp)
+  gf* LSf = (gf*)LS;
+  gf* LSTf = (gf*)LST;
+  gf* MLSf = (gf*)MLS;
+  gf* VLSf = (gf*)VLS;
+  gf* Af = (gf*)A;
+  gf* ATf = (gf*)AT;
+  gf* BMf = (gf*)BM;
+  gf* BMTf = (gf*)BMT;
+  gf* GAf = (gf*)GA;
   const int ct = cl_tid(), CT = cl_threads();
   double last_loss = 0.0;
 
   auto refresh_hypers = [&]() {
     __syncthreads();
     if (threadIdx.x == 0) {
-      sh.s = softplus(sh.rho_s);
-      sh.ell = softplus(sh.rho_l);
-      sh.inv_l2 = 1.0 / (sh.ell * sh.ell);
+      if (MX) {  // float32 parameters and float32 softplus
+        const float rs = (float)sh.rho_s, rl = (float)sh.rho_l;
+        const float sv = log1pf(expf(-fabsf(rs))) + fmaxf(rs, 0.f), lv = log1pf(expf(-fabsf(rl))) + fmaxf(rl, 0.f);
+        sh.s = (double)sv;
+        sh.ell = (double)lv;
+        sh.inv_l2 = (double)(1.0f / (lv * lv));
+      } else {
+        sh.s = softplus(sh.rho_s);
+        sh.ell = softplus(sh.rho_l);
+        sh.inv_l2 = 1.0 / (sh.ell * sh.ell);
+      }
     }
     __syncthreads();
   };
@@ -849,7 +1059,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
   auto factorize = [&]() {
     double extra = 0.0;
     for (int attempt = 0;; ++attempt) {
-      build_kzz(sh.s, sh.inv_l2, jitter + extra);
+      build_kzz<MX>(sh.s, sh.inv_l2, jitter, extra);
       cbar();
       stamp(0);
       cholesky_cluster();
@@ -875,10 +1085,10 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     const double s = sh.s, ell = sh.ell, inv_l2 = sh.inv_l2, c = sh.c;
     // ------------------------------- forward -------------------------------
     factorize();
-    build_kx(f.XtT, Mp, M, s, inv_l2);
+    build_kx<MX>(f.XtT, Mp, M, s, inv_l2);
     cbar();
     stamp(5);
-    forward_products(M);
+    forward_products<MX>(M);
     stamp(6);
     // quadrature: 16 lanes per training point, lane q < 10 evaluates the symmetric node pair +-t_q of the 20-point
     // Gauss-Hermite rule (BernoulliLikelihood.expected_log_prob), the 16 lanes are summed by xor-shuffles
@@ -932,7 +1142,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
       for (long long idx = ct; idx < n; idx += CT) {
         const int i = (int)(idx / M), j = (int)(idx - (long long)i * M);
         if (j <= i) {
-          const double v = LS[(size_t)i * Mp + j];
+          const double v = MX ? (double)LSf[(size_t)i * Mp + j] : LS[(size_t)i * Mp + j];
           sums[3] += v * v;
           if (i == j) sums[3] -= log(v * v);
         }
@@ -950,6 +1160,71 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     const double step_size = opt.lr / bc1;
     // G_m partials (through A^T) and G_A read L_S; the Adam update of L_S is fused into the G_LS product of the
     // NEXT phase, which runs beside G_KX = LI^T G_A
+    if (MX) {
+      const float step_f = (float)step_size, bc2s_f = (float)bc2s, Ndf = (float)Nd;
+      col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * (double)ATf[(size_t)r * Mp + cc]; });
+      // G_A = m g_mu^T + L_S (2 B g_v) - 2 A g_v on v_mfma_f32 (float32 operands, float32 epilogue)
+      gemm_tn_f32<2, false>(mt, mt, false, LSTf, BMf, Mp, nullptr,
+                            [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+                            [=](int i0, int n0, const f4& v) {
+                              const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+                              const int n = n0 + lr;
+                              const float gvn = (float)gv[n], gmn = (float)gmu[n];
+#pragma unroll
+                              for (int r = 0; r < 4; ++r) {
+                                const int i = i0 + 4 * lq + r;  // float32 C layout
+                                const float a = Af[(size_t)i * Mp + n];
+                                GAf[(size_t)i * Mp + n] = 2.0f * gvn * v[r] + (float)vm[i] * gmn - 2.0f * a * gvn;
+                              }
+                            });
+      cbar();
+      stamp(10);
+      // G_LS (lower) + KL' with Adam on the float32 L_S in the epilogue
+      gemm_tn_f32<2, true>(mt, mt, true, ATf, BMTf, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+                           [=](int i0, int j0, const f4& v) {
+                             const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+                             const int j = j0 + lr;
+                             f4 newv;
+#pragma unroll
+                             for (int r = 0; r < 4; ++r) {
+                               const int i = i0 + 4 * lq + r;
+                               const size_t o = (size_t)i * Mp + j;
+                               float lnew = 0.f;
+                               if (j <= i && i < M) {
+                                 const float l = LSf[o];
+                                 const float g = 2.0f * v[r] + (l - (i == j ? 1.0f / l : 0.f)) / Ndf;
+                                 const float m1 = 0.9f * MLSf[o] + 0.1f * g;
+                                 const float m2 = 0.999f * VLSf[o] + 0.001f * g * g;
+                                 MLSf[o] = m1;
+                                 VLSf[o] = m2;
+                                 lnew = l - step_f * m1 / (sqrtf(m2) / bc2s_f + 1e-8f);
+                                 LSf[o] = lnew;
+                               }
+                               newv[r] = lnew;
+                             }
+                             store_tile_f32(newv, (gf*)nullptr, LSTf, Mp, i0, j0);
+                           });
+      // G_KX = LI^T G_A in float64 (the float32 G_A enters through .double())
+      gemm_tn<2, false, gd, gf>(mt, mt, false, f.mat[B_LI], GAf, Mp, nullptr,
+                                [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                                [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
+      cbar();
+      stamp(11);
+      // G_L = -tril(G_KX A^T) in float64 -> the whole B slot (the float32 B in its first half is dead)
+      gd* GLm = BM;
+      gemm_tn<2, false, gd, gf>(mt, mt, true, GKXT, ATf, Mp, nullptr,
+                                [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+                                [=](int i0, int j0, const d4& v) {
+                                  const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+#pragma unroll
+                                  for (int r = 0; r < 4; ++r) {
+                                    const int i = i0 + lq + 4 * r, j = j0 + lr;
+                                    GLm[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
+                                  }
+                                });
+      cbar();
+      stamp(12);
+    } else {
     col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
     gemm_tn<2, false>(mt, mt, false, LST, BM, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
@@ -990,7 +1265,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
                          }
                          newv[r] = lnew;
                        }
-                       store_tile(newv, nullptr, LST, Mp, i0, j0);  // LST[j][i]; zeros above the diagonal
+                       store_tile(newv, (gd*)nullptr, LST, Mp, i0, j0);  // LST[j][i]; zeros above the diagonal
                      });
     // G_KX = LI^T G_A
     gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
@@ -999,18 +1274,20 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     cbar();
     stamp(11);
     // G_L = -tril(G_KX A^T) -> BM buffer
-    gd* GL = BM;
+    gd* GLd = BM;
     gemm_tn<2, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                       [=](int i0, int j0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                           const int i = i0 + lq + 4 * r, j = j0 + lr;
-                          GL[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
+                          GLd[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
                         }
                       });
     cbar();
     stamp(12);
+    }
+    gd* GL = BM;
     // Pm = Phi(tril(L^T G_L)) -> GA buffer
     gd* Pm = GA;
     gemm_tn<2, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
@@ -1029,7 +1306,7 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     gd* T1T = BMT;
     gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
-                      [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j); });
+                      [=](int i, int j, const d4& v) { store_tile(v, (gd*)nullptr, T1T, Mp, i, j); });
     cbar();
     stamp(14);
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer
@@ -1045,8 +1322,8 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     //   w  = sym(G)[i][j] s E_ij  ->  G_s += sym(G) E,  G_l += w d2,   G_Z[i] += 2 w (Z_i - Z_j)
     //   wx = G_KX[i][j] KX_ij     ->  G_s += G_KX KX / s, G_l += wx d2x, G_Z[i] += wx (Z_i - X_j)
     double ks[2] = {0.0, 0.0};
-    if (D <= 8) kernel_grads<8>(G, GT, GKX, KX, s, inv_l2, ks);
-    else kernel_grads<32>(G, GT, GKX, KX, s, inv_l2, ks);
+    if (D <= 8) kernel_grads<8, MX>(G, GT, GKX, KX, s, inv_l2, ks);
+    else kernel_grads<32, MX>(G, GT, GKX, KX, s, inv_l2, ks);
     cl_reduce(ks);  // its barrier also publishes G_Z: every entry was computed from the OLD Z
     stamp(16);
     const double g_s = ks[0] + gv_sum;
@@ -1092,9 +1369,9 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
   const double s = sh.s, inv_l2 = sh.inv_l2, c = sh.c;
   for (int t0 = 0; t0 < T; t0 += Mp) {
     const int nc = (T - t0) < Mp ? (T - t0) : Mp;
-    build_kx(f.Xt + t0, round_up(T > 0 ? T : 1, 32), nc, s, inv_l2);
+    build_kx<MX>(f.Xt + t0, round_up(T > 0 ? T : 1, 32), nc, s, inv_l2);
     cbar();
-    forward_products(nc);
+    forward_products<MX>(nc);
     for (int n = ct; n < nc; n += CT) {
       const double mu = col_final(0, Mp, n) + c;
       const double var = fmax(s + jitter + col_final(1, Mp, n), opt.min_variance);
@@ -1218,7 +1495,10 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     f.mat[B_LST][(size_t)i * Mp + i] = 1.0;
   }
   cbar();
-  fit_body(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+  if (opt.precision == GAPRO_PRECISION_MIXED)
+    fit_body<true>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+  else
+    fit_body<false>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
   __syncthreads();
   if (sh.g == 0 && threadIdx.x == 0) {
     int st = sh.status;

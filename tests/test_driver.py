@@ -228,7 +228,9 @@ def test_cli_two_workers_write_every_scene_exactly_once(tmp_path, farm):
     assert sorted(os.listdir(two)) == sorted(s.scan_name + ".pth" for s in scenes)  # and no .claims.* directory
     written = [int(l.split("device 0: ")[1].split(" scenes written")[0]) for l in r.stdout.splitlines()
                if "scenes written" in l]
-    assert len(written) == 2 and sum(written) == len(scenes) and min(written) >= 1
+    assert len(written) == 2 and sum(written) == len(scenes)
+    if farm == "lpt":  # the static shard gives both workers something; with the queue a late starter may find it drained
+        assert min(written) >= 1
     for s in scenes:
         for u, v in zip(torch.load(os.path.join(one, s.scan_name + ".pth"), weights_only=False),
                         torch.load(os.path.join(two, s.scan_name + ".pth"), weights_only=False)):
