@@ -42,7 +42,7 @@ struct gapro_fit_timing {
 };
 
 // svgp_fit_cluster.hip
-int gapro_cluster_size(int Mp);
+int gapro_cluster_size(int Mp, bool all);
 size_t gapro_cluster_stage_bytes(int n_fits);
 int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, const int* fit_mp, const int* fit_g,
                              int feat_dim, void* h_stage, void* d_stage, unsigned* d_ctl, const float* d_feats_spp,

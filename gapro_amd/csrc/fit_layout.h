@@ -15,21 +15,31 @@ enum ScalId { S_C = 0, S_RS, S_RL, S_MC, S_MRS, S_MRL, S_VC, S_VRS, S_VRL, S_LOS
 
 inline __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
-// Fits spread over several workgroups (svgp_fit_cluster.hip) exchange partial sums through a scratch region at the
-// end of their workspace: 3 column-partial planes of max(kClMaxThreads, Mp) doubles + 2 x 16 scalar slots per member,
-// then the transposed copies Zt[D][Mp], Xt[D][Mp] of the inducing / training points (coalesced kernel evaluation).
+// Fits run by the cluster kernel (svgp_fit_cluster.hip: one fit over G workgroups) exchange partial sums through a
+// scratch region at the end of their workspace: 3 column-partial planes of max(G * 512, Mp) doubles + 2 x 16 scalar
+// slots per member, then the transposed copies Zt[D][Mp], Xt[D][Mp] of the inducing / training points.
 constexpr int kClMaxG = 32;                      // largest cluster (workgroups per fit)
 constexpr int kClThreads = 512;                  // threads per cluster workgroup
-constexpr int kClMaxThreads = kClMaxG * kClThreads;
-constexpr int kClusterMinMp = 192;               // smallest padded M that may be routed to the cluster kernel (its
-                                                 // scratch exists from here on; tiles are 32 wide: M_p % 32 == 0)
+constexpr int kClusterMinMp = 64;                // smallest padded M the cluster kernel takes (64-wide panels)
 constexpr int kClusterDefaultMinMp = 416;        // default routing threshold (gapro_cluster_min_mp)
+// workgroups a fit of padded size Mp is spread over: the work grows with Mp^3 while a launch's other fits finish in
+// a fraction of a second, so the largest fits get the most CUs (powers of two; one CU up to Mp = 384)
+inline __host__ __device__ int cluster_g(int Mp) {
+  const double work = (double)Mp * Mp * Mp / (384.0 * 384.0 * 384.0);
+  int g = 1;
+  while (g < kClMaxG && (double)g < work) g *= 2;
+  return g;
+}
+inline __host__ __device__ bool cluster_capable(int Mp) { return Mp >= kClusterMinMp && Mp % 32 == 0; }
+inline __host__ __device__ long long cluster_plane_doubles(int Mp) {
+  const long long t = (long long)cluster_g(Mp) * kClThreads;
+  return Mp > t ? Mp : t;
+}
 inline __host__ __device__ long long cluster_part_doubles(int Mp) {
-  const long long w = Mp > kClMaxThreads ? Mp : kClMaxThreads;
-  return 3 * w + 2 * 16 * kClMaxG;
+  return 3 * cluster_plane_doubles(Mp) + 2 * 16 * kClMaxG;
 }
 inline __host__ __device__ long long cluster_scratch_doubles(int Mp, int d) {
-  if (Mp < kClusterMinMp) return 0;
+  if (!cluster_capable(Mp)) return 0;
   return cluster_part_doubles(Mp) + 2LL * Mp * d;
 }
 

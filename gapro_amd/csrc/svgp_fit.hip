@@ -2413,11 +2413,11 @@ __global__ void k_stream_calib(long long n, const double* __restrict__ src, doub
 // 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel, 3 = strip-streaming kernel of the small-fit
 // translation unit (M_p <= 64: 256 threads per fit, two fits per CU), 4 = cluster kernel (one fit over several
 // workgroups).  flags: gapro_fit_options.reserved debug bits (bit 0: never the strip kernels, bit 2: no small-fit
-// kernel, bit 3: no cluster kernel).
+// kernel, bit 3: no cluster kernel, bit 4: the cluster kernel for every fit it can take, M_p >= 64 and M_p % 32 == 0).
 constexpr int kSmallFitMp = 64;
 static int fit_route(int m, int feat_dim, int flags) {
   // large fits: spread over several CUs (svgp_fit_cluster.hip); debug bit 3 keeps them on one workgroup
-  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m)) > 0) return 4;
+  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m), (flags & 16) != 0) > 0) return 4;
   if (!(flags & 1) && strip_ok(m, feat_dim)) {
     const bool small = gapro_pad_m(m) <= kSmallFitMp && 2 * gapro_fit_strip_small_lds_bytes(m, feat_dim) + 16384 <= 160 * 1024;
     return (small && !(flags & 4)) ? 3 : 0;
@@ -2556,7 +2556,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     for (size_t k = 0; k < clus.size(); ++k) {
       fi[k] = (int)(clus_base + k);
       fmp[k] = gapro_pad_m(clus[k].m1 + clus[k].m2);
-      fg[k] = gapro_cluster_size(fmp[k]);
+      fg[k] = gapro_cluster_size(fmp[k], true);
     }
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[6], s_clus));
     // the block table is built in one half of the context's pinned buffer, the halves alternating per launch: the

@@ -839,7 +839,7 @@ template <typename Term>
 __device__ inline void col_partials(int plane, int Mp, Term term) {
   const int CT = cl_threads(), ct = cl_tid();
   const int RG = CT / Mp > 0 ? CT / Mp : 1;
-  gd* out = g_sh.f.part + (size_t)plane * (Mp > kClMaxThreads ? Mp : kClMaxThreads);
+  gd* out = g_sh.f.part + (size_t)plane * cluster_plane_doubles(Mp);
   if (CT >= Mp) {
     const int rg = ct / Mp, c = ct - rg * Mp;
     if (rg < RG) {
@@ -858,7 +858,7 @@ __device__ inline void col_partials(int plane, int Mp, Term term) {
 __device__ inline double col_final(int plane, int Mp, int c) {
   const int CT = cl_threads();
   const int RG = CT / Mp > 0 ? CT / Mp : 1;
-  const gd* in = g_sh.f.part + (size_t)plane * (Mp > kClMaxThreads ? Mp : kClMaxThreads);
+  const gd* in = g_sh.f.part + (size_t)plane * cluster_plane_doubles(Mp);
   double acc = 0.0;
   for (int rg = 0; rg < RG; ++rg) acc += in[(size_t)rg * Mp + c];
   return acc;
@@ -1001,7 +1001,7 @@ __device__ __noinline__ void kernel_grads(const gd* __restrict__ G, const gd* __
 }
 
 template <bool MX>
-__device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& desc, float* __restrict__ o_probs,
+__device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& desc, float* __restrict__ o_probs,
                          float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
                          float* __restrict__ o_mu, float* __restrict__ o_var, double* loss_out) {
   const Fit& f = g_sh.f;
@@ -1331,7 +1331,16 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     stamp(17);
 
     // ------------------------------- Adam (Z, m, scalars; L_S was updated in the G_LS epilogue) --------------
+    // torch.optim.Adam; under MX on float32 parameters in float32 arithmetic (values kept in the float64 slots)
     auto adam = [&](double p, double& m1, double& m2, double g) {
+      if (MX) {
+        const float gf32 = (float)g;
+        const float a1 = 0.9f * (float)m1 + 0.1f * gf32;
+        const float a2 = 0.999f * (float)m2 + 0.001f * gf32 * gf32;
+        m1 = (double)a1;
+        m2 = (double)a2;
+        return (double)((float)p - (float)step_size * a1 / (sqrtf(a2) / (float)bc2s + 1e-8f));
+      }
       m1 = b1 * m1 + (1.0 - b1) * g;
       m2 = b2 * m2 + (1.0 - b2) * g * g;
       return p - step_size * m1 / (sqrt(m2) / bc2s + aeps);
@@ -1356,8 +1365,10 @@ __device__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& des
     __syncthreads();
     if (threadIdx.x == 0) {  // every workgroup keeps the scalars and applies the same update
       sh.c = adam(sh.c, sh.mc, sh.vc, g_c);
-      sh.rho_s = adam(sh.rho_s, sh.mrs, sh.vrs, g_s * sigmoid(sh.rho_s));
-      sh.rho_l = adam(sh.rho_l, sh.mrl, sh.vrl, g_l * sigmoid(sh.rho_l));
+      const double sg_s = MX ? (double)(1.0f / (1.0f + expf(-(float)sh.rho_s))) : sigmoid(sh.rho_s);
+      const double sg_l = MX ? (double)(1.0f / (1.0f + expf(-(float)sh.rho_l))) : sigmoid(sh.rho_l);
+      sh.rho_s = adam(sh.rho_s, sh.mrs, sh.vrs, g_s * sg_s);
+      sh.rho_l = adam(sh.rho_l, sh.mrl, sh.vrl, g_l * sg_l);
     }
     cbar();
     stamp(18);
@@ -1452,7 +1463,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     f.dinvT = f.dinv + (long long)lay.Mp * 16;
     f.scal = base + lay.scal;
     f.part = base + lay.cl;
-    f.red = f.part + 3LL * (lay.Mp > kClMaxThreads ? lay.Mp : kClMaxThreads);
+    f.red = f.part + 3LL * cluster_plane_doubles(lay.Mp);
     f.Zt = base + lay.cl + cluster_part_doubles(lay.Mp);
     f.XtT = f.Zt + (long long)lay.Mp * D;
     sh.G = cb.G;
@@ -1491,8 +1502,13 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
   for (int i = ct; i < M; i += CT) {
     f.vec[V_Y][i] = i < desc.m1 ? -1.0 : 1.0;  // train_y  :396-398
     f.vec[V_M][i] = init_mean ? init_mean[desc.idx_offset + i] : 0.0;
-    f.mat[B_LS][(size_t)i * Mp + i] = 1.0;  // chol_variational_covar = I
-    f.mat[B_LST][(size_t)i * Mp + i] = 1.0;
+    if (opt.precision == GAPRO_PRECISION_MIXED) {  // float32 matrices in the first half of their slots
+      ((gf*)f.mat[B_LS])[(size_t)i * Mp + i] = 1.0f;
+      ((gf*)f.mat[B_LST])[(size_t)i * Mp + i] = 1.0f;
+    } else {
+      f.mat[B_LS][(size_t)i * Mp + i] = 1.0;  // chol_variational_covar = I
+      f.mat[B_LST][(size_t)i * Mp + i] = 1.0;
+    }
   }
   cbar();
   if (opt.precision == GAPRO_PRECISION_MIXED)
@@ -1510,8 +1526,8 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
 
 }  // namespace
 
-// Smallest padded M routed to this kernel (a fit below stays on one workgroup of the LDS-staged kernel).  Tunable for
-// A/B runs through GAPRO_CLUSTER_MIN_MP (read once).
+// Smallest padded M routed to this kernel by default (a fit below stays on one workgroup of the LDS-staged / strip
+// kernels).  Tunable for A/B runs through GAPRO_CLUSTER_MIN_MP (read once).
 int gapro_cluster_min_mp() {
   static int v = -1;
   if (v < 0) {
@@ -1522,15 +1538,11 @@ int gapro_cluster_min_mp() {
   return v;
 }
 
-// Workgroups a fit of padded size Mp is spread over (0 = not a cluster fit): the fit's work grows with Mp^3 while a
-// launch's other fits finish in a fraction of a second, so the largest fits get the most CUs (powers of two, at
-// most kClMaxG; one CU up to Mp = 384).
-int gapro_cluster_size(int Mp) {
-  if (Mp < gapro_cluster_min_mp()) return 0;
-  const double work = (double)Mp * Mp * Mp / (384.0 * 384.0 * 384.0);
-  int g = 1;
-  while (g < kClMaxG && (double)g < work) g *= 2;
-  return g;
+// Workgroups a fit of padded size Mp is spread over by gapro_svgp_fit_batch; 0 = not a cluster fit.  `all`: every fit
+// the kernel can take (debug bit 4 of gapro_fit_options.reserved: precision sweeps through one kernel).
+int gapro_cluster_size(int Mp, bool all) {
+  if (!cluster_capable(Mp) || (!all && Mp < gapro_cluster_min_mp())) return 0;
+  return cluster_g(Mp);
 }
 
 // Internal launcher used by gapro_svgp_fit_batch (svgp_fit.hip).  `fits` = the n cluster fits' indices into the device

@@ -185,7 +185,7 @@ class FitTiming:
 
 class Pipeline:
     def __init__(self, device=0, training_iter=50, init_mean_std=0.0, seed=0, eval_stale_chol=False,
-                 spp_range_cap=None, force_staged=False):
+                 spp_range_cap=None, force_staged=False, precision="f64", cluster_all=False):
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
         if not torch.cuda.is_available():
             raise RuntimeError("gapro_amd needs a HIP device (torch.cuda.is_available() is False); "
@@ -198,6 +198,14 @@ class Pipeline:
         # reserved: 0 default dispatch (strip-streaming kernel for M_p <= 128, LDS-staged kernel up to 512, generic
         # kernel beyond); 1 = never the strip kernel (A/B runs, tests)
         self.opt.reserved = 1 if force_staged else 0
+        # precision: "f64" (default, float64 throughout) or "mixed" (the reference's float32 / float64 split, run by
+        # the cluster kernel; fits routed elsewhere stay float64).  cluster_all: the cluster kernel for every fit it
+        # can take (precision sweeps, A/B runs)
+        if precision not in ("f64", "mixed"):
+            raise ValueError("precision must be 'f64' or 'mixed'")
+        self.opt.precision = 1 if precision == "mixed" else 0
+        if cluster_all:
+            self.opt.reserved |= 16
         self.init_mean_std = float(init_mean_std)
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap
@@ -729,6 +737,12 @@ class Pipeline:
             route = {int(v): int(lib.gapro_fit_route(int(v), D)) for v in np.unique(m)}
             flags = int(self.opt.reserved)
             r = np.array([route[int(v)] for v in m])
+            if flags & 16:
+                for v in np.unique(m):
+                    mp = (int(v) + 15) // 16 * 16
+                    mp = mp if mp <= 176 else (int(v) + 31) // 32 * 32
+                    if mp >= 64 and mp % 32 == 0 and D <= 32:
+                        r[m == v] = 4
             if flags & 8:  # no cluster kernel: those fits run where they ran in round 1
                 for v in np.unique(m[r == 4]):
                     r[m == v] = 1 if int(v) <= 512 and D <= 32 else 2

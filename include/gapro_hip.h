@@ -312,7 +312,8 @@ typedef struct {
   int32_t reserved;          /* 0; debug bits: 1 = never route a fit to the strip-streaming kernels,
                               * 2 = launch the fit kernels on the caller's stream (not the fit streams),
                               * 4 = no small-fit kernel (M_p <= 64 runs the 512-thread strip kernel),
-                              * 8 = no cluster kernel (large fits stay on one workgroup) */
+                              * 8 = no cluster kernel (large fits stay on one workgroup),
+                              * 16 = the cluster kernel for every fit it can take (M_p >= 64, M_p % 32 == 0) */
   int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive
                               *      pivot is repeated on K + psd_jitter 10^i I, i < psd_retries (psd_safe_cholesky,
                               *      reached from gaussian_process_utils.py:417); 0 = fail at once */
@@ -325,7 +326,9 @@ enum {
   GAPRO_PRECISION_F64 = 0,   /* everything in float64 (a superset of the reference's split) */
   GAPRO_PRECISION_MIXED = 1  /* the reference's own split: parameters, kernel matrices, A, B, variances and their
                               * gradients in float32 (v_mfma_f32), float64 for the Cholesky factor, the L^-1
-                              * products and their backward (gpytorch _cholesky_factor / torch autograd) */
+                              * products and their backward (gpytorch _cholesky_factor / torch autograd).
+                              * Implemented by the cluster kernel (route 4); fits routed to the other kernels run
+                              * in float64, a superset of the split */
 };
 
 void gapro_fit_options_default(gapro_fit_options* opt);

@@ -75,8 +75,15 @@ def psd_safe_cholesky(A, jitter=PSD_JITTER, max_tries=PSD_MAX_TRIES):
 
 def svgp_fit_predict_autograd(train_x, train_y, test_x, training_iter=50, dtype="f64", init_mean=None,
                               jitter=JITTER, eval_chol="fresh", lr=ADAM_LR, return_trace=False):
+    """dtype: "f64" all float64 (ground truth); "mixed" the reference's split (float32 everywhere, float64 for the
+    Cholesky factor and the triangular solve); tolerance-study modes of BASELINE configs[4]: "f32" float32 everywhere
+    including the factorisation, "bf16in" = "mixed" with the input features rounded to bfloat16 first."""
     import torch
 
+    if dtype == "bf16in":
+        train_x = torch.as_tensor(np.asarray(train_x), dtype=torch.float32).bfloat16().float().numpy()
+        test_x = torch.as_tensor(np.asarray(test_x), dtype=torch.float32).bfloat16().float().numpy()
+    chol_dt = torch.float32 if dtype == "f32" else torch.float64
     T = torch.float64 if dtype == "f64" else torch.float32
     X = torch.as_tensor(np.asarray(train_x), dtype=T)
     y = torch.as_tensor(np.asarray(train_y), dtype=T)
@@ -101,13 +108,13 @@ def svgp_fit_predict_autograd(train_x, train_y, test_x, training_iter=50, dtype=
         ell = torch.nn.functional.softplus(rho_l)
         s = torch.nn.functional.softplus(rho_s)
         Kzz = s * torch.exp(-0.5 * sqdist(Z / ell, Z / ell)) + jitter * torch.eye(M, dtype=T)
-        return psd_safe_cholesky(Kzz.double())  # _cholesky_factor: psd_safe_cholesky(K.double())
+        return psd_safe_cholesky(Kzz.to(chol_dt), jitter=PSD_JITTER if chol_dt == torch.float64 else 1e-6)  # K.double()
 
     def q_f(x, L):
         ell = torch.nn.functional.softplus(rho_l)
         s = torch.nn.functional.softplus(rho_s)
         Kzx = s * torch.exp(-0.5 * sqdist(Z / ell, x / ell))
-        A = torch.linalg.solve_triangular(L, Kzx.double(), upper=False).to(T)  # interp_term
+        A = torch.linalg.solve_triangular(L, Kzx.to(chol_dt), upper=False).to(T)  # interp_term
         mean = A.t() @ m + c
         B = torch.tril(LS).t() @ A
         var = s + jitter + ((B * B) - (A * A)).sum(0)
