@@ -608,15 +608,19 @@ def driver_line(scenes=384, unique=24, procs=16):
     import subprocess
 
     cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_driver.py"), "--scenes", str(scenes), "--unique",
-           str(unique), "--procs", str(procs), "--batch", "32"]
+           str(unique), "--procs", str(procs), "--batch", "32", "--raw-cache"]
     try:
-        txt = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT).stdout
-        m = re.search(r"(\d+) scenes written.*?\(([\d.]+) scenes/s\)", txt)
-        if not m:
+        txt = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT).stdout
+        ms = re.findall(r"(\d+) scenes written.*?\(([\d.]+) scenes/s\)", txt)
+        if not ms:
             return {"error": txt[-300:]}
-        return {"value": float(m.group(2)), "unit": "scenes/s", "scenes": int(m.group(1)),
-                "what": "gen_ps driver end to end on disk data (fixed 150k-point scenes, %d loader processes), "
-                        "tools/bench_driver.py" % procs}
+        out = {"value": float(ms[0][1]), "unit": "scenes/s", "scenes": int(ms[0][0]),
+               "what": "gen_ps driver end to end on disk data (fixed 150k-point scenes, %d loader processes): torch.load "
+                       "of the .pth files, host preprocessing, upload, generation, torch.save; tools/bench_driver.py" % procs}
+        if len(ms) > 1:
+            out["value_raw_cache"] = float(ms[1][1])
+            out["raw_cache"] = "the same run over the opt-in raw scene cache (gen_ps --raw_cache: memory-mapped flat files)"
+        return out
     except Exception as e:  # noqa: BLE001 - extra key only
         return {"error": repr(e)}
 

@@ -22,6 +22,12 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
     --init_mean_std S      std of the random initial variational mean (gpytorch: 1e-3 unseeded;
                            default 0 = deterministic), --seed seeds it
     --broadcast_mu_var     write mu/var at point length (what the released data loaders index)
+    --raw_cache DIR        opt-in raw scene cache: the first run writes, next to nothing else, one flat file per scene
+                           (<DIR>/<scan>.gaproraw: the arrays of read_scene exactly as they are uploaded, 64-byte
+                           aligned, with the sizes and mtimes of the source files in its header); later runs map it
+                           (np.memmap) and upload straight from the page cache -- no unpickling, no loader process,
+                           no shared-memory copy.  A cache whose source files changed is rebuilt.  Unpickling the
+                           ScanNet .pth tuples is what caps the loaders at ~350 scenes/s per host
     --loader_threads T     threads that read scenes from disk a batch ahead and write the results (default 4)
     --loader_procs P       read and write in P loader PROCESSES (default -1 = min(16, cores/4); 0 = threads only).
                            Unpickling a ScanNet .pth holds the GIL, so threads top out near one core; processes
@@ -113,6 +119,78 @@ def save_scene(save_path, outs, spp_inv=None, broadcast_mu_var=False):
 _SHM_KEYS = ("coords_float", "mask_feats", "spp", "semantic_label", "instance_label", "wall_box", "wall_box_volume")
 
 
+_RAW_MAGIC = b"GAPRORAW1\n"
+
+
+def _source_stamp(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
+    """(size, mtime_ns) of every file read_scene reads for this scene: a cache written from other bytes is stale."""
+    scan_name = filename.split("/")[-1][:12]
+    files = [filename, osp.join(data_root, "superpoints", scan_name + ".pth"),
+             osp.join(data_root, "scans_transform", scan_name, scan_name + ".txt"),
+             osp.join(data_root, "scannet_planes", scan_name + ".json")]
+    if use_deepfeat:
+        files.append(osp.join(deepfeat_folder, scan_name + ".pth"))
+    stamp = []
+    for fn in files:
+        try:
+            st = os.stat(fn)
+            stamp.append([os.path.basename(fn), int(st.st_size), int(st.st_mtime_ns)])
+        except OSError:
+            stamp.append([os.path.basename(fn), -1, -1])
+    return stamp
+
+
+def raw_cache_path(cache_dir, filename):
+    return osp.join(cache_dir, filename.split("/")[-1][:12] + ".gaproraw")
+
+
+def write_raw_cache(path, sc, stamp):
+    """One flat file: magic | u64 header length | JSON header | arrays (64-byte aligned), written atomically."""
+    import json
+
+    arrs = {k: np.ascontiguousarray(np.asarray(sc[k])) for k in _SHM_KEYS}
+    fields, off = [], 0
+    for k in _SHM_KEYS:
+        a = arrs[k]
+        fields.append([k, a.dtype.str, list(a.shape), off])
+        off += (a.nbytes + 63) // 64 * 64
+    header = json.dumps(dict(scan_name=sc["scan_name"], stamp=stamp, fields=fields, nbytes=off)).encode()
+    pre = len(_RAW_MAGIC) + 8 + len(header)
+    pad = (-pre) % 64
+    tmp = path + ".tmp.%d" % os.getpid()
+    with open(tmp, "wb") as fh:
+        fh.write(_RAW_MAGIC)
+        fh.write(np.uint64(len(header) + pad).tobytes())
+        fh.write(header + b" " * pad)
+        for (k, _, _, o) in fields:
+            a = arrs[k]
+            fh.write(a.tobytes())
+            fh.write(b"\0" * ((-a.nbytes) % 64))
+    os.replace(tmp, path)
+
+
+def read_raw_cache(path, stamp):
+    """The cached scene as a dict of read-only memory-mapped arrays, or None (absent, stale or damaged)."""
+    import json
+
+    try:
+        with open(path, "rb") as fh:
+            if fh.read(len(_RAW_MAGIC)) != _RAW_MAGIC:
+                return None
+            hlen = int(np.frombuffer(fh.read(8), dtype=np.uint64)[0])
+            header = json.loads(fh.read(hlen).decode())
+        base = len(_RAW_MAGIC) + 8 + hlen
+        if header["stamp"] != stamp or os.path.getsize(path) < base + header["nbytes"]:
+            return None
+        sc = dict(scan_name=header["scan_name"])
+        for (k, dt, shape, off) in header["fields"]:
+            n = int(np.prod(shape)) if len(shape) else 1
+            sc[k] = np.memmap(path, dtype=np.dtype(dt), mode="r", offset=base + off, shape=tuple(shape)) if n else []
+        return sc
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def _loader_init():
     """Loader process start-up: single-threaded BLAS / torch (the pool is the parallelism)."""
     torch.set_num_threads(1)
@@ -124,12 +202,19 @@ def _loader_init():
         pass
 
 
-def _read_scene_shm(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
+def _read_scene_shm(filename, data_root, use_deepfeat=False, deepfeat_folder=None, raw_cache=None):
     """Loader process: read_scene, then the arrays go into ONE POSIX shared-memory block (64-byte aligned
-    fields) and only its name and layout travel back through the pipe."""
+    fields) and only its name and layout travel back through the pipe.  With a raw cache directory the scene is
+    also written there, so that the next run maps it instead of unpickling."""
     from multiprocessing import shared_memory
 
     sc = read_scene(filename, data_root, use_deepfeat, deepfeat_folder)
+    if raw_cache:
+        try:
+            write_raw_cache(raw_cache_path(raw_cache, filename), sc,
+                            _source_stamp(filename, data_root, use_deepfeat, deepfeat_folder))
+        except OSError as e:  # a full disk must not lose the scene
+            print("[gen_ps] raw cache not written for %s: %r" % (filename, e), file=sys.stderr)
     arrs = {k: np.ascontiguousarray(np.asarray(sc[k])) for k in _SHM_KEYS}
     layout, off = [], 0
     for k in _SHM_KEYS:
@@ -247,6 +332,10 @@ def run_worker(filenames, args, device_index):
     pool = cf.ThreadPoolExecutor(max_workers=max(1, args.loader_threads))
     meta = []  # per yielded batch: (scenes, jobs)
     read_args = (args.data_root, args.use_deepfeat, args.deepfeat_folder)
+    raw_cache = getattr(args, "raw_cache", None)
+    if raw_cache:
+        os.makedirs(raw_cache, exist_ok=True)
+    cache_hits = [0]
     spent = dict(wait=0.0, upload=0.0, boxes=0.0, jobs=0.0, export=0.0)  # main-thread seconds, GAPRO_DRIVER_TIMES=1
 
     tls = threading.local()
@@ -272,17 +361,49 @@ def run_worker(filenames, args, device_index):
             inv = job.spp_inv.cpu().numpy() if args.broadcast_mu_var else None
         return procs.apply_async(_save_arrays, (path, arrays, inv))
 
-    def submit(chunk):
-        if procs is not None:  # read in a loader process; a pool thread maps the block and uploads from it
-            reads = [(fn, procs.apply_async(_read_scene_shm, (fn,) + read_args)) for fn in chunk]
-            return [(fn, pool.submit(upload, r)) for fn, r in reads]
-        return [(fn, pool.submit(read_scene, fn, *read_args)) for fn in chunk]
+    def upload_cached(fn, sc):
+        """Pool thread: a raw-cache hit -- the arrays are memory-mapped files, uploaded straight from the page cache."""
+        with torch.cuda.stream(side_stream()):
+            dev_sc = dict(scan_name=sc["scan_name"])
+            for k in _SHM_KEYS:
+                v = sc[k]
+                if k in _DEVICE_DTYPES:
+                    dev_sc[k] = torch.from_numpy(np.asarray(v)).to(device=dev, dtype=_DEVICE_DTYPES[k])
+                else:
+                    dev_sc[k] = np.array(v) if len(v) else []
+            return add_instance_info(dev_sc, dev)
 
-    def fetch(fut):
+    def read_and_cache(fn):
+        sc = read_scene(fn, *read_args)
+        if raw_cache:
+            try:
+                write_raw_cache(raw_cache_path(raw_cache, fn), sc, _source_stamp(fn, *read_args))
+            except OSError as e:
+                print("[gen_ps] raw cache not written for %s: %r" % (fn, e), file=sys.stderr)
+        return sc
+
+    def submit(chunk):
+        out, misses = [], []
+        for fn in chunk:
+            sc = read_raw_cache(raw_cache_path(raw_cache, fn), _source_stamp(fn, *read_args)) if raw_cache else None
+            if sc is not None:
+                cache_hits[0] += 1
+                out.append((fn, pool.submit(upload_cached, fn, sc), True))
+            else:
+                misses.append(fn)
+        if procs is not None:  # read in a loader process; a pool thread maps the block and uploads from it
+            reads = [(fn, procs.apply_async(_read_scene_shm, (fn,) + read_args + (raw_cache,))) for fn in misses]
+            out += [(fn, pool.submit(upload, r), True) for fn, r in reads]
+        else:
+            out += [(fn, pool.submit(read_and_cache, fn), False) for fn in misses]
+        order = {fn: i for i, fn in enumerate(chunk)}
+        return sorted(out, key=lambda e: order[e[0]])
+
+    def fetch(fut, on_device):
         t = time.time()
         got = fut.result()
         t1 = time.time()
-        if procs is not None:
+        if on_device:
             spent["wait"] += t1 - t
             return got
         sc = scene_to_device(got, dev)
@@ -307,9 +428,9 @@ def run_worker(filenames, args, device_index):
             if c:
                 ahead.append(submit(c))
             scenes = []
-            for fn, fut in futs:
+            for fn, fut, on_device in futs:
                 try:
-                    sc = fetch(fut)
+                    sc = fetch(fut, on_device)
                     if sc is None:
                         print("[gen_ps] %s: no instances, skipped" % fn, file=sys.stderr)
                         failed += 1
@@ -367,8 +488,9 @@ def run_worker(filenames, args, device_index):
             procs.close()
             procs.join()
     dt = time.time() - t0
-    print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)"
-          % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0))
+    print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)%s"
+          % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0,
+             ", %d from the raw cache" % cache_hits[0] if raw_cache else ""))
     if os.environ.get("GAPRO_DRIVER_TIMES"):
         print("[gen_ps] main-thread seconds: " + ", ".join("%s %.2f" % kv for kv in spent.items()))
     return done, failed
@@ -388,6 +510,7 @@ def main(argv=None):
     parser.add_argument("--init_mean_std", type=float, default=0.0)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--broadcast_mu_var", action="store_true")
+    parser.add_argument("--raw_cache", type=str, default=None)
     parser.add_argument("--loader_threads", type=int, default=4)
     parser.add_argument("--loader_procs", type=int, default=-1)
     parser.add_argument("--farm", type=str, default="queue", choices=["queue", "lpt", "roundrobin"])

@@ -236,3 +236,65 @@ def test_cli_two_workers_write_every_scene_exactly_once(tmp_path, farm):
                         torch.load(os.path.join(two, s.scan_name + ".pth"), weights_only=False)):
             assert u.dtype == v.dtype
             np.testing.assert_array_equal(u, v)
+
+
+def test_raw_cache_round_trip_is_byte_exact_and_notices_changed_sources(tmp_path):
+    """--raw_cache: the flat per-scene file holds exactly the arrays read_scene produces (dtype, shape, bytes), maps
+    back read-only, and is rejected once a source file changes (size / mtime stamp in its header)."""
+    from gapro_amd.gen_ps import (_SHM_KEYS, _source_stamp, raw_cache_path, read_raw_cache, read_scene,
+                                  write_raw_cache)
+
+    root, scenes = _dataset(tmp_path, 2)
+    cache = str(tmp_path / "cache")
+    os.makedirs(cache)
+    for sc in scenes:  # scene 0 has wall quads, scene 1 has none
+        fn = os.path.join(root, "train", sc.scan_name + "_inst_nostuff.pth")
+        want = read_scene(fn, root)
+        stamp = _source_stamp(fn, root)
+        path = raw_cache_path(cache, fn)
+        assert read_raw_cache(path, stamp) is None  # nothing there yet
+        write_raw_cache(path, want, stamp)
+        got = read_raw_cache(path, stamp)
+        assert got is not None and got["scan_name"] == want["scan_name"]
+        for k in _SHM_KEYS:
+            a, b = np.asarray(want[k]), np.asarray(got[k])
+            assert a.shape == b.shape and (a.size == 0 or (a.dtype == b.dtype and a.tobytes() == b.tobytes())), k
+        assert os.listdir(cache).count(os.path.basename(path)) == 1 and not [f for f in os.listdir(cache) if ".tmp." in f]
+    # a changed source invalidates the cache
+    sp = os.path.join(root, "superpoints", scenes[0].scan_name + ".pth")
+    torch.save(np.arange(scenes[0].n_points, dtype=np.int64), sp)
+    fn0 = os.path.join(root, "train", scenes[0].scan_name + "_inst_nostuff.pth")
+    assert read_raw_cache(raw_cache_path(cache, fn0), _source_stamp(fn0, root)) is None
+    # a truncated file is rejected, not mapped
+    fn1 = os.path.join(root, "train", scenes[1].scan_name + "_inst_nostuff.pth")
+    p1 = raw_cache_path(cache, fn1)
+    with open(p1, "r+b") as fh:
+        fh.truncate(os.path.getsize(p1) // 2)
+    assert read_raw_cache(p1, _source_stamp(fn1, root)) is None
+
+
+@pytest.mark.gpu
+def test_cli_raw_cache_second_run_maps_the_cache_and_writes_the_same_files(tmp_path):
+    import subprocess
+    import sys
+
+    root, scenes = _dataset(tmp_path, 5)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = str(tmp_path / "cache")
+    outs = []
+    for k, extra in enumerate((["--loader_procs", "2"], ["--loader_procs", "2"], ["--loader_procs", "0"])):
+        save = str(tmp_path / ("run%d" % k))
+        r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", root,
+                            "--batch_scenes", "2", "--raw_cache", cache] + extra, cwd=repo, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hits = int(r.stdout.split(" from the raw cache")[0].split(", ")[-1])
+        assert hits == (0 if k == 0 else len(scenes)), r.stdout
+        outs.append(save)
+    assert len(os.listdir(cache)) == len(scenes)
+    for s in scenes:
+        a = torch.load(os.path.join(outs[0], s.scan_name + ".pth"), weights_only=False)
+        for other in outs[1:]:
+            for u, v in zip(a, torch.load(os.path.join(other, s.scan_name + ".pth"), weights_only=False)):
+                assert u.dtype == v.dtype
+                np.testing.assert_array_equal(u, v)

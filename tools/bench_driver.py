@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--unique", type=int, default=32, help="distinct scenes on disk; the rest are links")
     ap.add_argument("--procs", type=int, default=0, help="loader processes (0 = threads)")
+    ap.add_argument("--raw-cache", action="store_true",
+                    help="also time a run over the opt-in raw scene cache (gen_ps --raw_cache), written by the warm run")
     args = ap.parse_args()
     from gapro_amd import gen_ps
     from gapro_amd.synth import make_scene, write_scannet_layout
@@ -48,19 +50,23 @@ def main():
         # run warms the page cache and the code-object cache, the second one is timed on fresh outputs
         import subprocess
 
-        def run(save):
+        def run(save, cache=None):
             cmd = [sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", data,
                    "--batch_scenes", str(args.batch), "--loader_threads", str(args.threads), "--loader_procs",
-                   str(args.procs)]
+                   str(args.procs)] + (["--raw_cache", cache] if cache else [])
             t = time.time()
             out = subprocess.run(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                  capture_output=True, text=True, check=True).stdout
             lines = out.strip().splitlines()
             return time.time() - t, "\n".join(l for l in lines if l.startswith("[gen_ps]"))
 
-        run(os.path.join(root, "warm"))
+        cache = os.path.join(root, "rawcache") if args.raw_cache else None
+        run(os.path.join(root, "warm"), cache)  # also writes the raw cache when asked
         dt, line = run(os.path.join(root, "labels"))
         print(line)
+        if cache:
+            dtc, linec = run(os.path.join(root, "labels_cached"), cache)
+            print("raw cache: " + linec)
         print("driver process wall time %.2f s (includes interpreter start and library load)" % dt)
         print("loaders: %s" % ("%d processes" % args.procs if args.procs else "%d threads" % args.threads))
     finally:
