@@ -123,7 +123,8 @@ def pmc_traffic(workload, scenes_per_step, points, feat_dim, distinct):
         best = (rec, fn)
     if best is None:
         return None, None
-    return float(best[0]["strip_kernel"]["hbm_bytes_per_launch"]), os.path.relpath(best[1], ROOT)
+    key = "fit_launch" if "fit_launch" in best[0] else "strip_kernel"
+    return float(best[0][key]["hbm_bytes_per_launch"]), os.path.relpath(best[1], ROOT)
 
 
 _CPU_JOBS = None

@@ -36,9 +36,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("src")
     ap.add_argument("tag")
-    ap.add_argument("--scenes-per-step", type=int, default=64)
+    ap.add_argument("--scenes-per-step", type=int, default=256)
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--feat-dim", type=int, default=6)
+    ap.add_argument("--workload", default="stream")
+    ap.add_argument("--distinct", type=int, default=64)
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -60,13 +62,16 @@ def main():
     write_unit = n_bytes * (w_launches / 2) / w_sum if w_sum else None  # half of the launches (mode 1) write n_bytes
     pf = counters(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"))
     pw = counters(os.path.join(src, "pmc_write", "bench_counter_collection.csv"))
-    traffic = {"workload": {"scenes_per_step": a.scenes_per_step, "points": a.points, "feat_dim": a.feat_dim},
+    traffic = {"workload": {"name": a.workload, "scenes_per_step": a.scenes_per_step, "points": a.points,
+                            "feat_dim": a.feat_dim, "distinct": a.distinct},
                "calibration": {"kernel": "k_stream_calib (one double per lane, grid-stride, 512 MiB per pass)",
                                "bytes_per_FETCH_SIZE_unit": fetch_unit, "bytes_per_WRITE_SIZE_unit": write_unit,
                                "note": "guide: FETCH_SIZE is in KiB and reports half of a coalesced streaming read "
                                        "on gfx950 (x2048 B per unit expected); WRITE_SIZE is KiB, exact (x1024)"}}
-    for key, sub in (("strip_kernel", "k_svgp_fit_strip<"), ("small_strip_kernel", "k_svgp_fit_strip256<"),
-                     ("staged_kernel", "k_svgp_fit<")):
+    for key, sub in (("cluster_kernel", "k_svgp_fit_cluster"), ("strip_kernel", "k_svgp_fit_strip<"),
+                     ("small_strip_kernel", "k_svgp_fit_strip256<"), ("staged_kernel", "k_svgp_fit<"),
+                     ("generic_kernel", "k_svgp_fit_large"), ("pool_kernel", "k_pool("), ("stats_kernel", "k_stats("),
+                     ("broadcast_kernel", "k_broadcast(")):
         fm, fn = mean_of(pf, sub, "FETCH_SIZE")
         wm, wn = mean_of(pw, sub, "WRITE_SIZE")
         if fm is None or wm is None or not fetch_unit or not write_unit:
@@ -74,6 +79,14 @@ def main():
         traffic[key] = {"launches_profiled": fn, "FETCH_SIZE_mean": fm, "WRITE_SIZE_mean": wm,
                         "read_bytes_per_launch": fm * fetch_unit, "written_bytes_per_launch": wm * write_unit,
                         "hbm_bytes_per_launch": fm * fetch_unit + wm * write_unit}
+    fit_keys = [k for k in ("cluster_kernel", "strip_kernel", "small_strip_kernel", "staged_kernel", "generic_kernel")
+                if k in traffic]
+    if fit_keys:  # one gapro_svgp_fit_batch launch = its fit kernels side by side
+        traffic["fit_launch"] = {
+            "kernels": fit_keys,
+            "read_bytes_per_launch": sum(traffic[k]["read_bytes_per_launch"] for k in fit_keys),
+            "written_bytes_per_launch": sum(traffic[k]["written_bytes_per_launch"] for k in fit_keys),
+            "hbm_bytes_per_launch": sum(traffic[k]["hbm_bytes_per_launch"] for k in fit_keys)}
     with open(os.path.join(out, a.tag + "_pmc_traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
 
@@ -97,21 +110,29 @@ def main():
     for name, calls, avg, tot, pct in rows[:14]:
         md.append("| %s | %d | %.1f | %.2f | %.2f |" % (name, calls, avg, tot, pct))
     md += ["",
-           "bench.py (un-profiled run): %.1f scenes/s, %.1f ms per step of %d scenes; dominant kernel %s: avg launch "
-           "%.2f ms by HIP events on its stream, %.3g algorithmic FLOP per launch -> %.2f TFLOP/s = %.1f %% of the %.1f "
-           "TFLOP/s FP64 MFMA peak." % (bench["value"], bench["ms_per_step"], bench["config"]["scenes_per_step_per_gpu"],
-                                       rl["kernel"].split(" ")[0], rl["avg_launch_ms"], rl["flops_per_launch"],
-                                       rl["achieved"], 100 * rl["frac"], rl["peak"]),
-           "Whole fit launch (strip + staged kernel side by side): %.2f ms, %.2f TFLOP/s, %.0f fits/s."
-           % (fl.get("avg_ms_first_start_to_last_end", 0), fl.get("tflops", 0), fl.get("fits_per_s", 0)), ""]
-    if "strip_kernel" in traffic:
-        t = traffic["strip_kernel"]
+           "bench.py (un-profiled run): %.1f scenes/s, %.1f ms per step of %d scenes; fit launch (%s): first kernel "
+           "start -> last kernel end %.2f ms by HIP events on the kernels' streams, %.3g algorithmic FLOP per launch -> "
+           "%.2f TFLOP/s = %.1f %% of the %.1f TFLOP/s FP64 MFMA datasheet peak (%.1f %% of the %.1f TFLOP/s measured on "
+           "this box by tools/mfma_peak.py)."
+           % (bench["value"], bench["ms_per_step"], bench["config"]["scenes_per_step_per_gpu"],
+              ", ".join("%s %.0f ms" % (k, v["avg_ms"]) for k, v in fl.get("kernels", {}).items() if v["flops"] > 0),
+              rl["avg_launch_ms"], rl["flops_per_launch"], rl["achieved"], 100 * rl["frac"], rl["peak"],
+              100 * rl["achieved"] / max((bench.get("peak_measured") or {}).get("f64_16x16x4", rl["peak"]), 1e-9),
+              (bench.get("peak_measured") or {}).get("f64_16x16x4", float("nan"))), ""]
+    if "fit_launch" in traffic:
+        t = traffic["fit_launch"]
         ms = rl["avg_launch_ms"]
-        md += ["HBM traffic of the strip kernel (PMC, corrected by the calibration pass: %.0f B per FETCH_SIZE unit, "
-               "%.0f B per WRITE_SIZE unit): %.1f GB read + %.1f GB written per launch = %.2f TB/s over the %.1f ms "
-               "launch (HBM peak 8 TB/s, ~6.3 achievable); algorithmic FLOP / HBM byte = %.2f."
+        md += ["HBM-side traffic of one fit launch (PMC, separate FETCH_SIZE / WRITE_SIZE passes, corrected by the "
+               "calibration pass of the same run: %.0f B per FETCH_SIZE unit, %.0f B per WRITE_SIZE unit): %.1f GB read + "
+               "%.1f GB written = %.2f TB/s over the %.1f ms launch (HBM peak 8 TB/s, ~6.3 achievable); algorithmic "
+               "FLOP / HBM byte = %.2f.  Per kernel: %s."
                % (fetch_unit, write_unit, t["read_bytes_per_launch"] / 1e9, t["written_bytes_per_launch"] / 1e9,
-                  t["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e12, ms, rl["flops_per_launch"] / t["hbm_bytes_per_launch"]), ""]
+                  t["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e12, ms, rl["flops_per_launch"] / t["hbm_bytes_per_launch"],
+                  "; ".join("%s %.1f GB" % (k, traffic[k]["hbm_bytes_per_launch"] / 1e9) for k in t["kernels"])), ""]
+    if "pool_kernel" in traffic:
+        pts = bench["config"].get("points_per_step_per_gpu", 0)
+        md += ["Partition: k_pool moves %.2f GB per launch by the counters for %.2f GB algorithmic (68 B / point)."
+               % (traffic["pool_kernel"]["hbm_bytes_per_launch"] / 1e9, 68.0 * pts / 1e9), ""]
     with open(os.path.join(out, a.tag + "_summary.md"), "w") as fh:
         fh.write("\n".join(md))
     print("\n".join(md))

@@ -7,11 +7,12 @@ R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err; cat $O/bench.json
-timeout 300 python bench.py --no-cpu-baseline --stage-times --steps 5 > $O/bench_stages.json 2> $O/bench_stages.err; tail -2 $O/bench_stages.err
+LIGHT="--no-cpu-baseline --no-fixed-line --no-driver-line"
+timeout 300 python bench.py $LIGHT --stage-times --steps 4 > $O/bench_stages.json 2> $O/bench_stages.err; tail -2 $O/bench_stages.err
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/stats.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o bench --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o bench --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 $LIGHT > $O/stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o bench --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $LIGHT > $O/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o bench --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 $LIGHT > $O/pmc_write.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib_fetch -o calib --output-format csv -- python3 $R/tools/pmc_calib.py > $O/calib_fetch.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/calib_write -o calib --output-format csv -- python3 $R/tools/pmc_calib.py > $O/calib_write.log 2>&1
 cd $R
