@@ -212,7 +212,7 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int cw = cl_wave(), CW = cl_waves();
   constexpr int TS = 16 * TU;
-  constexpr int KS = 2, KB = 4 * KS;
+  constexpr int KS = TU >= 4 ? 1 : 2, KB = 4 * KS;  // 64 x 64 wave tiles: 128 accumulator registers, one k-step per block
   const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
 #pragma nounroll
   for (int t = cw; t < ntiles; t += CW) {
@@ -309,7 +309,7 @@ __device__ __noinline__ void gemm_tn_f32(int mo_tiles, int no_tiles, bool lower_
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int cw = cl_wave(), CW = cl_waves();
   constexpr int TS = 16 * TU;
-  constexpr int KS = 2, KB = 4 * KS;
+  constexpr int KS = TU >= 4 ? 1 : 2, KB = 4 * KS;  // 64 x 64 wave tiles: 128 accumulator registers, one k-step per block
   const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
 #pragma nounroll
   for (int t = cw; t < ntiles; t += CW) {
@@ -867,23 +867,24 @@ __device__ inline double col_final(int plane, int Mp, int c) {
 // A = LI KX (+ A^T), B^T = A^T LS (+ B) over the first `ncols` columns, then the column partials of mu and var.
 // MX: A = (L^-1 K_ZX in float64) rounded to float32 (gpytorch: interp_term ... .to(float32)); B in float32 on
 // v_mfma_f32 from the float32 A and L_S; the column sums read the float32 matrices and accumulate in float64.
-template <bool MX>
+template <bool MX, int TU>
 __device__ __noinline__ void forward_products(int ncols) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp;
-  const int mt = Mp / 32, nt = (ncols + 31) / 32;
+  constexpr int TS = 16 * TU;
+  const int mt = Mp / TS, nt = (ncols + TS - 1) / TS;
   const gd* vm = f.vec[V_M];
   if (MX) {
     gf* A = (gf*)f.mat[B_A];
     gf* AT = (gf*)f.mat[B_AT];
     gf* BM = (gf*)f.mat[B_BM];
     gf* BMT = (gf*)f.mat[B_BMT];
-    gemm_tn<2, false, gd, gf>(mt, nt, false, f.mat[B_U], (const gf*)f.mat[B_KX], Mp, nullptr,
-                              [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+    gemm_tn<TU, false, gd, gf>(mt, nt, false, f.mat[B_U], (const gf*)f.mat[B_KX], Mp, nullptr,
+                              [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                               [=](int i, int n, const d4& v) { store_tile<gf>(v, A, AT, Mp, i, n); });
     cbar();
     stamp(20);
-    gemm_tn_f32<2, false>(nt, mt, false, A, (const gf*)f.mat[B_LS], Mp, nullptr,
+    gemm_tn_f32<TU, false>(nt, mt, false, A, (const gf*)f.mat[B_LS], Mp, nullptr,
                           [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                           [=](int n, int j, const f4& v) { store_tile_f32(v, BMT, BM, Mp, n, j); });
     cbar();
@@ -898,12 +899,12 @@ __device__ __noinline__ void forward_products(int ncols) {
     gd* AT = f.mat[B_AT];
     gd* BM = f.mat[B_BM];
     gd* BMT = f.mat[B_BMT];
-    gemm_tn<2, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
-                      [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+    gemm_tn<TU, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+                      [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                       [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n); });
     cbar();
     stamp(20);
-    gemm_tn<2, false>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
+    gemm_tn<TU, false>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                       [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j); });
     cbar();
@@ -1000,14 +1001,15 @@ __device__ __noinline__ void kernel_grads(const gd* __restrict__ G, const gd* __
   ks[1] = k1;
 }
 
-template <bool MX>
+template <bool MX, int TU>
 __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_fit_desc& desc, float* __restrict__ o_probs,
                          float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
                          float* __restrict__ o_mu, float* __restrict__ o_var, double* loss_out) {
   const Fit& f = g_sh.f;
   Shared& sh = g_sh;
   const int M = f.M, Mp = f.Mp, D = f.D, T = f.T;
-  const int mt = Mp / 32;
+  constexpr int TS = 16 * TU;
+  const int mt = Mp / TS;
   const double Nd = (double)M;
   const double jitter = opt.jitter;
   gd* LS = f.mat[B_LS];
@@ -1088,7 +1090,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     build_kx<MX>(f.XtT, Mp, M, s, inv_l2);
     cbar();
     stamp(5);
-    forward_products<MX>(M);
+    forward_products<MX, TU>(M);
     stamp(6);
     // quadrature: 16 lanes per training point, lane q < 10 evaluates the symmetric node pair +-t_q of the 20-point
     // Gauss-Hermite rule (BernoulliLikelihood.expected_log_prob), the 16 lanes are summed by xor-shuffles
@@ -1164,8 +1166,8 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       const float step_f = (float)step_size, bc2s_f = (float)bc2s, Ndf = (float)Nd;
       col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * (double)ATf[(size_t)r * Mp + cc]; });
       // G_A = m g_mu^T + L_S (2 B g_v) - 2 A g_v on v_mfma_f32 (float32 operands, float32 epilogue)
-      gemm_tn_f32<2, false>(mt, mt, false, LSTf, BMf, Mp, nullptr,
-                            [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+      gemm_tn_f32<TU, false>(mt, mt, false, LSTf, BMf, Mp, nullptr,
+                            [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                             [=](int i0, int n0, const f4& v) {
                               const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                               const int n = n0 + lr;
@@ -1180,7 +1182,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       cbar();
       stamp(10);
       // G_LS (lower) + KL' with Adam on the float32 L_S in the epilogue
-      gemm_tn_f32<2, true>(mt, mt, true, ATf, BMTf, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+      gemm_tn_f32<TU, true>(mt, mt, true, ATf, BMTf, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                            [=](int i0, int j0, const f4& v) {
                              const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                              const int j = j0 + lr;
@@ -1205,14 +1207,14 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                              store_tile_f32(newv, (gf*)nullptr, LSTf, Mp, i0, j0);
                            });
       // G_KX = LI^T G_A in float64 (the float32 G_A enters through .double())
-      gemm_tn<2, false, gd, gf>(mt, mt, false, f.mat[B_LI], GAf, Mp, nullptr,
+      gemm_tn<TU, false, gd, gf>(mt, mt, false, f.mat[B_LI], GAf, Mp, nullptr,
                                 [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                                 [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
       cbar();
       stamp(11);
       // G_L = -tril(G_KX A^T) in float64 -> the whole B slot (the float32 B in its first half is dead)
       gd* GLm = BM;
-      gemm_tn<2, false, gd, gf>(mt, mt, true, GKXT, ATf, Mp, nullptr,
+      gemm_tn<TU, false, gd, gf>(mt, mt, true, GKXT, ATf, Mp, nullptr,
                                 [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                                 [=](int i0, int j0, const d4& v) {
                                   const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1226,8 +1228,8 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       stamp(12);
     } else {
     col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
-    gemm_tn<2, false>(mt, mt, false, LST, BM, Mp, nullptr,
-                      [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + 32; },
+    gemm_tn<TU, false>(mt, mt, false, LST, BM, Mp, nullptr,
+                      [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                       [=](int i0, int n0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                         const int n = n0 + lr;
@@ -1243,7 +1245,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     stamp(10);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] B[j][n] (lower) + KL', Adam on L_S in the epilogue (L_S^T through the
     // wave's transpose tile: 128-byte rows)
-    gemm_tn<2, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+    gemm_tn<TU, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                      [=](int i0, int j0, const d4& v) {
                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                        const int j = j0 + lr;
@@ -1268,14 +1270,14 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                        store_tile(newv, (gd*)nullptr, LST, Mp, i0, j0);  // LST[j][i]; zeros above the diagonal
                      });
     // G_KX = LI^T G_A
-    gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
+    gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                       [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
     cbar();
     stamp(11);
     // G_L = -tril(G_KX A^T) -> BM buffer
     gd* GLd = BM;
-    gemm_tn<2, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+    gemm_tn<TU, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                       [=](int i0, int j0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
 #pragma unroll
@@ -1290,7 +1292,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     gd* GL = BM;
     // Pm = Phi(tril(L^T G_L)) -> GA buffer
     gd* Pm = GA;
-    gemm_tn<2, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
+    gemm_tn<TU, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                       [=](int i0, int j0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1304,7 +1306,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     stamp(13);
     // T1 = LI^T Pm, stored transposed -> BMT buffer
     gd* T1T = BMT;
-    gemm_tn<2, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+    gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, (gd*)nullptr, T1T, Mp, i, j); });
     cbar();
@@ -1312,7 +1314,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer
     gd* G = BM;
     gd* GT = GKXT;
-    gemm_tn<2, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+    gemm_tn<TU, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j); });
     cbar();
@@ -1382,7 +1384,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     const int nc = (T - t0) < Mp ? (T - t0) : Mp;
     build_kx<MX>(f.Xt + t0, round_up(T > 0 ? T : 1, 32), nc, s, inv_l2);
     cbar();
-    forward_products<MX>(nc);
+    forward_products<MX, TU>(nc);
     for (int n = ct; n < nc; n += CT) {
       const double mu = col_final(0, Mp, n) + c;
       const double var = fmax(s + jitter + col_final(1, Mp, n), opt.min_variance);
@@ -1511,10 +1513,16 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     }
   }
   cbar();
-  if (opt.precision == GAPRO_PRECISION_MIXED)
-    fit_body<true>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
-  else
-    fit_body<false>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+  // wave tiles of the M^3 products: 32 x 32, or 64 x 64 where M_p allows it (twice the FLOP per operand byte; the
+  // products of many concurrent fits stream their operands from HBM) -- debug bit 5 of gapro_fit_options.reserved
+  const bool wide = (opt.reserved & 32) && Mp % 64 == 0;
+  if (opt.precision == GAPRO_PRECISION_MIXED) {
+    if (wide) fit_body<true, 4>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+    else fit_body<true, 2>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+  } else {
+    if (wide) fit_body<false, 4>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+    else fit_body<false, 2>(opt, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
+  }
   __syncthreads();
   if (sh.g == 0 && threadIdx.x == 0) {
     int st = sh.status;

@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--own-stream", action="store_true", help="launch from a non-default torch stream")
     ap.add_argument("--no-small", action="store_true", help="M_p <= 64 on the 512-thread strip kernel (A/B)")
     ap.add_argument("--no-cluster", action="store_true", help="large fits stay on one workgroup (A/B)")
+    ap.add_argument("--cluster-all", action="store_true", help="the cluster kernel for every fit it can take (A/B)")
+    ap.add_argument("--wide-tiles", action="store_true", help="64 x 64 wave tiles in the cluster kernel (A/B)")
     args = ap.parse_args()
     if args.profile:
         import os
@@ -121,6 +123,10 @@ def main():
         pipe.opt.reserved |= 4
     if args.no_cluster:
         pipe.opt.reserved |= 8
+    if args.cluster_all:
+        pipe.opt.reserved |= 16
+    if args.wide_tiles:
+        pipe.opt.reserved |= 32
     if args.mix:
         run_mix(pipe, args)
         return
