@@ -95,19 +95,6 @@ inline __host__ __device__ long long staged_lds_bytes(int m, int d) {
   const int Mp = gapro_pad_m(m);
   return 8LL * (2LL * d * Mp + scratch_doubles(Mp));
 }
-// Workgroup-tiled products (gemm_tn_wg): k-chunks of the two operands of a 128 x 128 output tile, double-buffered,
-// behind the per-wave transpose tiles of the scratch region.
-constexpr int kWgKC = 16;        // k rows per chunk
-constexpr int kWgStride = 144;   // LDS row stride of a chunk (doubles): 128 columns + 16, so that the four k rows a
-                                 // fragment read touches start 128 bytes apart modulo the 256-byte bank row
-constexpr int kWgDoubles = 4 * kWgKC * kWgStride;
-constexpr int kWgMinMp = 192;    // smallest padded M the tiled products are used for (M_p % 32 == 0)
-inline __host__ __device__ bool wg_capable(int Mp) { return Mp >= kWgMinMp && Mp % 32 == 0; }
-inline __host__ __device__ long long staged_lds_bytes_wg(int m, int d) {
-  const int Mp = gapro_pad_m(m);
-  const int sc = scratch_doubles(Mp), need = kTileDoubles + kWgDoubles;
-  return 8LL * (2LL * d * Mp + (sc > need ? sc : need));
-}
 inline __host__ __device__ bool staged_ok(int m, int d) {
   return gapro_pad_m(m) <= kMaxMpLds && d <= 32 && staged_lds_bytes(m, d) <= kMaxDynLds;
 }
@@ -135,7 +122,6 @@ struct Shared {
   double c, rho_s, rho_l, s, ell, inv_l2;
   int status;
   int chol_bad;  // a pivot of the factorisation in progress was not positive (see factorize: the jitter retries)
-  ldsd* wgbuf;   // LDS operand chunks of the workgroup-tiled products (gemm_tn_wg); null = per-wave products
 };
 __shared__ Shared g_sh;  // one fit per workgroup
 
@@ -222,148 +208,6 @@ __device__ inline void stage_points_t(ldsd* dst, const gd* src, int n, int D, in
   }
 }
 
-// ---- TN-form MFMA product, workgroup-tiled through LDS ------------------------------------------------
-// Same contract as gemm_tn below (TU = 2: 32 x 32 pieces, kr / epi per piece).  The staged kernel hosts 256 independent
-// fits whose matrices stream from HBM: with one 32 x 32 tile per wave fed straight from global memory every operand
-// fragment is fetched by every wave that needs it (4 FLOP per byte; the kernel ran AT the HBM rate: 2.4 TB per
-// launch, profiles/r02k).  Here the eight waves of the workgroup share one 128 x 128 output tile: a k-chunk of 16
-// rows of both operands is loaded ONCE (coalesced 1 KiB rows, two 16-byte loads per thread) into LDS, double-buffered,
-// and every wave takes its fragments from there: 16 FLOP per byte of global traffic.  Wave w owns rows 64 (w >> 2) ..
-// and columns 32 (w & 3) .. of the tile (two 32 x 32 pieces: 8 accumulator tiles); a piece skips the chunks outside
-// its own contraction range, so triangular operands cost MFMA time only where they are non-zero.
-template <bool SCALE, typename KRange, typename Epi>
-__device__ __noinline__ void gemm_tn_wg(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
-                                        const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
-                                        Epi epi, ldsd* buf) {
-  mo_tiles = uni(mo_tiles);
-  no_tiles = uni(no_tiles);
-  lower_only = uni((int)lower_only) != 0;
-  ld = uni(ld);
-  P = uni_ptr(P);
-  Q = uni_ptr(Q);
-  qscale = uni_ptr(qscale);
-  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-  const int rows = 32 * mo_tiles, cols = 32 * no_tiles;
-  const int nti = (rows + 127) / 128, ntj = (cols + 127) / 128;
-  const int wi = wave >> 2, wj = wave & 3;
-  // loader coordinates of this thread inside a chunk: k row t / 32, four columns from 4 (t % 32)
-  const int lrow = threadIdx.x >> 5, lcol = (threadIdx.x & 31) * 4;
-  ldsd* Pl = buf;
-  ldsd* Ql = buf + 2 * kWgKC * kWgStride;
-  for (int ti = 0; ti < nti; ++ti) {
-    for (int tj = 0; tj < ntj; ++tj) {
-      if (lower_only && tj > ti) continue;
-      const int I0 = 128 * ti, J0 = 128 * tj;
-      // contraction range of the workgroup tile = hull of its pieces' ranges (all threads compute the same)
-      int klo = 1 << 30, khi = 0;
-      for (int pi = 0; pi < 4; ++pi)
-        for (int pj = 0; pj < 4; ++pj) {
-          const int ip = I0 + 32 * pi, jp = J0 + 32 * pj;
-          if (ip < rows && jp < cols && (!lower_only || ip >= jp)) {
-            int lo, hi;
-            kr(ip, jp, &lo, &hi);
-            if (lo < hi) {
-              klo = lo < klo ? lo : klo;
-              khi = hi > khi ? hi : khi;
-            }
-          }
-        }
-      klo = uni(klo);
-      khi = uni(khi);
-      // this wave's two pieces
-      int plo[2], phi[2];
-      bool pon[2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const int ip = I0 + 64 * wi + 32 * p, jp = J0 + 32 * wj;
-        pon[p] = ip < rows && jp < cols && (!lower_only || ip >= jp);
-        plo[p] = phi[p] = 0;
-        if (pon[p]) kr(ip, jp, &plo[p], &phi[p]);
-        plo[p] = uni(plo[p]);
-        phi[p] = uni(phi[p]);
-      }
-      d4 acc[4][2];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 2; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
-      double rp[4], rq[4];
-      auto gload = [&](int k0) {
-        const int k = k0 + lrow;
-        const bool pin = I0 + lcol < ld, qin = J0 + lcol < ld;
-        const gd* pp = P + (size_t)k * ld + I0 + lcol;
-        const gd* qp = Q + (size_t)k * ld + J0 + lcol;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          rp[e] = pin ? pp[e] : 0.0;
-          rq[e] = qin ? qp[e] : 0.0;
-        }
-        if (SCALE) {
-          const double sc = qscale[k];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) rq[e] *= sc;
-        }
-      };
-      auto lstore = [&](int b) {
-        ldsd* pd = Pl + b * kWgKC * kWgStride + lrow * kWgStride + lcol;
-        ldsd* qd = Ql + b * kWgKC * kWgStride + lrow * kWgStride + lcol;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pd[e] = rp[e];
-          qd[e] = rq[e];
-        }
-      };
-      if (klo < khi) {
-        gload(klo);
-        lstore(0);
-        __syncthreads();
-        int b = 0;
-#pragma nounroll
-        for (int k0 = klo; k0 < khi; k0 += kWgKC, b ^= 1) {
-          const bool more = k0 + kWgKC < khi;
-          if (more) gload(k0 + kWgKC);
-          const bool on0 = pon[0] && k0 >= plo[0] && k0 < phi[0];
-          const bool on1 = pon[1] && k0 >= plo[1] && k0 < phi[1];
-          if (on0 || on1) {
-            const ldsd* pa = Pl + b * kWgKC * kWgStride + lq * kWgStride + 64 * wi + lr;
-            const ldsd* qa = Ql + b * kWgKC * kWgStride + lq * kWgStride + 32 * wj + lr;
-#pragma unroll
-            for (int st = 0; st < kWgKC / 4; ++st) {
-              const double b0 = qa[4 * st * kWgStride], b1 = qa[4 * st * kWgStride + 16];
-              if (on0) {
-                const double a0 = pa[4 * st * kWgStride], a1 = pa[4 * st * kWgStride + 16];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-              }
-              if (on1) {
-                const double a2 = pa[4 * st * kWgStride + 32], a3 = pa[4 * st * kWgStride + 48];
-                acc[2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[2][0], 0, 0, 0);
-                acc[2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[2][1], 0, 0, 0);
-                acc[3][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b0, acc[3][0], 0, 0, 0);
-                acc[3][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b1, acc[3][1], 0, 0, 0);
-              }
-            }
-          }
-          if (more) lstore(b ^ 1);
-          __syncthreads();
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        if (pon[p]) {
-          const int ip = I0 + 64 * wi + 32 * p, jp = J0 + 32 * wj;
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) epi(ip + 16 * u, jp + 16 * v, acc[2 * p + u][v]);
-        }
-      }
-    }
-  }
-}
-
 // ---- TN-form MFMA product ---------------------------------------------------------------------------
 //   C[i][j] = sum_{k in [klo,khi)} P[k][i] * Q[k][j] (* qscale[k] if SCALE),  ld = leading dimension
 // Each wave owns (16 TU) x (16 TU) output tiles, round-robin; `lower_only` enumerates tiles ti >= tj.
@@ -376,10 +220,6 @@ template <int TU, bool SCALE, int KS = 2, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
-  if (TU == 2 && NT == 512 && g_sh.wgbuf) {  // staged kernel, M_p >= 192: workgroup-tiled through LDS
-    gemm_tn_wg<SCALE>(mo_tiles, no_tiles, lower_only, P, Q, ld, qscale, kr, epi, g_sh.wgbuf);
-    return;
-  }
   mo_tiles = uni(mo_tiles);
   no_tiles = uni(no_tiles);
   lower_only = uni((int)lower_only) != 0;
@@ -1655,7 +1495,6 @@ __device__ inline void fit_setup(const gapro_fit_desc& desc, int D, const float*
     sh.rho_l = 0.0;
     sh.status = GAPRO_OK;
     sh.chol_bad = 0;
-    sh.wgbuf = nullptr;
 #ifdef GAPRO_PROFILE
     for (int i = 0; i < kProfSlots; ++i) sh.prof[i] = 0;
     sh.t_last = wall_clock64();
@@ -1718,11 +1557,6 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   ldsd* Pt = Zt + D * Mp;
   ldsd* scratch = Pt + D * Mp;
   fit_setup(desc, D, feats_spp, idx, init_mean, ws, Zt, Pt);
-  // internal bit 6 of opt.reserved: the launch's LDS holds the operand chunks of the workgroup-tiled products
-  if ((opt.reserved & 64) && wg_capable(Mp)) {
-    if (threadIdx.x == 0) g_sh.wgbuf = scratch + kTileDoubles;
-    __syncthreads();
-  }
   double* loss_slot = &o_loss[desc.slot];
   // the reference's two feature widths (xyz+rgb = 6, deep features = 32) get a compile-time D: the distance
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
@@ -2636,8 +2470,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   std::vector<gapro_fit_desc> strip, small, staged, large, clus;
   strip.reserve(n_fits);
   small.reserve(n_fits);
-  long long need = 0, max_lds = 0, max_lds_strip = 0, max_lds_small = 0, max_lds_wg = 0;
-  bool any_wg = false;
+  long long need = 0, max_lds = 0, max_lds_strip = 0, max_lds_small = 0;
   const int route_flags = opt->reserved;
   for (int i = 0; i < n_fits; ++i) {
     gapro_fit_desc d = h_descs[i];
@@ -2656,8 +2489,6 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     } else if (route == 1) {
       staged.push_back(d);
       max_lds = std::max(max_lds, staged_lds_bytes(m, feat_dim));
-      max_lds_wg = std::max(max_lds_wg, staged_lds_bytes_wg(m, feat_dim));
-      any_wg = any_wg || wg_capable(gapro_pad_m(m));
     } else if (route == 4) {
       clus.push_back(d);
     } else {
@@ -2750,19 +2581,13 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     gapro_launch_fit_large(s_staged, (int)large.size(), feat_dim, d_feats_spp, d_idx, d_descs, d_init_mean, *opt,
                            d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   if (!staged.empty()) {
-    // Workgroup-tiled products (M_p >= 192): the operand chunks need LDS that leaves room for one workgroup per CU
-    // only, and its 256-register instantiation; debug bit 7 of opt.reserved keeps the per-wave products.
-    const bool wg = any_wg && !(route_flags & 128) && max_lds_wg <= kMaxDynLds;
-    gapro_fit_options o2 = *opt;
-    if (wg) o2.reserved |= 64;
-    const long long lds = wg ? max_lds_wg : max_lds;
     // fewer fits than CUs: every fit has a CU to itself anyway, so take the whole register file
-    auto kern = (wg || (int)staged.size() <= ctx->n_cu) ? k_svgp_fit<2> : k_svgp_fit<kWavesPerSimd>;
-    if (lds > 48 * 1024)
+    auto kern = (int)staged.size() <= ctx->n_cu ? k_svgp_fit<2> : k_svgp_fit<kWavesPerSimd>;
+    if (max_lds > 48 * 1024)
       GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds));
-    hipLaunchKernelGGL(kern, dim3((int)staged.size()), dim3(NT), (size_t)lds, s_staged, (int)staged.size(),
-                       (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size(), d_init_mean, o2, d_workspace,
+                                               (int)max_lds));
+    hipLaunchKernelGGL(kern, dim3((int)staged.size()), dim3(NT), (size_t)max_lds, s_staged, (int)staged.size(),
+                       (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size(), d_init_mean, *opt, d_workspace,
                        d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   }
   if (tm && tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[1], s_staged));

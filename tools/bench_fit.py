@@ -107,7 +107,6 @@ def main():
     ap.add_argument("--no-cluster", action="store_true", help="large fits stay on one workgroup (A/B)")
     ap.add_argument("--cluster-all", action="store_true", help="the cluster kernel for every fit it can take (A/B)")
     ap.add_argument("--wide-tiles", action="store_true", help="64 x 64 wave tiles in the cluster kernel (A/B)")
-    ap.add_argument("--no-wg", action="store_true", help="per-wave products in the staged kernel (A/B)")
     args = ap.parse_args()
     if args.profile:
         import os
@@ -128,8 +127,6 @@ def main():
         pipe.opt.reserved |= 16
     if args.wide_tiles:
         pipe.opt.reserved |= 32
-    if args.no_wg:
-        pipe.opt.reserved |= 128
     if args.mix:
         run_mix(pipe, args)
         return
