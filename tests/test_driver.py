@@ -298,3 +298,29 @@ def test_cli_raw_cache_second_run_maps_the_cache_and_writes_the_same_files(tmp_p
             for u, v in zip(a, torch.load(os.path.join(other, s.scan_name + ".pth"), weights_only=False)):
                 assert u.dtype == v.dtype
                 np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path on hardware: `--gpus 2` with no launcher in the environment starts two ranks itself;
+    `--share-gpu` lets both use the test box's single GPU (control-plane collectives over gloo then; on a node every
+    rank has its own GPU and they run over RCCL).  One JSON line from rank 0, n_gpus = 2, a whole-job value that
+    counts both ranks' scenes, and the roofline / partition objects of the contract."""
+    import json
+    import subprocess
+    import sys
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2",
+                        "--warmup", "1", "--scenes-per-step", "8", "--distinct", "4", "--no-cpu-baseline",
+                        "--no-fixed-line", "--no-driver-line"], cwd=repo, capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 8 * 2 / (rec["ms_per_step"] * 2 * 1e-3)) < 1e-6 * rec["value"]
+    assert rec["roofline"]["bound"] == "mfma" and rec["roofline"]["achieved"] > 0 and rec["partition"]["GB/s"] > 0
+    assert "test mode" in rec["config"]["parallelism"]
