@@ -69,6 +69,7 @@ constexpr int kMaxPairs = 40;
 struct Shared {
   Fit f;
   int G, g;
+  int same_xcd;  // every member of the cluster reported the same XCC id: barriers skip the L2 write-back
   unsigned epoch, red_par;
   gu32* count;
   double redw[NW];
@@ -150,13 +151,20 @@ __device__ inline int cl_wave() { return uni(g_sh.g * NW + (int)(threadIdx.x >> 
 __device__ inline int cl_waves() { return uni(g_sh.G * NW); }
 
 // ---- cluster barrier (Guideline 16: agent-scope release / acquire around one monotonic counter) ------
+// The release (buffer_wbl2 sc1: this XCD's dirty L2 lines to memory) is what makes stores visible to a CU behind
+// ANOTHER XCD's L2.  When every member of the cluster has reported the same HW_REG_XCC_ID (checked once per launch
+// behind a full barrier, never assumed from the block ids), the members share one L2: a store is visible to them once
+// it has been acknowledged (vmcnt(0)), and the write-back -- the expensive half of the barrier, it grows with the dirty
+// bytes of the whole XCD -- is skipped.  The acquire (buffer_inv sc1: drop this CU's stale L1 lines) stays.
 __device__ __noinline__ void cbar() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
   __syncthreads();
   if (g_sh.G > 1) {
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2 sc1: this XCD's dirty lines reach memory
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the arrive must not overtake the write-back
+      if (!g_sh.same_xcd) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the arrive must not overtake the write-back
+      }
       const unsigned target = (unsigned)g_sh.G * (++g_sh.epoch);
       __hip_atomic_fetch_add(g_sh.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       while (__hip_atomic_load(g_sh.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
@@ -166,6 +174,20 @@ __device__ __noinline__ void cbar() {
     }
     __syncthreads();
   }
+}
+
+// Once per launch, behind the first (full) barrier: do all members of the cluster sit on one XCD?
+__device__ inline void detect_same_xcd() {
+  if (g_sh.G == 1) return;
+  unsigned xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) __hip_atomic_fetch_or(g_sh.count + 1, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  cbar();  // full form: same_xcd is still 0
+  if (threadIdx.x == 0) {
+    const unsigned mask = __hip_atomic_load(g_sh.count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    g_sh.same_xcd = (mask != 0 && (mask & (mask - 1)) == 0) ? 1 : 0;
+  }
+  __syncthreads();
 }
 
 // Ordered cluster sum of K per-thread partials; the result is the same on every thread of every workgroup.
@@ -1472,6 +1494,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     sh.g = cb.g;
     sh.epoch = 0;
     sh.red_par = 0;
+    sh.same_xcd = 0;
     sh.count = (gu32*)(ctl + (size_t)cb.ctl * 32);
     sh.c = sh.rho_s = sh.rho_l = 0.0;
     sh.mc = sh.vc = sh.mrs = sh.vrs = sh.mrl = sh.vrl = 0.0;
@@ -1488,6 +1511,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
   // zero everything the kernel reads before writing (parameters / Adam state, padded operand tails)
   for (long long i = ct; i < lay.total; i += CT) base[i] = 0.0;
   cbar();
+  if (!(opt.reserved & 256)) detect_same_xcd();  // debug bit 8: always the full barrier
   const int* my_idx = idx + desc.idx_offset;
   for (int e = ct; e < M * D; e += CT) {
     const int i = e / D, d = e - i * D;
