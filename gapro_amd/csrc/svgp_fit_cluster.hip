@@ -69,6 +69,7 @@ constexpr int kMaxPairs = 40;
 struct Shared {
   Fit f;
   int G, g;
+  int wave_off;
   int same_xcd;  // every member of the cluster reported the same XCC id: barriers skip the L2 write-back
   unsigned epoch, red_par;
   gu32* count;
@@ -147,8 +148,9 @@ __device__ inline double block_sum(double v) {
 // cluster-wide thread / wave coordinates
 __device__ inline int cl_tid() { return g_sh.g * NT + (int)threadIdx.x; }
 __device__ inline int cl_threads() { return g_sh.G * NT; }
-__device__ inline int cl_wave() { return uni(g_sh.g * NW + (int)(threadIdx.x >> 6)); }
-__device__ inline int cl_waves() { return uni(g_sh.G * NW); }
+// wave_off: waves (of the leader) left out of the current product (look-ahead Cholesky); 0 otherwise
+__device__ inline int cl_wave() { return uni(g_sh.g * NW + (int)(threadIdx.x >> 6) - g_sh.wave_off); }
+__device__ inline int cl_waves() { return uni(g_sh.G * NW - g_sh.wave_off); }
 
 // ---- cluster barrier (Guideline 16: agent-scope release / acquire around one monotonic counter) ------
 // The release (buffer_wbl2 sc1: this XCD's dirty L2 lines to memory) is what makes stores visible to a CU behind
@@ -678,13 +680,19 @@ __device__ __noinline__ void cholesky_cluster() {
   gd* LT = f.mat[B_LT];
   const gd* U = f.mat[B_U];
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  // One-panel look-ahead: the leader-only diagonal block of panel p + 1 (~36 us, 7 .. 15 % of a step when everybody
+  // waits for it) runs BESIDE the bulk of panel p's trailing update.  Per panel:
+  //   (b)  panel solve p                                                 | barrier
+  //   (c1) trailing update of the next panel's 64 columns, all members   | barrier
+  //   (a') leader: diagonal block p + 1   ||   others: (c2) the rest of the trailing update   | barrier
+  // Same three barriers per panel, same MFMAs in the same order per tile (bit-identical factor).
+  if (g_sh.g == 0) chol_diag_block(0, Mp < NB ? Mp : NB);
+  cbar();
+  stamp(1);
   for (int c0 = 0; c0 < Mp; c0 += NB) {
     const int w = (Mp - c0) < NB ? (Mp - c0) : NB, c1 = c0 + w;
-    // (a) leader: diagonal block
-    if (g_sh.g == 0) chol_diag_block(c0, w);
-    cbar();
-    stamp(1);
     if (c1 >= Mp) break;
+    const int w1 = (Mp - c1) < NB ? (Mp - c1) : NB, c2 = c1 + w1;  // the next panel
     // (b) panel below: L[i][c0 + c] = sum_q S[i][c0 + q] W[c][q],  W^T = U (rows q, contiguous in c)
     {
       const int cw = cl_wave(), CW = cl_waves();
@@ -715,23 +723,44 @@ __device__ __noinline__ void cholesky_cluster() {
         L[(size_t)i * Mp + c] = LT[(size_t)c * Mp + i];
       }
     }
-    // (c) trailing update S[i][j] -= sum_{q in panel} L[i][q] L[j][q], lower 32 x 32 tiles (reads L^T only)
-    {
-      const gd* P = LT + c1;
-      gd* S = L + (size_t)c1 * Mp + c1;
-      const int mt = (Mp - c1) / 32;
-      gemm_tn<2, false>(mt, mt, true, P, P, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = c0; *hi = c1; },
-                        [=](int i, int j, const d4& v) {
-                          const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
+    // trailing update S[i][j] -= sum_{q in panel} L[i][q] L[j][q] (reads L^T only), 32 x 32 tiles
+    auto upd = [=](int i, int j, const d4& v, gd* S) {
+      const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
 #pragma unroll
-                          for (int r = 0; r < 4; ++r) {
-                            gd* p = S + (size_t)(i + g4 + 4 * r) * Mp + j + c;
-                            *p = *p - v[r];
-                          }
-                        });
+      for (int r = 0; r < 4; ++r) {
+        gd* p = S + (size_t)(i + g4 + 4 * r) * Mp + j + c;
+        *p = *p - v[r];
+      }
+    };
+    // (c1) the next panel's block column: rows >= c1, columns [c1, c2)
+    {
+      gd* S = L + (size_t)c1 * Mp + c1;
+      gemm_tn<2, false>((Mp - c1) / 32, w1 / 32, false, LT + c1, LT + c1, Mp, nullptr,
+                        [=](int, int, int* lo, int* hi) { *lo = c0; *hi = c1; },
+                        [=](int i, int j, const d4& v) { upd(i, j, v, S); });
     }
     cbar();
     stamp(3);
+    // (a') | (c2): the leader factors the next diagonal block while the other members update columns >= c2
+    const bool alone = g_sh.G == 1;
+    if (!alone) {  // the leader's waves take no tiles of the product below (set and cleared between barriers)
+      if (threadIdx.x == 0) g_sh.wave_off = NW;
+      __syncthreads();
+    }
+    if (g_sh.g == 0) chol_diag_block(c1, w1);
+    if (c2 < Mp && (alone || g_sh.g != 0)) {
+      gd* S = L + (size_t)c2 * Mp + c2;
+      const int mt = (Mp - c2) / 32;
+      gemm_tn<2, false>(mt, mt, true, LT + c2, LT + c2, Mp, nullptr,
+                        [=](int, int, int* lo, int* hi) { *lo = c0; *hi = c1; },
+                        [=](int i, int j, const d4& v) { upd(i, j, v, S); });
+    }
+    cbar();
+    if (!alone) {
+      if (threadIdx.x == 0) g_sh.wave_off = 0;
+      __syncthreads();
+    }
+    stamp(1);
   }
 }
 
@@ -1495,6 +1524,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     sh.epoch = 0;
     sh.red_par = 0;
     sh.same_xcd = 0;
+    sh.wave_off = 0;
     sh.count = (gu32*)(ctl + (size_t)cb.ctl * 32);
     sh.c = sh.rho_s = sh.rho_l = 0.0;
     sh.mc = sh.vc = sh.mrs = sh.vrs = sh.mrl = sh.vrl = 0.0;
