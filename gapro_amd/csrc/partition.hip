@@ -5,6 +5,8 @@
 // :347-363 (is_within_bb_torch + three torch_scatter means + threshold) and :478-480.
 // All of it is HBM-bound streaming work: one coalesced pass over the point arrays, box corners in
 // LDS, integer atomics for the per-superpoint tallies (bit-reproducible, order-independent).
+#include <stdlib.h>
+
 #include "common.h"
 
 #include <algorithm>
@@ -358,6 +360,146 @@ __global__ __launch_bounds__(kThreads) void k_pool(const gapro_scene_task* __res
 }
 
 // ---- K5: per-superpoint finalisation -----------------------------------------------------------
+// ---- K4 (round 2): the same pass with the tallies privatised in LDS ------------------------------------------
+// k_pool issues ~9 global atomics per point (count, D feature sums, one per containing box) and runs at the L2's
+// atomic rate (48 G/s: 8.4 ms for 256 scenes, 3.5 % of the HBM roof; the counters see 2.8x the algorithmic bytes).
+// Vertex order is spatially coherent, so a run of a few thousand consecutive points touches only a few dozen
+// superpoints: each workgroup takes one such run (kPoolRun points), keeps an open-addressing table
+// superpoint rank -> {count, D 64-bit feature sums, n_boxes occupancy counts} in LDS, adds into it with LDS atomics,
+// and flushes its non-zero entries with one global atomic each at the end (~30x fewer global atomics).  A point whose
+// superpoint finds no slot within kProbe probes falls back to the global atomics.  Integer sums: the result is
+// bit-identical to k_pool's whatever the order.
+constexpr int kPoolRun = 1024;   // points per workgroup
+constexpr int kProbe = 8;
+
+__global__ __launch_bounds__(kThreads) void k_pool_lds(const gapro_scene_task* __restrict__ tasks, int d, int log2_slots,
+                                                       int nb_cap) {
+  const gapro_scene_task& t = tasks[blockIdx.y];
+  const long long n = t.n_points;
+  const long long p0 = (long long)blockIdx.x * kPoolRun;
+  if (p0 >= n) return;
+  const long long p1 = p0 + kPoolRun < n ? p0 + kPoolRun : n;
+  const int nb = t.n_boxes, shift = t.fixed_shift;
+  const double* __restrict__ coords = t.coords;
+  const float* __restrict__ feats = t.feats;
+  const int* __restrict__ spp_inv = t.spp_inv;
+  const double* __restrict__ boxes = t.boxes;
+  unsigned long long* __restrict__ feat_sum = (unsigned long long*)t.feat_sum;
+  int* __restrict__ occ_count = t.occ_count;
+  int* __restrict__ point_count = t.point_count;
+  extern __shared__ double sh_raw[];
+  // layout: box corners [nb_cap][6] f64 | fsum [T][d] u64 | keys [T] i32 | cnt [T] u32 | occ [T][nb] u32
+  const int T = 1 << log2_slots;
+  double* sh_box = sh_raw;
+  unsigned long long* fsum = (unsigned long long*)(sh_box + 6 * nb_cap);
+  int* keys = (int*)(fsum + (size_t)T * d);
+  unsigned* cnt = (unsigned*)(keys + T);
+  unsigned* occ = cnt + T;
+  for (int j = threadIdx.x; j < nb * 6; j += kThreads) {
+    const int c = j % 6;
+    sh_box[j] = c < 3 ? boxes[j] - 0.005 : boxes[j] + 0.005;
+  }
+  for (int j = threadIdx.x; j < T * d; j += kThreads) fsum[j] = 0ull;
+  for (int j = threadIdx.x; j < T; j += kThreads) {
+    keys[j] = -1;
+    cnt[j] = 0u;
+  }
+  for (int j = threadIdx.x; j < T * nb; j += kThreads) occ[j] = 0u;
+  __syncthreads();
+  const int k = threadIdx.x & (kLanesPerPoint - 1);
+  const int ppb = kThreads / kLanesPerPoint;
+  for (long long i = p0 + (threadIdx.x / kLanesPerPoint); i < p1; i += ppb) {
+    const double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    const int r = spp_inv[i];
+    // slot of superpoint r: the eight lanes of the point probe together (the compare-and-swap is idempotent)
+    int slot = -1;
+    unsigned h = ((unsigned)r * 2654435761u) >> (32 - log2_slots);
+    for (int pr = 0; pr < kProbe; ++pr) {
+      const int cur = keys[h];
+      if (cur == r) { slot = (int)h; break; }
+      if (cur == -1) {
+        const int old = atomicCAS(&keys[h], -1, r);
+        if (old == -1 || old == r) { slot = (int)h; break; }
+      }
+      h = (h + 1) & (unsigned)(T - 1);
+    }
+    const float* f = feats + i * d;
+    // the wave's eight points usually belong to ONE superpoint (runs of 50 .. 400 points): then their contributions
+    // are summed across the eight point groups by shuffles and lanes 0 .. 7 issue one LDS atomic per feature / box
+    // instead of eight to the same address
+    const long long i_first = __shfl(i, 0, 64);
+    const bool full_wave = i_first + 64 / kLanesPerPoint - 1 < p1;
+    const bool one_spp = full_wave && __all(r == __shfl(r, 0, 64) && slot >= 0);
+    if (one_spp) {
+      const bool head = (threadIdx.x & 63) < kLanesPerPoint;
+      if (head && k == (d & (kLanesPerPoint - 1))) atomicAdd(&cnt[slot], (unsigned)(64 / kLanesPerPoint));
+      for (int c0 = 0; c0 < d; c0 += kLanesPerPoint) {
+        const int c = c0 + k;
+        long long q = c < d ? __double2ll_rn(ldexp((double)f[c], shift)) : 0ll;
+        q += __shfl_down(q, 8, 64);
+        q += __shfl_down(q, 16, 64);
+        q += __shfl_down(q, 32, 64);
+        if (head && c < d) atomicAdd(&fsum[(size_t)slot * d + c], (unsigned long long)q);
+      }
+      unsigned* occ_row = occ + (size_t)slot * nb;
+      for (int b0 = 0; b0 < nb; b0 += kLanesPerPoint) {
+        const int b = b0 + k;
+        int in = 0;
+        if (b < nb) {
+          const double* bx = sh_box + 6 * b;
+          in = (x >= bx[0]) & (y >= bx[1]) & (z >= bx[2]) & (x <= bx[3]) & (y <= bx[4]) & (z <= bx[5]);
+        }
+        in += __shfl_down(in, 8, 64);
+        in += __shfl_down(in, 16, 64);
+        in += __shfl_down(in, 32, 64);
+        if (head && in) atomicAdd(&occ_row[b], (unsigned)in);
+      }
+    } else if (slot >= 0) {
+      if (k == (d & (kLanesPerPoint - 1))) atomicAdd(&cnt[slot], 1u);
+      for (int c = k; c < d; c += kLanesPerPoint) {
+        const long long q = __double2ll_rn(ldexp((double)f[c], shift));
+        atomicAdd(&fsum[(size_t)slot * d + c], (unsigned long long)q);
+      }
+      unsigned* occ_row = occ + (size_t)slot * nb;
+      for (int b = k; b < nb; b += kLanesPerPoint) {
+        const double* bx = sh_box + 6 * b;
+        const bool in = (x >= bx[0]) & (y >= bx[1]) & (z >= bx[2]) & (x <= bx[3]) & (y <= bx[4]) & (z <= bx[5]);
+        if (in) atomicAdd(&occ_row[b], 1u);
+      }
+    } else {  // table full around this hash: straight to global memory, as k_pool does
+      if (k == (d & (kLanesPerPoint - 1))) atomicAdd(&point_count[r], 1);
+      for (int c = k; c < d; c += kLanesPerPoint) {
+        const long long q = __double2ll_rn(ldexp((double)f[c], shift));
+        atomicAdd(&feat_sum[(long long)r * d + c], (unsigned long long)q);
+      }
+      int* occ_row = occ_count + (long long)r * nb;
+      for (int b = k; b < nb; b += kLanesPerPoint) {
+        const double* bx = sh_box + 6 * b;
+        const bool in = (x >= bx[0]) & (y >= bx[1]) & (z >= bx[2]) & (x <= bx[3]) & (y <= bx[4]) & (z <= bx[5]);
+        if (in) atomicAdd(&occ_row[b], 1);
+      }
+    }
+  }
+  __syncthreads();
+  // flush the non-zero entries
+  for (int j = threadIdx.x; j < T; j += kThreads) {
+    const int r = keys[j];
+    if (r >= 0 && cnt[j]) atomicAdd(&point_count[r], (int)cnt[j]);
+  }
+  for (int j = threadIdx.x; j < T * d; j += kThreads) {
+    const int sl = j / d, c = j - sl * d;
+    const int r = keys[sl];
+    const unsigned long long v = fsum[j];
+    if (r >= 0 && v) atomicAdd(&feat_sum[(long long)r * d + c], v);
+  }
+  for (int j = threadIdx.x; j < T * nb; j += kThreads) {
+    const int sl = j / nb, b = j - sl * nb;
+    const int r = keys[sl];
+    const unsigned v = occ[j];
+    if (r >= 0 && v) atomicAdd(&occ_count[(long long)r * nb + b], (int)v);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_pool_finalize(const gapro_scene_task* __restrict__ tasks, int d) {
   const gapro_scene_task& t = tasks[blockIdx.y];
   const int n_spps = t.n_spps, nb = t.n_boxes, shift = t.fixed_shift;
@@ -500,10 +642,26 @@ int gapro_partition_pool_batch(gapro_ctx* ctx, void* stream_, int32_t n_scenes, 
                                       hipMemcpyHostToDevice, stream));
   const unsigned ny = (unsigned)n_scenes;
   hipLaunchKernelGGL(k_pool_clear, dim3(grid_for(clear_max, 256), ny), dim3(kThreads), 0, stream, d_tasks, (int)feat_dim);
-  // the whole batch shares the GPU: cap the per-scene grid so that the batch is a few waves of workgroups
-  const int cap = n_scenes >= 8 ? 512 : 4096;
-  hipLaunchKernelGGL(k_pool, dim3(grid_for(n_max * kLanesPerPoint, cap), ny), dim3(kThreads), lds, stream, d_tasks,
-                     (int)feat_dim);
+  // LDS-privatised tallies (k_pool_lds): a table of 16 .. 64 slots beside the box corners; GAPRO_POOL_GLOBAL_ATOMICS=1 keeps round 1's kernel (A/B runs, tests)
+  static const bool global_only = getenv("GAPRO_POOL_GLOBAL_ATOMICS") != nullptr;
+  const int slot_bytes = 8 + 4 * nb_max + 8 * (int)feat_dim;
+  // 64 slots hold the ~10 .. 40 superpoints of a run several times over; a small table keeps 5+ workgroups per CU
+  int log2_slots = 6;
+  while (log2_slots > 4 && lds + ((size_t)slot_bytes << log2_slots) > 60 * 1024) --log2_slots;
+  const size_t lds2 = lds + ((size_t)slot_bytes << log2_slots);
+  if (!global_only && lds2 <= 60 * 1024) {
+    if (lds2 > 48 * 1024)
+      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_pool_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds2));
+    const unsigned gx = (unsigned)((n_max + kPoolRun - 1) / kPoolRun);
+    hipLaunchKernelGGL(k_pool_lds, dim3(gx, ny), dim3(kThreads), lds2, stream, d_tasks, (int)feat_dim, log2_slots,
+                       nb_max);
+  } else {
+    // the whole batch shares the GPU: cap the per-scene grid so that the batch is a few waves of workgroups
+    const int cap = n_scenes >= 8 ? 512 : 4096;
+    hipLaunchKernelGGL(k_pool, dim3(grid_for(n_max * kLanesPerPoint, cap), ny), dim3(kThreads), lds, stream, d_tasks,
+                       (int)feat_dim);
+  }
   hipLaunchKernelGGL(k_pool_finalize, dim3((s_max + kThreads - 1) / kThreads, ny), dim3(kThreads), 0, stream, d_tasks,
                      (int)feat_dim);
   GAPRO_LAUNCH_CHECK(ctx);
