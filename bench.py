@@ -417,6 +417,8 @@ def summarize(args, res, B, world, steps, workload, peak):
                   "pair would count as kernel time)"}
     m = res["last_fit_m"]
     if m is not None and len(m):
+        if os.environ.get("GAPRO_DUMP_FIT_M"):  # the M of every fit of the last launch, for tools/bench_fit.py --mix
+            np.save(os.environ["GAPRO_DUMP_FIT_M"], np.sort(m))
         edges = [0, 32, 64, 96, 128, 192, 256, 384, 512, 1 << 30]
         hist = np.histogram(m, bins=edges)[0]
         w = np.histogram(m, bins=edges, weights=m.astype(np.float64) ** 3)[0]

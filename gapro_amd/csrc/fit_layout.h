@@ -24,15 +24,21 @@ constexpr int kClusterMinMp = 64;                // smallest padded M the cluste
 constexpr int kClusterDefaultMinMp = 416;        // default routing threshold (gapro_cluster_min_mp)
 // workgroups a fit of padded size Mp is spread over: the work grows with Mp^3 while a launch's other fits finish in
 // a fraction of a second, so the largest fits get the most CUs (powers of two; one CU up to Mp = 384)
-inline __host__ __device__ int cluster_g(int Mp) {
-  const double work = (double)Mp * Mp * Mp / (384.0 * 384.0 * 384.0);
+inline int cluster_g(int Mp, double unit = 384.0, bool pow2 = true) {
+  const double work = (double)Mp * Mp * Mp / (unit * unit * unit);
   int g = 1;
-  while (g < kClMaxG && (double)g < work) g *= 2;
+  if (pow2) {
+    while (g < kClMaxG && (double)g < work) g *= 2;
+  } else {
+    while (g < kClMaxG && (double)g < work) ++g;
+  }
   return g;
 }
 inline __host__ __device__ bool cluster_capable(int Mp) { return Mp >= kClusterMinMp && Mp % 32 == 0; }
+// a plane of the ordered two-stage column sums: sized for the largest cluster, so that the layout does not depend on
+// the cluster size policy
 inline __host__ __device__ long long cluster_plane_doubles(int Mp) {
-  const long long t = (long long)cluster_g(Mp) * kClThreads;
+  const long long t = (long long)kClMaxG * kClThreads;
   return Mp > t ? Mp : t;
 }
 inline __host__ __device__ long long cluster_part_doubles(int Mp) {

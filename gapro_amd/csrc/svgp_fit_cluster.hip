@@ -26,6 +26,7 @@
 // as CUs are free; the other fit kernels' workgroups never wait on anything.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -1604,7 +1605,17 @@ int gapro_cluster_min_mp() {
 // the kernel can take (debug bit 4 of gapro_fit_options.reserved: precision sweeps through one kernel).
 int gapro_cluster_size(int Mp, bool all) {
   if (!cluster_capable(Mp) || (!all && Mp < gapro_cluster_min_mp())) return 0;
-  return cluster_g(Mp);
+  // a pure function of Mp (never of the batch: the summation order inside a fit depends on G); the two environment
+  // variables are tuning knobs for tools/bench_fit.py
+  static double unit = 0.0;
+  static int pow2 = 1;
+  if (unit == 0.0) {
+    const char* e = getenv("GAPRO_CLUSTER_UNIT");
+    const char* r = getenv("GAPRO_CLUSTER_ROUND");
+    if (r) pow2 = strcmp(r, "ceil") != 0;
+    unit = e && atof(e) >= 64.0 ? atof(e) : 384.0;
+  }
+  return cluster_g(Mp, unit, pow2 != 0);
 }
 
 // Internal launcher used by gapro_svgp_fit_batch (svgp_fit.hip).  `fits` = the n cluster fits' indices into the device
