@@ -57,6 +57,9 @@ constexpr int kRedSlots = 8;            // values reduced across row groups per 
 #define GAPRO_WAVES_PER_SIMD 4           // 2 workgroups of 8 waves per CU -> 128 VGPRs per lane
 #endif
 constexpr int kWavesPerSimd = GAPRO_WAVES_PER_SIMD;
+#ifndef GAPRO_GEMM_RING
+#define GAPRO_GEMM_RING 2
+#endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 // LDS pointers carry their address space explicitly: ds_read/ds_write instead of flat accesses, and no
@@ -115,6 +118,7 @@ struct Shared {
 #ifdef GAPRO_PROFILE
   unsigned long long prof[kProfSlots];
   unsigned long long t_last;
+  unsigned long long t_start;
 #endif
   double red[NW];
   double dblk[16 * 17];
@@ -216,7 +220,15 @@ __device__ inline void stage_points_t(ldsd* dst, const gd* src, int n, int D, in
 // 8-deep block are loaded before the MFMAs of the current one are issued.
 // MFMA f64 16x16x4 lane maps (cdna_hip_programming.md section 3): A[i = l & 15][k = l >> 4],
 // B[k = l >> 4][j = l & 15], C/D register r -> row (l >> 4) + 4 r, col l & 15.
-template <int TU, bool SCALE, int KS = 2, typename KRange, typename Epi>
+// ORD: the order in which the tiles are enumerated, heaviest contraction range first for the product's kr (a wave
+// takes the tiles of that order in serpentine rounds: 0..7, 7..0, ...; with triangular operands a round-robin deal in
+// row-major order leaves the slowest wave up to 1.8x the mean work, e.g. the same tile column for every tile of a wave
+// when a row has 8 tiles).  Which wave computes a tile does not change the tile: results are bit-identical.
+enum { ORD_ROWMAJOR = 0,   // equal ranges, or ranges shrinking with the tile row
+       ORD_ROWS_DESC = 1,  // ranges growing with the tile row: last row first
+       ORD_COLMAJOR = 2,   // ranges shrinking with the tile column
+       ORD_SHELLS = 3 };   // ranges shrinking with max(row, column) (square tile grids): shells m = 0, 1, ...
+template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
@@ -231,13 +243,29 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
   const int lr = lane & 15, lq = lane >> 4;
   constexpr int TS = 16 * TU;
   const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
+  const int rounds = (ntiles + NW - 1) / NW;
 #pragma nounroll
-  for (int t = wave; t < ntiles; t += NW) {
+  for (int q = 0; q < rounds; ++q) {
+    const int t = q * NW + ((q & 1) ? NW - 1 - wave : wave);
+    if (t >= ntiles) continue;
     int ti, tj;
     if (lower_only) {
       ti = 0;
       while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
       tj = t - ti * (ti + 1) / 2;
+    } else if (ORD == ORD_ROWS_DESC) {
+      ti = t / no_tiles;
+      tj = t - ti * no_tiles;
+      ti = mo_tiles - 1 - ti;
+    } else if (ORD == ORD_COLMAJOR) {
+      tj = t / mo_tiles;
+      ti = t - tj * mo_tiles;
+    } else if (ORD == ORD_SHELLS) {
+      int m = 0;
+      while ((m + 1) * (m + 1) <= t) ++m;
+      const int r = t - m * m;
+      ti = r <= m ? m : r - m - 1;
+      tj = r <= m ? r : m;
     } else {
       ti = t / no_tiles;
       tj = t - ti * no_tiles;
@@ -290,6 +318,33 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
             acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], bs[v], acc[u][v], 0, 0, 0);
       }
     };
+#if GAPRO_GEMM_RING > 2
+    // experiment: a ring of GAPRO_GEMM_RING register blocks, RING - 1 of them in flight.  Every load is
+    // unconditional (the block index is clamped to the last one, so the tail re-requests lines it already has) and
+    // the loop only has exit branches: the waits stay counted.
+    if (KS == 2 && klo < khi) {
+      constexpr int NB = GAPRO_GEMM_RING;
+      double ra[NB][KS][TU], rb[NB][KS][TU], rs[NB][KS];
+      const int nblk = (khi - klo) / KB;
+#pragma unroll
+      for (int i = 0; i < NB - 1; ++i) load_block(klo + (i < nblk ? i : nblk - 1) * KB, ra[i], rb[i], rs[i]);
+      int j = 0;
+#pragma nounroll
+      while (true) {
+        bool done = false;
+#pragma unroll
+        for (int sidx = 0; sidx < NB; ++sidx) {
+          if (!done) {
+            const int jn = j + NB - 1 < nblk ? j + NB - 1 : nblk - 1;
+            load_block(klo + jn * KB, ra[(sidx + NB - 1) % NB], rb[(sidx + NB - 1) % NB], rs[(sidx + NB - 1) % NB]);
+            mma_block(ra[sidx], rb[sidx], rs[sidx]);
+            if (++j == nblk) done = true;
+          }
+        }
+        if (done) break;
+      }
+    } else
+#endif
     if (klo < khi) {  // khi - klo is a multiple of 16 (tile-aligned ranges), hence of KB
       load_block(klo, a0, b0, s0);
       int k = klo;
@@ -1184,7 +1239,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   auto forward_products = [&](int ncols, double s_, double jitter_) {
     const int nt = (ncols + TS - 1) / TS;
     // A[i][n] = sum_k U[k][i] KX[k][n],  U[k][i] = LI[i][k] = 0 for k > i
-    gemm_tn<TU, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+    gemm_tn<TU, false, 2, ORD_ROWS_DESC>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                        [=](int i, int n, const d4& v) {
                          store_tile(v, A, AT, Mp, i, n, tile);
@@ -1208,7 +1263,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                        });
     __syncthreads();
     // BMT[n][j] = sum_i A[i][n] LS[i][j],  LS[i][j] = 0 for i < j
-    gemm_tn<TU, false>(nt, mt, false, A, LS, Mp, nullptr,
+    gemm_tn<TU, false, 2, ORD_COLMAJOR>(nt, mt, false, A, LS, Mp, nullptr,
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                        [=](int n, int j, const d4& v) {
                          store_tile(v, BMT, BM, Mp, n, j, tile);
@@ -1279,7 +1334,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     // G_m = A g_mu (+ m / N, added with the Adam update below): fused into the G_A epilogue, or through AT
     if (!fuse) weighted_colsum(AT, gmu, Mp, f.vec[V_GM], scratch);
     // G_A[i][n] = 2 g_v[n] sum_j LS[i][j] BM[j][n] + m[i] g_mu[n] - 2 A[i][n] g_v[n]
-    gemm_tn<TU, false>(mt, mt, false, LST, BM, Mp, nullptr,
+    gemm_tn<TU, false, 2, ORD_ROWS_DESC>(mt, mt, false, LST, BM, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                        [=](int i0, int n0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -1372,7 +1427,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     stamp(11);
     // T1 = LI^T Pm, stored transposed -> BMT buffer   (k >= max(i0, j0))
     gd* T1T = BMT;
-    gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+    gemm_tn<TU, false, 2, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                        [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                        [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
     __syncthreads();
@@ -1380,7 +1435,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the A buffer   (k >= j0)
     gd* G = BM;
     gd* GT = A;
-    gemm_tn<TU, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+    gemm_tn<TU, false, 2, ORD_COLMAJOR>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                        [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j, tile); });
     __syncthreads();
@@ -1454,7 +1509,15 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   stamp(17);
 #ifdef GAPRO_PROFILE
   if (threadIdx.x == 0)
-    for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+{
+      for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+      unsigned xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      f.scal[24 + 25] = (double)sh.t_start;  // timeline of the launch: tools/fit_timeline.py
+      f.scal[24 + 26] = (double)wall_clock64();
+      f.scal[24 + 27] = (double)(((xcc & 15u) << 16) | (hwid & 0xFFFFu));
+    }
 #endif
   if (threadIdx.x == 0) {
     f.scal[S_C] = sh.c;
@@ -1498,6 +1561,7 @@ __device__ inline void fit_setup(const gapro_fit_desc& desc, int D, const float*
 #ifdef GAPRO_PROFILE
     for (int i = 0; i < kProfSlots; ++i) sh.prof[i] = 0;
     sh.t_last = wall_clock64();
+    sh.t_start = sh.t_last;
 #endif
   }
   const int M = desc.m1 + desc.m2, Mp = lay.Mp;
@@ -2232,11 +2296,11 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
                            }
                          });
       __syncthreads();
-      gemm_tn<TU, false, 4>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+      gemm_tn<TU, false, 4, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                          [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                          [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
       __syncthreads();
-      gemm_tn<TU, false, 4>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+      gemm_tn<TU, false, 4, ORD_COLMAJOR>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                          [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                          [=](int i, int j, const d4& v) { store_tile(v, Gb, GTb, Mp, i, j, tile); });
       __syncthreads();
@@ -2316,7 +2380,15 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   stamp(17);
 #ifdef GAPRO_PROFILE
   if (threadIdx.x == 0)
-    for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+{
+      for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+      unsigned xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      f.scal[24 + 25] = (double)sh.t_start;  // timeline of the launch: tools/fit_timeline.py
+      f.scal[24 + 26] = (double)wall_clock64();
+      f.scal[24 + 27] = (double)(((xcc & 15u) << 16) | (hwid & 0xFFFFu));
+    }
 #endif
   if (threadIdx.x == 0) {
     f.scal[S_C] = sh.c;

@@ -86,6 +86,7 @@ struct Shared {
 #ifdef GAPRO_PROFILE
   unsigned long long prof[28];
   unsigned long long t_last;
+  unsigned long long t_start;
 #endif
 };
 __shared__ Shared g_sh;
@@ -223,7 +224,45 @@ __device__ __noinline__ void cl_reduce(double (&v)[K]) {
 //   Two register blocks of KS k-steps alternate with no guard in the steady-state body (see svgp_fit.hip).
 //   EP / EQ: element types of P and Q in memory (gd = float64, gf = float32: the mixed-precision mode's float32
 //   matrices feeding a float64 product are converted when a fragment is consumed, not when it is loaded).
-template <int TU, bool SCALE, typename EP = gd, typename EQ = gd, typename KRange, typename Epi>
+// ORD: tile enumeration, heaviest contraction range first for the product's kr; the cluster's waves take the tiles of
+// that order in serpentine rounds (0 .. CW-1, CW-1 .. 0, ...).  dealt round-robin in row-major order a wave whose
+// tiles all lie in one tile column (row length a multiple of the wave count) carries up to 1.9x the mean work when the
+// range depends on the column.  Which wave computes a tile does not change the tile.
+enum { ORD_ROWMAJOR = 0, ORD_ROWS_DESC = 1, ORD_COLMAJOR = 2, ORD_SHELLS = 3 };
+template <int ORD>
+__device__ inline bool tile_of(int q, int cw, int CW, int ntiles, int mo_tiles, int no_tiles, bool lower_only, int* ti_,
+                               int* tj_) {
+  const int t = q * CW + ((q & 1) ? CW - 1 - cw : cw);
+  if (t >= ntiles || cw < 0) return false;
+  int ti, tj;
+  if (lower_only) {
+    ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    tj = t - ti * (ti + 1) / 2;
+  } else if (ORD == ORD_ROWS_DESC) {
+    ti = t / no_tiles;
+    tj = t - ti * no_tiles;
+    ti = mo_tiles - 1 - ti;
+  } else if (ORD == ORD_COLMAJOR) {
+    tj = t / mo_tiles;
+    ti = t - tj * mo_tiles;
+  } else if (ORD == ORD_SHELLS) {  // square grids: shell m holds (m, 0 .. m) and (0 .. m-1, m)
+    int m = (int)sqrt((double)t);
+    while ((m + 1) * (m + 1) <= t) ++m;
+    while (m * m > t) --m;
+    const int r = t - m * m;
+    ti = r <= m ? m : r - m - 1;
+    tj = r <= m ? r : m;
+  } else {
+    ti = t / no_tiles;
+    tj = t - ti * no_tiles;
+  }
+  *ti_ = ti;
+  *tj_ = tj;
+  return true;
+}
+template <int TU, bool SCALE, typename EP = gd, typename EQ = gd, int ORD = ORD_ROWMAJOR, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const EP* __restrict__ P,
                                      const EQ* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
@@ -239,18 +278,13 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
   constexpr int TS = 16 * TU;
   constexpr int KS = TU >= 4 ? 1 : 2, KB = 4 * KS;  // 64 x 64 wave tiles: 128 accumulator registers, one k-step per block
   const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
+  const int rounds = (ntiles + CW - 1) / CW;
 #pragma nounroll
-  for (int t = cw; t < ntiles; t += CW) {
+  for (int q = 0; q < rounds; ++q) {
     int ti, tj;
-    if (lower_only) {
-      ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-      while (ti * (ti + 1) / 2 > t) --ti;
-      tj = t - ti * (ti + 1) / 2;
-    } else {
-      ti = t / no_tiles;
-      tj = t - ti * no_tiles;
-    }
+    if (!tile_of<ORD>(q, cw, CW, ntiles, mo_tiles, no_tiles, lower_only, &ti, &tj)) continue;
+    ti = uni(ti);
+    tj = uni(tj);
     const int i0 = ti * TS, j0 = tj * TS;
     int klo, khi;
     kr(i0, j0, &klo, &khi);
@@ -320,7 +354,7 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 
 // The same product on float32 operands with v_mfma_f32_16x16x4_f32 (the mixed-precision mode's L_S^T A, dA and dL_S
 // products): float32 accumulators in the standard C layout, register r -> row 4 (l >> 4) + r, column l & 15.
-template <int TU, bool SCALE, typename KRange, typename Epi>
+template <int TU, bool SCALE, int ORD = ORD_ROWMAJOR, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn_f32(int mo_tiles, int no_tiles, bool lower_only, const gf* __restrict__ P,
                                          const gf* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                          Epi epi) {
@@ -336,18 +370,13 @@ __device__ __noinline__ void gemm_tn_f32(int mo_tiles, int no_tiles, bool lower_
   constexpr int TS = 16 * TU;
   constexpr int KS = TU >= 4 ? 1 : 2, KB = 4 * KS;  // 64 x 64 wave tiles: 128 accumulator registers, one k-step per block
   const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
+  const int rounds = (ntiles + CW - 1) / CW;
 #pragma nounroll
-  for (int t = cw; t < ntiles; t += CW) {
+  for (int q = 0; q < rounds; ++q) {
     int ti, tj;
-    if (lower_only) {
-      ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-      while (ti * (ti + 1) / 2 > t) --ti;
-      tj = t - ti * (ti + 1) / 2;
-    } else {
-      ti = t / no_tiles;
-      tj = t - ti * no_tiles;
-    }
+    if (!tile_of<ORD>(q, cw, CW, ntiles, mo_tiles, no_tiles, lower_only, &ti, &tj)) continue;
+    ti = uni(ti);
+    tj = uni(tj);
     const int i0 = ti * TS, j0 = tj * TS;
     int klo, khi;
     kr(i0, j0, &klo, &khi);
@@ -931,12 +960,12 @@ __device__ __noinline__ void forward_products(int ncols) {
     gf* AT = (gf*)f.mat[B_AT];
     gf* BM = (gf*)f.mat[B_BM];
     gf* BMT = (gf*)f.mat[B_BMT];
-    gemm_tn<TU, false, gd, gf>(mt, nt, false, f.mat[B_U], (const gf*)f.mat[B_KX], Mp, nullptr,
+    gemm_tn<TU, false, gd, gf, ORD_ROWS_DESC>(mt, nt, false, f.mat[B_U], (const gf*)f.mat[B_KX], Mp, nullptr,
                               [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                               [=](int i, int n, const d4& v) { store_tile<gf>(v, A, AT, Mp, i, n); });
     cbar();
     stamp(20);
-    gemm_tn_f32<TU, false>(nt, mt, false, A, (const gf*)f.mat[B_LS], Mp, nullptr,
+    gemm_tn_f32<TU, false, ORD_COLMAJOR>(nt, mt, false, A, (const gf*)f.mat[B_LS], Mp, nullptr,
                           [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                           [=](int n, int j, const f4& v) { store_tile_f32(v, BMT, BM, Mp, n, j); });
     cbar();
@@ -951,12 +980,12 @@ __device__ __noinline__ void forward_products(int ncols) {
     gd* AT = f.mat[B_AT];
     gd* BM = f.mat[B_BM];
     gd* BMT = f.mat[B_BMT];
-    gemm_tn<TU, false>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                       [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n); });
     cbar();
     stamp(20);
-    gemm_tn<TU, false>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_COLMAJOR>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                       [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j); });
     cbar();
@@ -1218,7 +1247,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       const float step_f = (float)step_size, bc2s_f = (float)bc2s, Ndf = (float)Nd;
       col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * (double)ATf[(size_t)r * Mp + cc]; });
       // G_A = m g_mu^T + L_S (2 B g_v) - 2 A g_v on v_mfma_f32 (float32 operands, float32 epilogue)
-      gemm_tn_f32<TU, false>(mt, mt, false, LSTf, BMf, Mp, nullptr,
+      gemm_tn_f32<TU, false, ORD_ROWS_DESC>(mt, mt, false, LSTf, BMf, Mp, nullptr,
                             [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                             [=](int i0, int n0, const f4& v) {
                               const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1280,7 +1309,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       stamp(12);
     } else {
     col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
-    gemm_tn<TU, false>(mt, mt, false, LST, BM, Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC>(mt, mt, false, LST, BM, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                       [=](int i0, int n0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1358,7 +1387,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     stamp(13);
     // T1 = LI^T Pm, stored transposed -> BMT buffer
     gd* T1T = BMT;
-    gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, (gd*)nullptr, T1T, Mp, i, j); });
     cbar();
@@ -1366,7 +1395,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer
     gd* G = BM;
     gd* GT = GKXT;
-    gemm_tn<TU, false>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_COLMAJOR>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j); });
     cbar();
@@ -1462,7 +1491,15 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
   stamp(19);
 #ifdef GAPRO_PROFILE
   if (sh.g == 0 && threadIdx.x == 0)
+  {
     for (int i = 0; i < 28; ++i) f.scal[24 + i] = (double)sh.prof[i];
+    unsigned xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    f.scal[24 + 25] = (double)sh.t_start;  // timeline of the launch: tools/fit_timeline.py
+    f.scal[24 + 26] = (double)wall_clock64();
+    f.scal[24 + 27] = (double)(((xcc & 15u) << 16) | (hwid & 0xFFFFu));
+  }
 #endif
   if (sh.g == 0 && threadIdx.x == 0) {
     if (sh.status == GAPRO_OK && st[0] != 0.0) sh.status = GAPRO_ERR_NOT_FINITE;
@@ -1534,6 +1571,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
 #ifdef GAPRO_PROFILE
     for (int i = 0; i < 28; ++i) sh.prof[i] = 0;
     sh.t_last = wall_clock64();
+    sh.t_start = sh.t_last;
 #endif
   }
   __syncthreads();

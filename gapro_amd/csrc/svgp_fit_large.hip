@@ -427,6 +427,7 @@ struct Shared {
 #ifdef GAPRO_PROFILE
   unsigned long long prof[kProfSlots];
   unsigned long long t_last;
+  unsigned long long t_start;
 #endif
   double red[NW];
   double dblk[16 * 17];
@@ -724,7 +725,15 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
   stamp(17);
 #ifdef GAPRO_PROFILE
   if (threadIdx.x == 0)
-    for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+{
+      for (int i = 0; i < kProfSlots; ++i) f.scal[24 + i] = (double)sh.prof[i];
+      unsigned xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      f.scal[24 + 25] = (double)sh.t_start;  // timeline of the launch: tools/fit_timeline.py
+      f.scal[24 + 26] = (double)wall_clock64();
+      f.scal[24 + 27] = (double)(((xcc & 15u) << 16) | (hwid & 0xFFFFu));
+    }
 #endif
   if (threadIdx.x == 0) {
     f.scal[S_C] = sh.c;
@@ -800,6 +809,7 @@ __global__ __launch_bounds__(NT) void k_svgp_fit_large(int n_fits, int D, const 
 #ifdef GAPRO_PROFILE
     for (int i = 0; i < kProfSlots; ++i) sh.prof[i] = 0;
     sh.t_last = wall_clock64();
+    sh.t_start = sh.t_last;
 #endif
   }
   __syncthreads();
