@@ -262,7 +262,10 @@ __device__ inline bool tile_of(int q, int cw, int CW, int ntiles, int mo_tiles, 
   *tj_ = tj;
   return true;
 }
-template <int TU, bool SCALE, typename EP = gd, typename EQ = gd, int ORD = ORD_ROWMAJOR, typename KRange, typename Epi>
+// TRIM: the contraction runs over inducing / training points: it stops at M rounded up to the register block (rows
+// >= M of both operands are padding; valid outputs keep their bits).
+template <int TU, bool SCALE, typename EP = gd, typename EQ = gd, int ORD = ORD_ROWMAJOR, bool TRIM = false,
+          typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const EP* __restrict__ P,
                                      const EQ* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
@@ -290,6 +293,10 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
     kr(i0, j0, &klo, &khi);
     klo = uni(klo);
     khi = uni(khi);
+    if (TRIM) {
+      const int kmax = uni((g_sh.f.M + KB - 1) / KB * KB);
+      khi = khi < kmax ? khi : kmax;
+    }
     d4 acc[TU][TU];
 #pragma unroll
     for (int u = 0; u < TU; ++u)
@@ -354,7 +361,7 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 
 // The same product on float32 operands with v_mfma_f32_16x16x4_f32 (the mixed-precision mode's L_S^T A, dA and dL_S
 // products): float32 accumulators in the standard C layout, register r -> row 4 (l >> 4) + r, column l & 15.
-template <int TU, bool SCALE, int ORD = ORD_ROWMAJOR, typename KRange, typename Epi>
+template <int TU, bool SCALE, int ORD = ORD_ROWMAJOR, bool TRIM = false, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn_f32(int mo_tiles, int no_tiles, bool lower_only, const gf* __restrict__ P,
                                          const gf* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                          Epi epi) {
@@ -382,6 +389,10 @@ __device__ __noinline__ void gemm_tn_f32(int mo_tiles, int no_tiles, bool lower_
     kr(i0, j0, &klo, &khi);
     klo = uni(klo);
     khi = uni(khi);
+    if (TRIM) {
+      const int kmax = uni((g_sh.f.M + KB - 1) / KB * KB);
+      khi = khi < kmax ? khi : kmax;
+    }
     f4 acc[TU][TU];
 #pragma unroll
     for (int u = 0; u < TU; ++u)
@@ -960,12 +971,12 @@ __device__ __noinline__ void forward_products(int ncols) {
     gf* AT = (gf*)f.mat[B_AT];
     gf* BM = (gf*)f.mat[B_BM];
     gf* BMT = (gf*)f.mat[B_BMT];
-    gemm_tn<TU, false, gd, gf, ORD_ROWS_DESC>(mt, nt, false, f.mat[B_U], (const gf*)f.mat[B_KX], Mp, nullptr,
+    gemm_tn<TU, false, gd, gf, ORD_ROWS_DESC, true>(mt, nt, false, f.mat[B_U], (const gf*)f.mat[B_KX], Mp, nullptr,
                               [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                               [=](int i, int n, const d4& v) { store_tile<gf>(v, A, AT, Mp, i, n); });
     cbar();
     stamp(20);
-    gemm_tn_f32<TU, false, ORD_COLMAJOR>(nt, mt, false, A, (const gf*)f.mat[B_LS], Mp, nullptr,
+    gemm_tn_f32<TU, false, ORD_COLMAJOR, true>(nt, mt, false, A, (const gf*)f.mat[B_LS], Mp, nullptr,
                           [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                           [=](int n, int j, const f4& v) { store_tile_f32(v, BMT, BM, Mp, n, j); });
     cbar();
@@ -980,12 +991,12 @@ __device__ __noinline__ void forward_products(int ncols) {
     gd* AT = f.mat[B_AT];
     gd* BM = f.mat[B_BM];
     gd* BMT = f.mat[B_BMT];
-    gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC, true>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                       [=](int i, int n, const d4& v) { store_tile(v, A, AT, Mp, i, n); });
     cbar();
     stamp(20);
-    gemm_tn<TU, false, gd, gd, ORD_COLMAJOR>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_COLMAJOR, true>(nt, mt, false, A, f.mat[B_LS], Mp, nullptr,
                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                       [=](int n, int j, const d4& v) { store_tile(v, BMT, BM, Mp, n, j); });
     cbar();
@@ -1247,7 +1258,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       const float step_f = (float)step_size, bc2s_f = (float)bc2s, Ndf = (float)Nd;
       col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * (double)ATf[(size_t)r * Mp + cc]; });
       // G_A = m g_mu^T + L_S (2 B g_v) - 2 A g_v on v_mfma_f32 (float32 operands, float32 epilogue)
-      gemm_tn_f32<TU, false, ORD_ROWS_DESC>(mt, mt, false, LSTf, BMf, Mp, nullptr,
+      gemm_tn_f32<TU, false, ORD_ROWS_DESC, true>(mt, mt, false, LSTf, BMf, Mp, nullptr,
                             [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                             [=](int i0, int n0, const f4& v) {
                               const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1263,7 +1274,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       cbar();
       stamp(10);
       // G_LS (lower) + KL' with Adam on the float32 L_S in the epilogue
-      gemm_tn_f32<TU, true>(mt, mt, true, ATf, BMTf, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+      gemm_tn_f32<TU, true, ORD_ROWMAJOR, true>(mt, mt, true, ATf, BMTf, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                            [=](int i0, int j0, const f4& v) {
                              const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                              const int j = j0 + lr;
@@ -1288,14 +1299,14 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                              store_tile_f32(newv, (gf*)nullptr, LSTf, Mp, i0, j0);
                            });
       // G_KX = LI^T G_A in float64 (the float32 G_A enters through .double())
-      gemm_tn<TU, false, gd, gf>(mt, mt, false, f.mat[B_LI], GAf, Mp, nullptr,
+      gemm_tn<TU, false, gd, gf, ORD_ROWMAJOR, true>(mt, mt, false, f.mat[B_LI], GAf, Mp, nullptr,
                                 [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                                 [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
       cbar();
       stamp(11);
       // G_L = -tril(G_KX A^T) in float64 -> the whole B slot (the float32 B in its first half is dead)
       gd* GLm = BM;
-      gemm_tn<TU, false, gd, gf>(mt, mt, true, GKXT, ATf, Mp, nullptr,
+      gemm_tn<TU, false, gd, gf, ORD_ROWMAJOR, true>(mt, mt, true, GKXT, ATf, Mp, nullptr,
                                 [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                                 [=](int i0, int j0, const d4& v) {
                                   const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1309,7 +1320,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       stamp(12);
     } else {
     col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
-    gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC>(mt, mt, false, LST, BM, Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC, true>(mt, mt, false, LST, BM, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                       [=](int i0, int n0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1326,7 +1337,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     stamp(10);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] B[j][n] (lower) + KL', Adam on L_S in the epilogue (L_S^T through the
     // wave's transpose tile: 128-byte rows)
-    gemm_tn<TU, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+    gemm_tn<TU, true, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                      [=](int i0, int j0, const d4& v) {
                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                        const int j = j0 + lr;
@@ -1351,14 +1362,14 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                        store_tile(newv, (gd*)nullptr, LST, Mp, i0, j0);  // LST[j][i]; zeros above the diagonal
                      });
     // G_KX = LI^T G_A
-    gemm_tn<TU, false>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                       [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
     cbar();
     stamp(11);
     // G_L = -tril(G_KX A^T) -> BM buffer
     gd* GLd = BM;
-    gemm_tn<TU, false>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+    gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                       [=](int i0, int j0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
 #pragma unroll
@@ -1373,7 +1384,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     gd* GL = BM;
     // Pm = Phi(tril(L^T G_L)) -> GA buffer
     gd* Pm = GA;
-    gemm_tn<TU, false>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                       [=](int i0, int j0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
@@ -1387,7 +1398,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     stamp(13);
     // T1 = LI^T Pm, stored transposed -> BMT buffer
     gd* T1T = BMT;
-    gemm_tn<TU, false, gd, gd, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_SHELLS, true>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, (gd*)nullptr, T1T, Mp, i, j); });
     cbar();
@@ -1395,7 +1406,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer
     gd* G = BM;
     gd* GT = GKXT;
-    gemm_tn<TU, false, gd, gd, ORD_COLMAJOR>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+    gemm_tn<TU, false, gd, gd, ORD_COLMAJOR, true>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j); });
     cbar();
