@@ -2501,7 +2501,11 @@ static int fit_route(int m, int feat_dim, int flags) {
     const bool small = gapro_pad_m(m) <= kSmallFitMp && 2 * gapro_fit_strip_small_lds_bytes(m, feat_dim) + 16384 <= 160 * 1024;
     return (small && !(flags & 4)) ? 3 : 0;
   }
-  return staged_ok(m, feat_dim) ? 1 : 2;
+  if (staged_ok(m, feat_dim)) return 1;
+  // neither LDS-resident kernel takes it (deep features: Z and X of M_p > 192 points at D = 32 do not fit beside the
+  // Cholesky block column): the cluster kernel keeps the points in global memory and runs such a fit on one workgroup
+  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m), true) > 0) return 4;
+  return 2;
 }
 
 extern "C" {

@@ -673,42 +673,93 @@ __device__ inline double sqdist_t(const gd* At, int i, const gd* Bt, int j, int 
 // point: broadcast loads) and walks the columns 64 at a time (coalesced loads of the transposed points).
 // MX (mixed precision, the reference's split): the kernel matrix is evaluated in float32 arithmetic, as gpytorch
 // evaluates it, and handed to the float64 factorisation (K.double()).
+// Squared distances between RB consecutive row points i0 .. i0 + RB - 1 of At[D][lda] (i0 wave-uniform: their
+// coordinates are the same address in every lane) and column point j of Bt[D][ldb] (coalesced over the lanes).  A
+// column coordinate is loaded once for RB pairs and the d-loop is unrolled, so several loads are in flight: with one
+// row per pass and a rolled loop the kernel evaluations waited for one load at a time and, at D = 32, re-streamed
+// 2 D M_p coordinates per row through a 32 KiB L1.
+constexpr int kRowBlock = 4;
+// the row block's coordinates, [d][kRowBlock], in the wave's transpose tile (LDS): read back as broadcasts
+__device__ inline const ldsd* stage_rows(const gd* __restrict__ At, int lda, int i0, int D) {
+  ldsd* zl = (ldsd*)g_sh.tile + (threadIdx.x >> 6) * (16 * 17);
+  const int lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();  // the previous block's reads are done
+  for (int e = lane; e < kRowBlock * D; e += 64) zl[e] = At[(size_t)(e / kRowBlock) * lda + i0 + (e % kRowBlock)];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  return zl;
+}
+template <typename R>
+__device__ inline void sqdist_rows(const ldsd* zl, const gd* __restrict__ Bt, int ldb, int j, int D,
+                                   R (&d2)[kRowBlock]) {
+#pragma unroll
+  for (int r = 0; r < kRowBlock; ++r) d2[r] = (R)0;
+#pragma unroll 8
+  for (int d = 0; d < D; ++d) {
+    const R q = (R)Bt[(size_t)d * ldb + j];
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) {
+      const R t = (R)zl[kRowBlock * d + r] - q;
+      d2[r] += t * t;
+    }
+  }
+}
+// the same against two column sets at once (kernel gradients: Z_j and X_j)
+template <typename R>
+__device__ inline void sqdist_rows2(const ldsd* zl, const gd* __restrict__ Bt, const gd* __restrict__ Ct, int ldb, int j,
+                                    int D, R (&d2)[kRowBlock], R (&d2x)[kRowBlock]) {
+#pragma unroll
+  for (int r = 0; r < kRowBlock; ++r) d2[r] = d2x[r] = (R)0;
+#pragma unroll 8
+  for (int d = 0; d < D; ++d) {
+    const R q = (R)Bt[(size_t)d * ldb + j], qx = (R)Ct[(size_t)d * ldb + j];
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) {
+      const R z = (R)zl[kRowBlock * d + r];
+      const R t = z - q, tx = z - qx;
+      d2[r] += t * t;
+      d2x[r] += tx * tx;
+    }
+  }
+}
+
 template <bool MX>
 __device__ __noinline__ void build_kzz(double s, double inv_l2, double jitter, double extra) {
+  typedef typename std::conditional<MX, float, double>::type R;
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   gd* L = f.mat[B_L];
   const gd* Zt = f.Zt;
   const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
   const float sf = (float)s, hf = -0.5f * (float)inv_l2, jf = (float)jitter;
-  for (int i = cw; i < Mp; i += CW) {
-    gd* row = L + (size_t)i * Mp;
+  for (int i0 = kRowBlock * cw; i0 < Mp; i0 += kRowBlock * CW) {  // M_p is a multiple of 32
+    const ldsd* zl = stage_rows(Zt, Mp, i0, D);
     for (int j = lane; j < Mp; j += 64) {
-      double v = 0.0;
-      if (i < M && j <= i) {
-        if (MX) {
-          float d2 = 0.f;
-          for (int d = 0; d < D; ++d) {
-            const float t = (float)Zt[(size_t)d * Mp + i] - (float)Zt[(size_t)d * Mp + j];
-            d2 += t * t;
+      double v[kRowBlock];
+#pragma unroll
+      for (int r = 0; r < kRowBlock; ++r) v[r] = (i0 + r >= M && i0 + r == j) ? 1.0 : 0.0;  // identity on the padded tail
+      if (i0 < M && j < i0 + kRowBlock && j < M) {  // some row of the block has j <= i < M
+        R d2[kRowBlock];
+        sqdist_rows<R>(zl, Zt, Mp, j, D, d2);
+#pragma unroll
+        for (int r = 0; r < kRowBlock; ++r) {
+          const int i = i0 + r;
+          if (i < M && j <= i) {
+            if (MX) {
+              float kv = sf * expf(hf * (float)d2[r]);
+              if (i == j) kv += jf;  // the variational jitter is added to the float32 matrix ...
+              v[r] = (double)kv;
+              if (i == j) v[r] += extra;  // ... psd_safe_cholesky's retry jitter to its float64 copy
+            } else {
+              v[r] = s * exp(-0.5 * inv_l2 * (double)d2[r]);
+              if (i == j) v[r] += jitter + extra;
+            }
           }
-          float kv = sf * expf(hf * d2);
-          if (i == j) kv += jf;  // the variational jitter is added to the float32 matrix ...
-          v = (double)kv;
-          if (i == j) v += extra;  // ... psd_safe_cholesky's retry jitter to its float64 copy
-        } else {
-          double d2 = 0.0;
-          for (int d = 0; d < D; ++d) {
-            const double t = Zt[(size_t)d * Mp + i] - Zt[(size_t)d * Mp + j];
-            d2 += t * t;
-          }
-          v = s * exp(-0.5 * inv_l2 * d2);
-          if (i == j) v += jitter + extra;
         }
-      } else if (i >= M && i == j) {
-        v = 1.0;
       }
-      row[j] = v;
+#pragma unroll
+      for (int r = 0; r < kRowBlock; ++r) L[(size_t)(i0 + r) * Mp + j] = v[r];
     }
   }
 }
@@ -888,6 +939,7 @@ __device__ __noinline__ void tri_inverse_cluster() {
 // MX: float32 arithmetic, float32 storage.
 template <bool MX>
 __device__ __noinline__ void build_kx(const gd* Pt, int ldp, int ncols, double s, double inv_l2) {
+  typedef typename std::conditional<MX, float, double>::type R;
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = f.D;
   gd* KX = f.mat[B_KX];
@@ -895,30 +947,19 @@ __device__ __noinline__ void build_kx(const gd* Pt, int ldp, int ncols, double s
   const gd* Zt = f.Zt;
   const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63;
   const float sf = (float)s, hf = -0.5f * (float)inv_l2;
-  for (int k = cw; k < Mp; k += CW) {
+  for (int k0 = kRowBlock * cw; k0 < Mp; k0 += kRowBlock * CW) {
+    const ldsd* zl = stage_rows(Zt, Mp, k0, D);
     for (int c = lane; c < Mp; c += 64) {
-      if (MX) {
-        float v = 0.f;
-        if (k < M && c < ncols) {
-          float d2 = 0.f;
-          for (int d = 0; d < D; ++d) {
-            const float t = (float)Zt[(size_t)d * Mp + k] - (float)Pt[(size_t)d * ldp + c];
-            d2 += t * t;
-          }
-          v = sf * expf(hf * d2);
-        }
-        KXf[(size_t)k * Mp + c] = v;
-      } else {
-        double v = 0.0;
-        if (k < M && c < ncols) {
-          double d2 = 0.0;
-          for (int d = 0; d < D; ++d) {
-            const double t = Zt[(size_t)d * Mp + k] - Pt[(size_t)d * ldp + c];
-            d2 += t * t;
-          }
-          v = s * exp(-0.5 * inv_l2 * d2);
-        }
-        KX[(size_t)k * Mp + c] = v;
+      R d2[kRowBlock];
+      const bool in = k0 < M && c < ncols;
+      if (in) sqdist_rows<R>(zl, Pt, ldp, c, D, d2);
+#pragma unroll
+      for (int r = 0; r < kRowBlock; ++r) {
+        const bool ok = in && k0 + r < M;
+        if (MX)
+          KXf[(size_t)(k0 + r) * Mp + c] = ok ? sf * expf(hf * (float)d2[r]) : 0.f;
+        else
+          KX[(size_t)(k0 + r) * Mp + c] = ok ? s * exp(-0.5 * inv_l2 * (double)d2[r]) : 0.0;
       }
     }
   }
@@ -1026,71 +1067,154 @@ __device__ __noinline__ void kernel_grads(const gd* __restrict__ G, const gd* __
   const gf* KXf = (const gf*)KX;
   const R sr = (R)s, hr = (R)(-0.5) * (R)inv_l2;
   double k0 = 0.0, k1 = 0.0;
-  for (int i = cw; i < M; i += CW) {
-    R acc[DMAX], zi[DMAX];
+  // kRowBlock rows per pass: a column's points are loaded once for the block, and the block's 4 x kRowBlock matrix
+  // elements are requested together (one row per pass waited ~1.7 us per 64 pairs for four dependent-free loads)
+  for (int i0 = kRowBlock * cw; i0 < M; i0 += kRowBlock * CW) {
+    R acc[kRowBlock][DMAX], wsum[kRowBlock];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) {
-      acc[d] = (R)0;
-      zi[d] = d < D ? (R)Zt[(size_t)d * Mp + i] : (R)0;
+    for (int r = 0; r < kRowBlock; ++r) {
+      wsum[r] = (R)0;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) acc[r][d] = (R)0;
     }
-    R wsum = (R)0;
+    const ldsd* zl = stage_rows(Zt, Mp, i0, D);
     for (int j = lane; j < M; j += 64) {
-      const size_t o = (size_t)i * Mp + j;
-      const R gsym = (R)(0.5 * (G[o] + GT[o]));
-      const R gk = (R)GKX[o];
-      const R kx = MX ? (R)KXf[o] : (R)KX[o];
-      R d2 = (R)0, d2x = (R)0;
-      if (DMAX <= 8) {  // narrow features: the column's points stay in registers between the two uses
-        R zj[DMAX], xj[DMAX];
+      R gsym[kRowBlock], gk[kRowBlock], kx[kRowBlock];
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) {
-          zj[d] = d < D ? (R)Zt[(size_t)d * Mp + j] : (R)0;
-          xj[d] = d < D ? (R)Xc[(size_t)d * Mp + j] : (R)0;
-          const R a = zi[d] - zj[d], bx = zi[d] - xj[d];
-          d2 += a * a;
-          d2x += bx * bx;
-        }
-        const R e = MX ? (R)expf((float)(hr * d2)) : (R)exp((double)(hr * d2));
-        const R w = gsym * sr * e, wx = gk * kx;
-        k0 += (double)(gsym * e + gk * kx / sr);
-        k1 += (double)(w * d2 + wx * d2x);
-        // sum_j w_j (Z_i - P_j) = Z_i sum_j w_j - sum_j w_j P_j : only the weighted point sums are accumulated
-        wsum += (R)2 * w + wx;
+      for (int r = 0; r < kRowBlock; ++r) {
+        const size_t o = (size_t)(i0 + r < M ? i0 + r : i0) * Mp + j;
+        gsym[r] = (R)(0.5 * (G[o] + GT[o]));
+        gk[r] = (R)GKX[o];
+        kx[r] = MX ? (R)KXf[o] : (R)KX[o];
+      }
+      R zj[DMAX], xj[DMAX];
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) acc[d] += (R)2 * w * zj[d] + wx * xj[d];
-      } else {  // deep features (D = 32): re-read the column's points (L1 hits) instead of holding 64 more values
+      for (int d = 0; d < DMAX; ++d) {
+        zj[d] = d < D ? (R)Zt[(size_t)d * Mp + j] : (R)0;
+        xj[d] = d < D ? (R)Xc[(size_t)d * Mp + j] : (R)0;
+      }
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) {
-          if (d < D) {
-            const R a = zi[d] - (R)Zt[(size_t)d * Mp + j], bx = zi[d] - (R)Xc[(size_t)d * Mp + j];
+      for (int r = 0; r < kRowBlock; ++r) {
+        if (i0 + r < M) {
+          R d2 = (R)0, d2x = (R)0;
+#pragma unroll
+          for (int d = 0; d < DMAX; ++d) {
+            const R zi = d < D ? (R)zl[kRowBlock * d + r] : (R)0;
+            const R a = zi - zj[d], bx = zi - xj[d];
             d2 += a * a;
             d2x += bx * bx;
           }
-        }
-        const R e = MX ? (R)expf((float)(hr * d2)) : (R)exp((double)(hr * d2));
-        const R w = gsym * sr * e, wx = gk * kx;
-        k0 += (double)(gsym * e + gk * kx / sr);
-        k1 += (double)(w * d2 + wx * d2x);
-        wsum += (R)2 * w + wx;
+          const R e = MX ? (R)expf((float)(hr * d2)) : (R)exp((double)(hr * d2));
+          const R w = gsym[r] * sr * e, wx = gk[r] * kx[r];
+          k0 += (double)(gsym[r] * e + gk[r] * kx[r] / sr);
+          k1 += (double)(w * d2 + wx * d2x);
+          // sum_j w_j (Z_i - P_j) = Z_i sum_j w_j - sum_j w_j P_j : only the weighted point sums are accumulated
+          wsum[r] += (R)2 * w + wx;
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d)
-          if (d < D) acc[d] += (R)2 * w * (R)Zt[(size_t)d * Mp + j] + wx * (R)Xc[(size_t)d * Mp + j];
+          for (int d = 0; d < DMAX; ++d) acc[r][d] += (R)2 * w * zj[d] + wx * xj[d];
+        }
       }
     }
-    const double wsum_d = wave_sum((double)wsum);
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) {
-      if (d < D) {
-        const double a = wave_sum((double)acc[d]);
-        if (lane == 0) {
-          const double gz = -inv_l2 * (wsum_d * (double)zi[d] - a);
-          f.gZ[(size_t)i * D + d] = MX ? (double)(float)gz : gz;
+    for (int r = 0; r < kRowBlock; ++r) {
+      const double wsum_d = wave_sum((double)wsum[r]);
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) {
+        if (d < D && i0 + r < M) {
+          const double a = wave_sum((double)acc[r][d]);
+          if (lane == 0) {
+            const double gz = -inv_l2 * (wsum_d * (double)(R)zl[kRowBlock * d + r] - a);
+            f.gZ[(size_t)(i0 + r) * D + d] = MX ? (double)(float)gz : gz;
+          }
         }
       }
     }
   }
   ks[0] = k0;
   ks[1] = k1;
+}
+
+// The same gradients for deep features (8 < D <= 32), in two phases.  One pass with D = 32 needs the 32 weighted point
+// sums AND the row's point in registers and spilled (it took 2/3 of a step at M = 224).  Here the elementwise phase only
+// forms the weights, W2 = 2 w in place of G and WX = wx in place of G_KX (row sums of both in V_MU), and the weighted
+// point sums  sum_j W2[i][j] Z_j + WX[i][j] X_j  are an M x M x D product on the matrix cores: A fragments straight
+// from the row-major weights (lane (i, k) reads W[i][k]: 32-byte segments, L2-resident, the product is tiny), B
+// fragments from the row-major points.
+template <bool MX>
+__device__ __noinline__ void kernel_grads_deep(gd* __restrict__ G, const gd* __restrict__ GT, gd* __restrict__ GKX,
+                                               const gd* __restrict__ KX, double s, double inv_l2, double (&ks)[2]) {
+  typedef typename std::conditional<MX, float, double>::type R;
+  const Fit& f = g_sh.f;
+  const int M = f.M, Mp = f.Mp, D = f.D;
+  const int cw = cl_wave(), CW = cl_waves(), lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const gd* Zt = f.Zt;
+  const gd* Xc = f.XtT;
+  const gf* KXf = (const gf*)KX;
+  gd* wsum_v = f.vec[V_MU];
+  const R sr = (R)s, hr = (R)(-0.5) * (R)inv_l2;
+  double k0 = 0.0, k1 = 0.0;
+  for (int i0 = kRowBlock * cw; i0 < M; i0 += kRowBlock * CW) {
+    R wsum[kRowBlock];
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) wsum[r] = (R)0;
+    const ldsd* zl = stage_rows(Zt, Mp, i0, D);
+    for (int j = lane; j < M; j += 64) {
+      R d2[kRowBlock], d2x[kRowBlock];
+      sqdist_rows2<R>(zl, Zt, Xc, Mp, j, D, d2, d2x);
+#pragma unroll
+      for (int r = 0; r < kRowBlock; ++r) {
+        if (i0 + r < M) {
+          const size_t o = (size_t)(i0 + r) * Mp + j;
+          const R gsym = (R)(0.5 * (G[o] + GT[o]));
+          const R gk = (R)GKX[o];
+          const R kx = MX ? (R)KXf[o] : (R)KX[o];
+          const R e = MX ? (R)expf((float)(hr * d2[r])) : (R)exp((double)(hr * d2[r]));
+          const R w = gsym * sr * e, wx = gk * kx;
+          k0 += (double)(gsym * e + gk * kx / sr);
+          k1 += (double)(w * d2[r] + wx * d2x[r]);
+          wsum[r] += (R)2 * w + wx;
+          G[o] = (double)((R)2 * w);
+          GKX[o] = (double)wx;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowBlock; ++r) {
+      const double wsum_d = wave_sum((double)wsum[r]);
+      if (lane == 0 && i0 + r < M) wsum_v[i0 + r] = wsum_d;
+    }
+  }
+  ks[0] = k0;
+  ks[1] = k1;
+  cbar();  // the weights of every row are visible to the whole cluster
+  const int mt16 = (M + 15) / 16, dt16 = (D + 15) / 16, k4 = (M + 3) / 4 * 4;
+  const gd* Zr = f.Z;
+  const gd* Xr = f.X;
+  for (int t = cw; t < mt16 * dt16; t += CW) {
+    const int ti = t / dt16, td = t - ti * dt16;
+    const int i0 = 16 * ti, d0 = 16 * td;
+    const int ia = i0 + lr, dn = d0 + lr;
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    const gd* w2 = G + (size_t)(ia < M ? ia : 0) * Mp;
+    const gd* wxr = GKX + (size_t)(ia < M ? ia : 0) * Mp;
+#pragma unroll 4
+    for (int k = lq; k < k4; k += 4) {
+      const bool kin = k < M;
+      const double a2 = (kin && ia < M) ? w2[k] : 0.0, ax = (kin && ia < M) ? wxr[k] : 0.0;
+      const double bz = (kin && dn < D) ? Zr[(size_t)k * D + dn] : 0.0;
+      const double bxv = (kin && dn < D) ? Xr[(size_t)k * D + dn] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bz, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bxv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + lq + 4 * r;
+      if (i < M && dn < D) {
+        const double gz = -inv_l2 * (wsum_v[i] * Zr[(size_t)i * D + dn] - acc[r]);
+        f.gZ[(size_t)i * D + dn] = MX ? (double)(float)gz : gz;
+      }
+    }
+  }
 }
 
 template <bool MX, int TU>
@@ -1417,7 +1541,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     //   wx = G_KX[i][j] KX_ij     ->  G_s += G_KX KX / s, G_l += wx d2x, G_Z[i] += wx (Z_i - X_j)
     double ks[2] = {0.0, 0.0};
     if (D <= 8) kernel_grads<8, MX>(G, GT, GKX, KX, s, inv_l2, ks);
-    else kernel_grads<32, MX>(G, GT, GKX, KX, s, inv_l2, ks);
+    else kernel_grads_deep<MX>(G, GT, GKX, KX, s, inv_l2, ks);
     cl_reduce(ks);  // its barrier also publishes G_Z: every entry was computed from the OLD Z
     stamp(16);
     const double g_s = ks[0] + gv_sum;

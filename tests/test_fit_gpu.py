@@ -67,11 +67,11 @@ def test_fit_matches_oracle(m1, m2, t, d, iters):
     _compare(out, _oracle(feats, b1, b2, it, iters))
 
 
-@pytest.mark.parametrize("m1,m2,t,iters,route", [(150, 170, 60, 50, 1), (200, 210, 90, 50, 4), (260, 270, 90, 50, 4),
-                                                  (340, 360, 50, 50, 4), (260, 270, 90, 5, 2)])
+@pytest.mark.parametrize("m1,m2,t,iters,route", [(150, 170, 60, 50, 1), (200, 210, 90, 50, 1), (230, 245, 40, 50, 4),
+                                                  (260, 270, 90, 50, 4), (340, 360, 50, 50, 4), (260, 270, 90, 5, 2)])
 def test_fit_large_inducing_sets(m1, m2, t, iters, route):
-    """BASELINE configs[3] territory (large overlap regions): M_p = 320 runs the LDS-staged kernel on one CU; from
-    M_p > 384 on a fit is spread over 2, 4, 8, ... workgroups by the cluster kernel (route 4; here G = 2, 4, 8), checked
+    """BASELINE configs[3] territory (large overlap regions): M_p = 320 and 416 run the LDS-staged kernel on one CU; from
+    M_p >= 480 on a fit is spread over 2, 4, 8, ... workgroups by the cluster kernel (route 4; here G = 2, 4, 8), checked
     against the float64 oracle at the full 50 Adam steps; route 2 = the same fit kept on one workgroup in the generic
     kernel (debug bit 3 of gapro_fit_options.reserved)."""
     import torch
@@ -293,17 +293,29 @@ def test_small_fit_kernel_and_strip_kernel_agree():
             np.testing.assert_allclose(np.asarray(x, np.float64), np.asarray(y, np.float64), rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("m1,m2,t,route", [(20, 28, 12, 3), (40, 50, 33, 0), (90, 100, 40, 1), (120, 136, 25, 2)])
+@pytest.mark.parametrize("m1,m2,t,route", [(20, 28, 12, 3), (40, 50, 33, 0), (90, 100, 40, 1), (120, 136, 25, 4),
+                                           (120, 136, 25, 2), (250, 262, 30, 4)])
 def test_fit_matches_oracle_with_deep_features_on_every_route(m1, m2, t, route):
     """D = 32 (--use_deepfeat) against the float64 oracle on each kernel: small-fit strip (3), 512-thread strip (0),
-    LDS-staged (1) and generic (2), 50 Adam steps, the tolerances of D = 6."""
+    LDS-staged (1), the cluster kernel (4: on ONE workgroup for 192 < M_p < 480, where 2 x 32 x M_p staged point
+    coordinates do not fit the LDS beside the Cholesky block column, and over 4 at M_p = 512) and the generic kernel
+    (2, debug bit 3), 50 Adam steps, the tolerances of D = 6."""
+    import torch
     from gapro_amd import _lib
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.gen_ps_utils import _pipeline
     from gapro_amd.synth import make_gp_problem
 
-    assert _lib.load().gapro_fit_route(m1 + m2, 32) == route
+    assert _lib.load().gapro_fit_route(m1 + m2, 32) == (route if route != 2 else 4)
     feats, b1, b2, it = make_gp_problem(70 + m1, m1, m2, t, 32, std=0.3)
-    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=50)[0]
+    pipe = _pipeline(torch.device("cuda", 0), 50)
+    old = pipe.opt.reserved
+    if route == 2:
+        pipe.opt.reserved = old | 8
+    try:
+        out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=50)[0]
+    finally:
+        pipe.opt.reserved = old
     _compare(out, _oracle(feats, b1, b2, it, 50))
 
 

@@ -185,17 +185,19 @@ def main():
             names = ["chol:update", "chol:rest", "inv", "kx", "A+BMT+meanvar", "chol:diag", "quad/kl", "Gm+GA",
                      "GLS+adam", "GKX", "GL", "Pm", "T1", "G", "kgrads+adamZ", "-", "adam", "predict", "chol:panel",
                      "misc"]
-            if not args.force_staged and m <= 128:
+            route = _lib.load().gapro_fit_route(m, args.d)
+            if not args.force_staged and route in (0, 3):
                 names = ["chol:update", "chol:rest", "inv", "s:fill", "s:A", "chol:diag", "post-strips", "s:B",
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
                          "s:GKX", "adam", "predict", "s:GLacc+store", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
                          "(diag:stores", "x25", "x26", "x27"]
             from gapro_amd import _lib as _l
-            if _l.load().gapro_fit_route(m, args.d) == 4 and not args.no_cluster:
+            if (route == 4 or args.cluster_all) and not args.no_cluster:
                 names = ["kzz", "chol:diag(leader)", "chol:panel", "chol:trailing", "inverse", "kx", "fwd:colpart",
                          "-", "chol:flag", "quad+kl", "Gm+GA", "GLS+adamLS+GKX", "GL", "Pm", "T1", "G", "kgrads(fused)", "-",
                          "adam", "predict", "fwd:A", "fwd:B", "-", "-", "-", "-", "-", "-"]
-            tot = prof.sum()
+            prof = prof[:25]  # slots 25 .. 27: start / end / CU of the workgroup (tools/fit_timeline.py)
+            tot = prof[:22].sum()
             print("    phases (us per fit, share): " + "  ".join(
                 "%s %.0f (%.0f%%)" % (nm, v / 100.0, 100 * v / tot) for nm, v in zip(names, prof) if v > 0), flush=True)
 
