@@ -205,6 +205,26 @@ def test_s3dis_shaped_scene_matches_oracle():
     assert (~ok).sum() <= n_loose_spp  # ... everywhere but on superpoints labelled by the ill-conditioned fit(s)
 
 
+@pytest.mark.parametrize("seed", [63, 20])
+def test_train_split_shaped_scenes_match_oracle(seed):
+    """BASELINE configs[2]'s scene stream as bench.py draws it (N ~ logN(150k, 0.5), 10 .. 40 objects, wall boxes
+    read back from ScanNet-Planes quads through get_wall_boxes): the two smallest scenes with walls of the first 64
+    seeds (50k and 70k points, 23 fits each, M up to 105), whole generator against the oracle."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from gapro_amd import gen_pseudo_label_gaussian_process
+
+    kw = bench.build_scene_inputs(seed, 150000, 6, "stream")
+    assert len(kw["wall_box"]) == 4
+    kw["training_iter"] = 50
+    ref, dbg = _oracle_outputs(kw)
+    assert len(dbg["results"]) >= 20
+    _check(gen_pseudo_label_gaussian_process(**kw), ref, dbg)
+
+
 def test_scenes_without_any_gp_fit_and_mixed_batches():
     """Edge cases of the schedule: a scene whose boxes never overlap on a shared superpoint has no GP fit at all
     (labels come from containment alone, mu / var stay -100), alone and batched with a scene that does."""
