@@ -14,6 +14,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kChains = 8;
 
 __global__ __launch_bounds__(256) void k_peak_f64(int iters, double* __restrict__ sink) {
+  const long long c0 = clock64(), w0 = wall_clock64();  // shader cycles (s_memtime) / 100 MHz constant clock
   d4 acc[kChains];
 #pragma unroll
   for (int c = 0; c < kChains; ++c) acc[c] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -26,6 +27,10 @@ __global__ __launch_bounds__(256) void k_peak_f64(int iters, double* __restrict_
 #pragma unroll
   for (int c = 0; c < kChains; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
   if (s == 12345.678) sink[0] = s;  // keeps the chains alive without a store in the common case
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // sink[1], sink[2]: this wave's shader cycles and 100 MHz ticks
+    sink[1] = (double)(clock64() - c0);
+    sink[2] = (double)(wall_clock64() - w0);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_peak_f32(int iters, double* __restrict__ sink) {
@@ -45,15 +50,34 @@ __global__ __launch_bounds__(256) void k_peak_f32(int iters, double* __restrict_
 
 }  // namespace
 
+static int mfma_peak(gapro_ctx* ctx, void* stream_, int32_t kind, int32_t iters, int32_t waves_per_simd,
+                     int32_t n_blocks, double* d_sink, double* out_tflops);
+
 extern "C" int gapro_debug_mfma_peak(gapro_ctx* ctx, void* stream_, int32_t kind, int32_t iters,
                                      int32_t waves_per_simd, double* d_sink, double* out_tflops) {
+  return mfma_peak(ctx, stream_, kind, iters, waves_per_simd, 0, d_sink, out_tflops);
+}
+
+extern "C" int gapro_debug_mfma_clock(gapro_ctx* ctx, void* stream_, int32_t iters, int32_t waves_per_simd,
+                                      int32_t n_blocks, double* d_sink, double* out_tflops, double* out_shader_mhz) {
+  if (!out_shader_mhz) return GAPRO_ERR_BAD_ARG;
+  const int rc = mfma_peak(ctx, stream_, 0, iters, waves_per_simd, n_blocks, d_sink, out_tflops);
+  if (rc != GAPRO_OK) return rc;
+  double h[3] = {0.0, 0.0, 0.0};
+  GAPRO_HIP_CHECK(ctx, hipMemcpy(h, d_sink, sizeof(h), hipMemcpyDeviceToHost));
+  *out_shader_mhz = h[2] > 0.0 ? h[1] / h[2] * 100.0 : 0.0;
+  return GAPRO_OK;
+}
+
+static int mfma_peak(gapro_ctx* ctx, void* stream_, int32_t kind, int32_t iters, int32_t waves_per_simd,
+                     int32_t n_blocks, double* d_sink, double* out_tflops) {
   if (!ctx || !out_tflops || !d_sink || iters <= 0 || waves_per_simd <= 0 || waves_per_simd > 8 || kind < 0 || kind > 1)
     return GAPRO_ERR_BAD_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   hipEvent_t e0, e1;
   GAPRO_HIP_CHECK(ctx, hipEventCreate(&e0));
   GAPRO_HIP_CHECK(ctx, hipEventCreate(&e1));
-  const int blocks = ctx->n_cu * waves_per_simd;  // 256 threads = one wave per SIMD of a CU
+  const int blocks = n_blocks > 0 ? n_blocks : ctx->n_cu * waves_per_simd;  // 256 threads = one wave per SIMD of a CU
   auto launch = [&](int n) {
     if (kind == 0) hipLaunchKernelGGL(k_peak_f64, dim3(blocks), dim3(256), 0, stream, n, d_sink);
     else hipLaunchKernelGGL(k_peak_f32, dim3(blocks), dim3(256), 0, stream, n, d_sink);

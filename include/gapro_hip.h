@@ -396,6 +396,11 @@ int gapro_debug_stream(gapro_ctx* ctx, void* stream, int64_t n, const double* d_
  * The roofline peak the fit kernels are priced against (the local guide has no FP64 row). */
 int gapro_debug_mfma_peak(gapro_ctx* ctx, void* stream, int32_t kind, int32_t iters, int32_t waves_per_simd,
                           double* d_sink, double* out_tflops);
+/* The same FP64 loop on n_blocks workgroups (<= 0: every CU x waves_per_simd) with the shader clock it ran at:
+ * shader cycles (s_memtime) of one wave over the 100 MHz constant clock.  d_sink: three device doubles.  Shows what
+ * the matrix cores sustain when only a part of the chip is busy (tools/mfma_peak.py --clock). */
+int gapro_debug_mfma_clock(gapro_ctx* ctx, void* stream, int32_t iters, int32_t waves_per_simd, int32_t n_blocks,
+                           double* d_sink, double* out_tflops, double* out_shader_mhz);
 
 #ifdef __cplusplus
 }

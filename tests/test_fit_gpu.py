@@ -319,6 +319,20 @@ def test_fit_matches_oracle_with_deep_features_on_every_route(m1, m2, t, route):
     _compare(out, _oracle(feats, b1, b2, it, 50))
 
 
+@pytest.mark.parametrize("d,m1,m2,t", [(20, 250, 262, 30), (9, 300, 330, 17)])
+def test_cluster_kernel_with_other_feature_widths(d, m1, m2, t):
+    """Feature widths between the reference's two (8 < D < 32 takes the deep-feature gradient path with a partly
+    empty second 16-column tile; M not a multiple of the 4-row blocks of the kernel evaluation)."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    assert _lib.load().gapro_fit_route(m1 + m2, d) == 4
+    feats, b1, b2, it = make_gp_problem(90 + d, m1, m2, t, d, std=0.4)
+    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=50)[0]
+    _compare(out, _oracle(feats, b1, b2, it, 50))
+
+
 def test_fit_status_is_per_fit_and_a_failed_fit_does_not_touch_its_neighbours():
     """gapro_svgp_fit_batch reports a gapro_status per fit and never fails the batch: a fit with a NaN feature row is
     flagged, the other fits of the same launch are bit-identical to a launch without it."""

@@ -18,7 +18,7 @@ def measure(device=0, iters=20000):
     from gapro_amd._lib import Context
 
     ctx = Context.get(device)
-    sink = torch.zeros(1, dtype=torch.float64, device="cuda:%d" % device)
+    sink = torch.zeros(4, dtype=torch.float64, device="cuda:%d" % device)
     out = {}
     for kind, name in ((0, "f64_16x16x4"), (1, "f32_16x16x4")):
         best = 0.0
@@ -32,5 +32,27 @@ def measure(device=0, iters=20000):
     return out
 
 
+def clocks(device=0, iters=20000):
+    """FP64 MFMA rate and the s_memtime rate with 1/8 .. all of the wave slots of the benchmark filled (the dispatcher
+    spreads the workgroups over all CUs: 1/4 of them = one wave per SIMD everywhere).  On the boxes measured s_memtime
+    ticks at ~2.39 GHz whatever the load, so the 48 of 78.6 TFLOP/s is not a visible clock drop."""
+    import torch
+
+    from gapro_amd._lib import Context
+
+    ctx = Context.get(device)
+    sink = torch.zeros(4, dtype=torch.float64, device="cuda:%d" % device)
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    out = {}
+    for frac in (8, 4, 2, 1):
+        tf, mhz = C.c_double(), C.c_double()
+        ctx.check(ctx.lib.gapro_debug_mfma_clock(ctx.handle, None, iters, 4, 4 * n_cu // frac,
+                                                 C.c_void_p(sink.data_ptr()), C.byref(tf), C.byref(mhz)))
+        out["workgroups_%d" % (4 * n_cu // frac)] = {"tflops": round(tf.value, 2), "s_memtime_mhz": round(mhz.value, 1)}
+    return out
+
+
 if __name__ == "__main__":
     print(json.dumps(measure()))
+    if "--clock" in sys.argv:
+        print(json.dumps(clocks()))
