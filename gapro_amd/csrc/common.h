@@ -15,10 +15,12 @@ struct gapro_ctx {
   int n_cu = 0;
   std::string last_error;
   gapro_scene_header* h_header_pinned = nullptr;  // pinned staging for the blocking prepare call
-  // The fit kernels run on four library-owned streams ([0] staged / generic kernel, [1] strip kernel, [2] the
-  // small-fit strip kernel, [3] the cluster kernel: large fits spread over several CUs), so that they share the GPU.
-  hipStream_t fit_stream[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // The fit kernels run on five library-owned streams ([0] staged / generic kernel, [1] strip kernel, [2] the
+  // small-fit strip kernel, [3] the cluster kernel: large fits spread over several CUs, [4] the staged fits whose LDS
+  // fits a CU twice, when the launch also has larger ones), so that they share the GPU.
+  static constexpr int kFitStreams = 5;
+  hipStream_t fit_stream[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_join[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // cluster kernel: block table staging (pinned host + device) and the clusters' barrier counters, grown on demand
   void* h_cl_stage = nullptr;
   void* d_cl_stage = nullptr;

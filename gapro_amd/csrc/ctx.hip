@@ -32,7 +32,7 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
   // [2] carries the small fits: lowest priority, so that they fill what the larger fits leave (longest first)
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < gapro_ctx::kFitStreams; ++k)
     if (hipStreamCreateWithPriority(&ctx->fit_stream[k], hipStreamNonBlocking, k == 2 ? prio_least : prio_greatest) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) != hipSuccess) {
       gapro_ctx_destroy(ctx);
@@ -47,7 +47,7 @@ void gapro_ctx_destroy(gapro_ctx* ctx) {
   if (ctx->h_header_pinned) (void)hipHostFree(ctx->h_header_pinned);
   if (ctx->h_task_ring) (void)hipHostFree(ctx->h_task_ring);
   if (ctx->d_task_ring) (void)hipFree(ctx->d_task_ring);
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < gapro_ctx::kFitStreams; ++k) {
     if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     if (ctx->fit_stream[k]) (void)hipStreamDestroy(ctx->fit_stream[k]);
   }

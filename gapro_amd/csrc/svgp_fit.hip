@@ -2621,11 +2621,12 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // with the NEXT dispatch of `stream` under this runtime, which would serialise the kernels again).  Both
   // are joined back into `stream` with events.
   const bool own = !(route_flags & 2) && ctx->fit_stream[0] && ctx->fit_stream[1] && ctx->fit_stream[2] &&
-                   ctx->fit_stream[3];  // debug bit 1
+                   ctx->fit_stream[3] && ctx->fit_stream[4];  // debug bit 1
   hipStream_t s_staged = own ? ctx->fit_stream[0] : stream;
   hipStream_t s_strip = own ? ctx->fit_stream[1] : stream;
   hipStream_t s_small = own ? ctx->fit_stream[2] : stream;
   hipStream_t s_clus = own ? ctx->fit_stream[3] : stream;
+  hipStream_t s_staged2 = own ? ctx->fit_stream[4] : stream;
   gapro_fit_timing* tm = ctx->armed_timing;
   ctx->armed_timing = nullptr;
   if (tm) {
@@ -2664,14 +2665,46 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     gapro_launch_fit_large(s_staged, (int)large.size(), feat_dim, d_feats_spp, d_idx, d_descs, d_init_mean, *opt,
                            d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
   if (!staged.empty()) {
-    // fewer fits than CUs: every fit has a CU to itself anyway, so take the whole register file
-    auto kern = (int)staged.size() <= ctx->n_cu ? k_svgp_fit<2> : k_svgp_fit<kWavesPerSimd>;
-    if (max_lds > 48 * 1024)
-      GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)max_lds));
-    hipLaunchKernelGGL(kern, dim3((int)staged.size()), dim3(NT), (size_t)max_lds, s_staged, (int)staged.size(),
-                       (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size(), d_init_mean, *opt, d_workspace,
-                       d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+    // The dynamic LDS of a launch is its largest fit's, and beyond ~72 KiB (M_p > 256 at D = 6) a CU holds ONE
+    // workgroup whatever the registers allow: a launch with one such fit ran every staged fit one per CU.  So the
+    // staged fits go out as two launches side by side: those whose LDS fits a CU twice in the `<4>` build (128 VGPRs,
+    // two workgroups per CU: 17 % more fits/s at M <= 256 than one per CU), the larger ones in the `<2>` build (the
+    // whole register file, no spills).  Either part with fewer fits than CUs takes `<2>` as well.
+    const long long kTwice = 72 * 1024;
+    size_t nbig = 0;  // sorted by M, the LDS need grows with M
+    long long lds_big = 0, lds_rest = 0;
+    for (const gapro_fit_desc& d : staged) {
+      const long long b = staged_lds_bytes(d.m1 + d.m2, feat_dim);
+      if (b > kTwice && !(route_flags & 128)) {
+        ++nbig;
+        lds_big = std::max(lds_big, b);
+      } else {
+        lds_rest = std::max(lds_rest, b);
+      }
+    }
+    auto launch = [&](hipStream_t st, size_t first, size_t count, long long lds) -> int {
+      const bool one_per_cu = (int)count <= ctx->n_cu || lds > kTwice || (route_flags & 64);
+      auto kern = one_per_cu ? k_svgp_fit<2> : k_svgp_fit<kWavesPerSimd>;
+      if (lds > 48 * 1024)
+        GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kern, dim3((int)count), dim3(NT), (size_t)lds, st, (int)count, (int)feat_dim, d_feats_spp, d_idx,
+                         d_descs + large.size() + first, d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels,
+                         d_mu, d_var, d_fit_status, d_fit_loss);
+      return GAPRO_OK;
+    };
+    if (nbig > 0) {
+      const int rc = launch(s_staged, 0, nbig, lds_big);
+      if (rc != GAPRO_OK) return rc;
+    }
+    if (nbig < staged.size()) {
+      hipStream_t st = nbig > 0 ? s_staged2 : s_staged;
+      const int rc = launch(st, nbig, staged.size() - nbig, lds_rest);
+      if (rc != GAPRO_OK) return rc;
+      if (st != s_staged) {  // everything staged is finished once s_staged has passed this point
+        GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[4], st));
+        GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(s_staged, ctx->ev_join[4], 0));
+      }
+    }
   }
   if (tm && tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[1], s_staged));
   if (!strip.empty()) {
