@@ -1,10 +1,28 @@
 // Context management of libgapro_hip.so.
+#include <cstdlib>
+#include <cstdio>
 #include "common.h"
 
 
 extern "C" {
 
 int gapro_version(void) { return GAPRO_VERSION; }
+
+// stream priorities of the fit kernels; GAPRO_FIT_PRIO="a,b,c,d,e" (0 = greatest, 1 = middle, 2 = least) overrides
+static int fit_prio(int k, int least, int greatest) {
+  static int lvl[gapro_ctx::kFitStreams] = {0, 0, 2, 0, 0};
+  static bool init = false;
+  if (!init) {
+    init = true;
+    if (const char* e = getenv("GAPRO_FIT_PRIO")) {
+      int v[gapro_ctx::kFitStreams];
+      if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
+        for (int i = 0; i < gapro_ctx::kFitStreams; ++i) lvl[i] = v[i];
+    }
+  }
+  const int mid = (least + greatest) / 2;
+  return lvl[k] <= 0 ? greatest : lvl[k] == 1 ? mid : least;
+}
 
 int gapro_ctx_create(int device, gapro_ctx** out) {
   if (!out) return GAPRO_ERR_BAD_ARG;
@@ -33,7 +51,7 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   for (int k = 0; k < gapro_ctx::kFitStreams; ++k)
-    if (hipStreamCreateWithPriority(&ctx->fit_stream[k], hipStreamNonBlocking, k == 2 ? prio_least : prio_greatest) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&ctx->fit_stream[k], hipStreamNonBlocking, fit_prio(k, prio_least, prio_greatest)) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming) != hipSuccess) {
       gapro_ctx_destroy(ctx);
       return GAPRO_ERR_HIP;

@@ -2587,6 +2587,32 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   std::stable_sort(staged.begin(), staged.end(), by_cost);
   std::stable_sort(large.begin(), large.end(), by_cost);
   std::stable_sort(clus.begin(), clus.end(), by_cost);
+  // the staged fits whose LDS fits a CU twice and the larger ones are two launches (see below)
+  const long long kTwice = 72 * 1024;
+  size_t nbig = 0;  // sorted by M, the LDS need grows with M
+  long long lds_big = 0, lds_rest = 0;
+  for (const gapro_fit_desc& d : staged) {
+    const long long b = staged_lds_bytes(d.m1 + d.m2, feat_dim);
+    if (b > kTwice && !(route_flags & 128)) {
+      ++nbig;
+      lds_big = std::max(lds_big, b);
+    } else {
+      lds_rest = std::max(lds_rest, b);
+    }
+  }
+  // Workgroup b of a launch runs on XCD b % 8 (one slice of 32 CUs; the cluster kernel's same-XCD barrier relies on the
+  // same fact and checks it), so in longest-first order XCD 0 would get the largest fit of every group of eight and XCD
+  // 7 the smallest, in every kernel: at the end of a launch four XCDs sat idle for ~50 ms while the others still had
+  // their share of strip fits (tools/fit_timeline.py).  Every second group of eight is reversed.
+  auto serpentine = [](std::vector<gapro_fit_desc>& v, size_t lo, size_t hi) {
+    for (size_t g0 = lo + 8; g0 + 8 <= hi; g0 += 16) std::reverse(v.begin() + g0, v.begin() + g0 + 8);
+  };
+  if (!(route_flags & 512)) {
+    serpentine(strip, 0, strip.size());
+    serpentine(small, 0, small.size());
+    serpentine(staged, 0, nbig);
+    serpentine(staged, nbig, staged.size());
+  }
   std::vector<gapro_fit_desc> all(large);
   all.insert(all.end(), staged.begin(), staged.end());
   all.insert(all.end(), strip.begin(), strip.end());
@@ -2670,18 +2696,6 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     // staged fits go out as two launches side by side: those whose LDS fits a CU twice in the `<4>` build (128 VGPRs,
     // two workgroups per CU: 17 % more fits/s at M <= 256 than one per CU), the larger ones in the `<2>` build (the
     // whole register file, no spills).  Either part with fewer fits than CUs takes `<2>` as well.
-    const long long kTwice = 72 * 1024;
-    size_t nbig = 0;  // sorted by M, the LDS need grows with M
-    long long lds_big = 0, lds_rest = 0;
-    for (const gapro_fit_desc& d : staged) {
-      const long long b = staged_lds_bytes(d.m1 + d.m2, feat_dim);
-      if (b > kTwice && !(route_flags & 128)) {
-        ++nbig;
-        lds_big = std::max(lds_big, b);
-      } else {
-        lds_rest = std::max(lds_rest, b);
-      }
-    }
     auto launch = [&](hipStream_t st, size_t first, size_t count, long long lds) -> int {
       const bool one_per_cu = (int)count <= ctx->n_cu || lds > kTwice || (route_flags & 64);
       auto kern = one_per_cu ? k_svgp_fit<2> : k_svgp_fit<kWavesPerSimd>;

@@ -1810,20 +1810,35 @@ int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, co
   });
   ClBlock* hb = (ClBlock*)h_stage;
   int nb = 0;
+  // slot x of a window is XCD x: the window's clusters (largest first) go to the slots that carry the least work so
+  // far (M_p^3 per cluster), so that no XCD gets the largest cluster of every window
+  double load[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int w0 = 0; w0 < n; w0 += 8) {
     const int cnt = std::min(8, n - w0);
     const int Gw = fit_g[order[w0]];
+    int slot_fit[8], slot_ctl[8];
+    {
+      int slots[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+      std::stable_sort(slots, slots + 8, [&](int a, int b) { return load[a] < load[b]; });
+      for (int x = 0; x < 8; ++x) slot_fit[x] = -1;
+      for (int c = 0; c < cnt; ++c) {
+        const int fi = order[w0 + c];
+        slot_fit[slots[c]] = fi;
+        slot_ctl[slots[c]] = w0 + c;  // the cluster's barrier counter line
+        load[slots[c]] += (double)fit_mp[fi] * fit_mp[fi] * fit_mp[fi];
+      }
+    }
     for (int j = 0; j < Gw; ++j)
       for (int x = 0; x < 8; ++x) {
         ClBlock b;
         b.fit = -1; b.g = 0; b.G = 0; b.ctl = 0;
-        if (x < cnt) {
-          const int fi = order[w0 + x];
+        if (slot_fit[x] >= 0) {
+          const int fi = slot_fit[x];
           if (j < fit_g[fi]) {
             b.fit = fit_index[fi];
             b.g = j;
             b.G = fit_g[fi];
-            b.ctl = w0 + x;
+            b.ctl = slot_ctl[x];
           }
         }
         hb[nb++] = b;

@@ -126,8 +126,15 @@ def main():
         tc = 0.5 * (edges[b] + edges[b + 1])
         act = (st <= tc) & (en > tc)
         print("  %6.0f  " % tc + " ".join("%8d" % int(a[act & (a[:, 1] == r), 5].sum()) for r in sorted(names)))
-    # per-CU busy share (leaders only for cluster fits)
-    cu = a[:, 4].astype(int)
+    # workgroups per XCD (HW_REG_XCC_ID) at the bin centres: a kernel's workgroups go to the XCDs round-robin
+    xcd = (a[:, 4].astype(int) >> 16) & 15
+    print("  active workgroups per XCD (all kernels, leaders only for cluster fits):")
+    for b in range(args.bins):
+        tc = 0.5 * (edges[b] + edges[b + 1])
+        act = (st <= tc) & (en > tc)
+        print("  %6.0f  " % tc + " ".join("%4d" % int((act & (xcd == x)).sum()) for x in range(8)))
+    # per-CU busy share (leaders only for cluster fits); CU = (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID
+    cu = a[:, 4].astype(int) & 0xFFF00
     busy = []
     for c in np.unique(cu):
         k = cu == c
