@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--lib", default="libgapro_hip_prof.so", help="library file inside gapro_amd/; with the product "
                     "library (libgapro_hip.so) only the launch times by HIP events are printed (A/B runs)")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--no-raise", action="store_true", help="timing experiments that break the arithmetic")
     args = ap.parse_args()
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), args.lib)
     prof = "prof" in args.lib
@@ -66,11 +67,13 @@ def main():
     h_idx = np.concatenate(idx).astype(np.int32)
     pipe = Pipeline(device=0, training_iter=50)
     pipe.opt.reserved |= args.flags
+    if args.no_raise:
+        pipe.opt.psd_retries = 0
     pipe.profile_fit = True
     spans = []
     for rep in range(2 if prof else args.reps + 1):
         pipe.fit_events = []
-        res = pipe.fit_descs(feats, descs, n, h_idx, oo, keep_debug=prof)
+        res = pipe.fit_descs(feats, descs, n, h_idx, oo, keep_debug=prof, raise_on_failure=not args.no_raise)
         torch.cuda.synchronize()
         ev = pipe.fit_events[0].read()
         spans.append(ev[2])
@@ -135,6 +138,9 @@ def main():
         print("  %6.0f  " % tc + " ".join("%4d" % int((act & (xcd == x)).sum()) for x in range(8)))
     # per-CU busy share (leaders only for cluster fits); CU = (XCC_ID, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID
     cu = a[:, 4].astype(int) & 0xFFF00
+    print("  CUs with at least one workgroup at the bin centres (of %d seen in all): " % len(np.unique(cu)) + " ".join(
+        "%d" % len(np.unique(cu[(st <= 0.5 * (edges[b] + edges[b + 1])) & (en > 0.5 * (edges[b] + edges[b + 1]))]))
+        for b in range(args.bins)))
     busy = []
     for c in np.unique(cu):
         k = cu == c
