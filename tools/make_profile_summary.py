@@ -28,8 +28,12 @@ def counters(path):
 
 
 def mean_of(acc, key_substr, counter):
-    vals = [v for (k, c), vs in acc.items() if key_substr in k and c == counter for v in vs]
-    return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+    """Mean counter value per launch of the kernels matching key_substr; kernels with different names that match
+    (k_svgp_fit<2> and k_svgp_fit<4>: the two staged launches of one fit batch) are summed, each at its own mean."""
+    per = {k: vs for (k, c), vs in acc.items() if key_substr in k and c == counter and vs}
+    if not per:
+        return None, 0
+    return sum(sum(vs) / len(vs) for vs in per.values()), max(len(vs) for vs in per.values())
 
 
 def main():
