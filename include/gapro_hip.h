@@ -313,7 +313,11 @@ typedef struct {
                               * 2 = launch the fit kernels on the caller's stream (not the fit streams),
                               * 4 = no small-fit kernel (M_p <= 64 runs the 512-thread strip kernel),
                               * 8 = no cluster kernel (large fits stay on one workgroup),
-                              * 16 = the cluster kernel for every fit it can take (M_p >= 64, M_p % 32 == 0) */
+                              * 16 = the cluster kernel for every fit it can take (M_p >= 64, M_p % 32 == 0),
+                              * 32 = 64 x 64 wave tiles in the cluster kernel, 64 = the full-register build for every
+                              * staged launch, 128 = the staged fits as ONE launch (not split by their LDS need),
+                              * 256 = cluster barriers always with the L2 write-back, 512 = plain longest-first order
+                              * (no serpentine over the XCDs) -- A/B switches of tools/bench_fit.py / fit_timeline.py */
   int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive
                               *      pivot is repeated on K + psd_jitter 10^i I, i < psd_retries (psd_safe_cholesky,
                               *      reached from gaussian_process_utils.py:417); 0 = fail at once */
@@ -356,9 +360,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t f
                          float* d_mu, float* d_var, int32_t* d_fit_status, double* d_fit_loss);
 
 /* Which kernel gapro_svgp_fit_batch routes a fit of m = m1 + m2 inducing points to: 0 = strip-streaming
- * kernel (64 < M_p <= 128), 1 = LDS-staged kernel, 2 = generic kernel (working set beyond LDS), 3 = the
- * small-fit strip kernel (M_p <= 64: 256 threads per fit, two fits per CU), 4 = the cluster kernel (M_p > 384: one
- * fit spread over 2..32 workgroups with cluster barriers).  M_p = m padded to the MFMA tile. */
+ * kernel (64 < M_p <= 128), 1 = LDS-staged kernel (128 < M_p < 480 while Z and X fit the LDS: M_p <= 192 at
+ * feat_dim 32), 2 = generic kernel (feat_dim > 32), 3 = the small-fit strip kernel (M_p <= 64: 256 threads per fit,
+ * two fits per CU), 4 = the cluster kernel (M_p >= 480: one fit spread over 2..32 workgroups with cluster barriers;
+ * also, on one workgroup, every fit that fits neither LDS kernel).  M_p = m padded to the MFMA tile. */
 int gapro_fit_route(int32_t m, int32_t feat_dim);
 
 /* Optional device-side timing of one fit launch (bench.py's roofline figure).  gapro_svgp_fit_batch runs
