@@ -1236,12 +1236,17 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(2);
   };
-  // Column sums fused into the GEMM epilogues (Mp <= kFuseMaxMp): every 16x16 result tile leaves the
-  // partial sum of its 16 rows per column in part_x[tile_row][column]; summed later in tile order.
+  // Column sums fused into the GEMM epilogues: every 16x16 result tile leaves the partial sum of its 16 rows per
+  // column in part_x[tile_row][column]; summed later in tile order.  The partials live in LDS up to M_p = kFuseMaxMp
+  // and beyond it in the G_A slot of the workspace (free until the backward pass; 3/16 of a matrix): a separate pass
+  // over A and B (mean_var: two more matrix reads per step, 3 % of a step at M = 257 .. 464) is not needed.
   const bool fuse = Mp <= kFuseMaxMp;
   ldsd* part_m = scratch + kTileDoubles;       // sum_i m[i] A[i][n]   (later reused for G_m partials)
   ldsd* part_a = part_m + (Mp / 16) * Mp;      // sum_i A[i][n]^2
   ldsd* part_b = part_a + (Mp / 16) * Mp;      // sum_j B[j][n]^2
+  gd* gpart_m = f.mat[B_GA];
+  gd* gpart_a = gpart_m + (size_t)(Mp / 16) * Mp;
+  gd* gpart_b = gpart_a + (size_t)(Mp / 16) * Mp;
   // A = LI * KX (+ AT) and BMT = A^T LS (+ BM) over ncols columns; then mu (without c) and var
   auto forward_products = [&](int ncols, double s_, double jitter_) {
     const int nt = (ncols + TS - 1) / TS;
@@ -1250,7 +1255,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                        [=](int i, int n, const d4& v) {
                          store_tile(v, A, AT, Mp, i, n, tile);
-                         if (fuse) {
+                         {
                            const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                            double pm = 0.0, pa = 0.0;
 #pragma unroll
@@ -1263,8 +1268,13 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            pm += __shfl_xor(pm, 32, 64);
                            pa += __shfl_xor(pa, 32, 64);
                            if (lq == 0) {
-                             part_m[(i >> 4) * Mp + n + lr] = pm;
-                             part_a[(i >> 4) * Mp + n + lr] = pa;
+                             if (fuse) {
+                               part_m[(i >> 4) * Mp + n + lr] = pm;
+                               part_a[(i >> 4) * Mp + n + lr] = pa;
+                             } else {
+                               gpart_m[(size_t)(i >> 4) * Mp + n + lr] = pm;
+                               gpart_a[(size_t)(i >> 4) * Mp + n + lr] = pa;
+                             }
                            }
                          }
                        });
@@ -1274,7 +1284,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                        [=](int n, int j, const d4& v) {
                          store_tile(v, BMT, BM, Mp, n, j, tile);
-                         if (fuse) {
+                         {
                            const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
 #pragma unroll
                            for (int r = 0; r < 4; ++r) {
@@ -1283,26 +1293,33 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                              pb += __shfl_xor(pb, 2, 64);
                              pb += __shfl_xor(pb, 4, 64);
                              pb += __shfl_xor(pb, 8, 64);
-                             if (lr == 0) part_b[(j >> 4) * Mp + n + lq + 4 * r] = pb;
+                             if (lr == 0) {
+                               if (fuse) part_b[(j >> 4) * Mp + n + lq + 4 * r] = pb;
+                               else gpart_b[(size_t)(j >> 4) * Mp + n + lq + 4 * r] = pb;
+                             }
                            }
                          }
                        });
     __syncthreads();
-    if (fuse) {
-      for (int n = threadIdx.x; n < nt * TS; n += NT) {
-        double sm = 0.0, sa = 0.0, sb = 0.0;
+    for (int n = threadIdx.x; n < nt * TS; n += NT) {
+      double sm = 0.0, sa = 0.0, sb = 0.0;
+      if (fuse) {
         for (int tq = 0; tq < Mp / 16; ++tq) {
           sm += part_m[tq * Mp + n];
           sa += part_a[tq * Mp + n];
           sb += part_b[tq * Mp + n];
         }
-        f.vec[V_MU][n] = sm;
-        f.vec[V_VAR][n] = s_ + jitter_ + (sb - sa);
+      } else {
+        for (int tq = 0; tq < Mp / 16; ++tq) {
+          sm += gpart_m[(size_t)tq * Mp + n];
+          sa += gpart_a[(size_t)tq * Mp + n];
+          sb += gpart_b[(size_t)tq * Mp + n];
+        }
       }
-      __syncthreads();
-    } else {
-      mean_var(s_, jitter_, scratch);
+      f.vec[V_MU][n] = sm;
+      f.vec[V_VAR][n] = s_ + jitter_ + (sb - sa);
     }
+    __syncthreads();
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
