@@ -231,6 +231,11 @@ enum { ORD_ROWMAJOR = 0,   // equal ranges, or ranges shrinking with the tile ro
 // TRIM: the contraction index runs over inducing / training points; rows >= M of both operands are padding whose
 // products with every valid output vanish, so the range stops at M rounded up to the register block (M = 230 padded to
 // 256: 9 % fewer loads and MFMAs; valid outputs keep their bits, x + 0 * y = x).
+// TU = 4 (the staged kernel's full-register build, M_p >= 352): 64 x 64 wave tiles, i.e. 8 instead of 16 operand columns
+// fetched per 16 x 16 output block -- no fragment of these products is ever found in L2 (the hit rate does not move
+// with the tile order; 256 concurrent fits stream ~100 MB per Adam step each at M = 384, together the ~6.3 TB/s the
+// HBM delivers), so the bytes per block are what a product costs.  The extents are then given in 32 x 32 units and an
+// odd count leaves a last row / column of 32 x 32 tiles, dealt after the full ones.
 template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, bool TRIM = false, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
@@ -244,115 +249,61 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
   qscale = uni_ptr(qscale);
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
-  constexpr int TS = 16 * TU;
-  const int ntiles = lower_only ? mo_tiles * (mo_tiles + 1) / 2 : mo_tiles * no_tiles;
-  const int rounds = (ntiles + NW - 1) / NW;
-#pragma nounroll
-  for (int q = 0; q < rounds; ++q) {
-    const int t = q * NW + ((q & 1) ? NW - 1 - wave : wave);
-    if (t >= ntiles) continue;
-    int ti, tj;
-    if (lower_only) {
-      ti = 0;
-      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-      tj = t - ti * (ti + 1) / 2;
-    } else if (ORD == ORD_ROWS_DESC) {
-      ti = t / no_tiles;
-      tj = t - ti * no_tiles;
-      ti = mo_tiles - 1 - ti;
-    } else if (ORD == ORD_COLMAJOR) {
-      tj = t / mo_tiles;
-      ti = t - tj * mo_tiles;
-    } else if (ORD == ORD_SHELLS) {
-      int m = 0;
-      while ((m + 1) * (m + 1) <= t) ++m;
-      const int r = t - m * m;
-      ti = r <= m ? m : r - m - 1;
-      tj = r <= m ? r : m;
-    } else {
-      ti = t / no_tiles;
-      tj = t - ti * no_tiles;
-    }
-    const int i0 = ti * TS, j0 = tj * TS;
+  // One output tile of TV x TV blocks at (i0, j0).  KSV = k-steps (of 4) per register block; two blocks alternate (one
+  // in flight): 2 under the 128-VGPR budget of the LDS-staged kernel, 4 in the strip kernels' tail (256 VGPRs: +1.5 %;
+  // in the staged kernel -3..-6 %), 1 with the 128 accumulator registers of a 64 x 64 tile.  Everything between the
+  // issue of a block's loads and its MFMAs is straight-line code: s_waitcnt counts memory operations in issue order,
+  // and behind a join of two paths ("prefetch only if there is a next block") the compiler falls back to waiting for
+  // everything, i.e. for the block it has just requested -- no load would ever overlap an MFMA.  So the steady-state
+  // loop has no guard in its body (the last one or two blocks are peeled off behind it), and the column scale of the
+  // SCALE form is applied when a block is consumed, not when it is loaded (a multiply at load time is a wait at load
+  // time).
+  auto tile = [&](auto tv_tag, int i0, int j0) {
+    constexpr int TV = decltype(tv_tag)::value;
+    constexpr int KSV = TV >= 4 ? 1 : KS, KB = 4 * KSV;
     int klo, khi;
     kr(i0, j0, &klo, &khi);
     klo = uni(klo);
     khi = uni(khi);
     if (TRIM) {
-      const int kmax = uni((g_sh.f.M + 4 * KS - 1) / (4 * KS) * (4 * KS));
+      const int kmax = uni((g_sh.f.M + 7) / 8 * 8);  // a multiple of every KB in use but the strip tail's 16 (M_p there)
       khi = khi < kmax ? khi : kmax;
     }
-    d4 acc[TU][TU];
+    d4 acc[TV][TV];
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int u = 0; u < TV; ++u)
 #pragma unroll
-      for (int v = 0; v < TU; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int v = 0; v < TV; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
     const gd* pbase = P + (size_t)lq * ld + i0 + lr;
     const gd* qbase = Q + (size_t)lq * ld + j0 + lr;
-    // KS = k-steps (of 4) per register block; two blocks alternate (one in flight).  2 under the 128-VGPR budget of
-    // the LDS-staged kernel, 4 in the strip kernels' tail (256 VGPRs: +1.5 %; in the staged kernel -3..-6 %)
-    constexpr int KB = 4 * KS;
-    // Two register blocks alternate.  Everything between the issue of a block's loads and its MFMAs is straight-line
-    // code: s_waitcnt counts memory operations in issue order, and behind a join of two paths ("prefetch only if
-    // there is a next block") the compiler falls back to waiting for everything, i.e. for the block it has just
-    // requested -- no load would ever overlap an MFMA.  So the steady-state loop has no guard in its body (the last
-    // one or two blocks are peeled off behind it), and the column scale of the SCALE form is applied when a block
-    // is consumed, not when it is loaded (a multiply at load time is a wait at load time).
-    double a0[KS][TU], b0[KS][TU], a1[KS][TU], b1[KS][TU];
-    double s0[KS], s1[KS];
-    auto load_block = [&](int k, double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
+    double a0[KSV][TV], b0[KSV][TV], a1[KSV][TV], b1[KSV][TV];
+    double s0[KSV], s1[KSV];
+    auto load_block = [&](int k, double (&a)[KSV][TV], double (&b)[KSV][TV], double (&sc)[KSV]) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
+      for (int s = 0; s < KSV; ++s) {
         const gd* pr = pbase + (size_t)(k + 4 * s) * ld;
         const gd* qr = qbase + (size_t)(k + 4 * s) * ld;
 #pragma unroll
-        for (int u = 0; u < TU; ++u) a[s][u] = pr[16 * u];
+        for (int u = 0; u < TV; ++u) a[s][u] = pr[16 * u];
 #pragma unroll
-        for (int v = 0; v < TU; ++v) b[s][v] = qr[16 * v];
+        for (int v = 0; v < TV; ++v) b[s][v] = qr[16 * v];
         if (SCALE) sc[s] = qscale[k + 4 * s + lq];
       }
     };
-    auto mma_block = [&](double (&a)[KS][TU], double (&b)[KS][TU], double (&sc)[KS]) {
+    auto mma_block = [&](double (&a)[KSV][TV], double (&b)[KSV][TV], double (&sc)[KSV]) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        double bs[TU];
+      for (int s = 0; s < KSV; ++s) {
+        double bs[TV];
 #pragma unroll
-        for (int v = 0; v < TU; ++v) bs[v] = SCALE ? b[s][v] * sc[s] : b[s][v];
+        for (int v = 0; v < TV; ++v) bs[v] = SCALE ? b[s][v] * sc[s] : b[s][v];
 #pragma unroll
-        for (int u = 0; u < TU; ++u)
+        for (int u = 0; u < TV; ++u)
 #pragma unroll
-          for (int v = 0; v < TU; ++v)
+          for (int v = 0; v < TV; ++v)
             acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][u], bs[v], acc[u][v], 0, 0, 0);
       }
     };
-#if GAPRO_GEMM_RING > 2
-    // experiment: a ring of GAPRO_GEMM_RING register blocks, RING - 1 of them in flight.  Every load is
-    // unconditional (the block index is clamped to the last one, so the tail re-requests lines it already has) and
-    // the loop only has exit branches: the waits stay counted.
-    if (KS == 2 && klo < khi) {
-      constexpr int NB = GAPRO_GEMM_RING;
-      double ra[NB][KS][TU], rb[NB][KS][TU], rs[NB][KS];
-      const int nblk = (khi - klo) / KB;
-#pragma unroll
-      for (int i = 0; i < NB - 1; ++i) load_block(klo + (i < nblk ? i : nblk - 1) * KB, ra[i], rb[i], rs[i]);
-      int j = 0;
-#pragma nounroll
-      while (true) {
-        bool done = false;
-#pragma unroll
-        for (int sidx = 0; sidx < NB; ++sidx) {
-          if (!done) {
-            const int jn = j + NB - 1 < nblk ? j + NB - 1 : nblk - 1;
-            load_block(klo + jn * KB, ra[(sidx + NB - 1) % NB], rb[(sidx + NB - 1) % NB], rs[(sidx + NB - 1) % NB]);
-            mma_block(ra[sidx], rb[sidx], rs[sidx]);
-            if (++j == nblk) done = true;
-          }
-        }
-        if (done) break;
-      }
-    } else
-#endif
-    if (klo < khi) {  // khi - klo is a multiple of 16 (tile-aligned ranges), hence of KB
+    if (klo < khi) {  // khi - klo is a multiple of KB (tile-aligned ranges, trimmed to a multiple of 8)
       load_block(klo, a0, b0, s0);
       int k = klo;
 #pragma nounroll
@@ -371,9 +322,52 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
       }
     }
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int u = 0; u < TV; ++u)
 #pragma unroll
-      for (int v = 0; v < TU; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
+      for (int v = 0; v < TV; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
+  };
+  // full tiles: fo x fn of TU x TU blocks; TU = 4 takes its extents in 32 x 32 units and may leave a last row / column
+  constexpr int TE = TU >= 4 ? 2 : TU;  // blocks per side of an edge tile
+  const int fo = TU >= 4 ? mo_tiles / 2 : mo_tiles, fn = TU >= 4 ? no_tiles / 2 : no_tiles;
+  const int odd_i = TU >= 4 ? (mo_tiles & 1) : 0, odd_j = (TU >= 4 && !lower_only) ? (no_tiles & 1) : 0;
+  const int nfull = lower_only ? fo * (fo + 1) / 2 : fo * fn;
+  const int nrow = odd_i ? (lower_only ? mo_tiles : no_tiles) : 0;  // edge row: tiles (mo_tiles - 1, 0 ..) in 32-units
+  const int ncol = odd_j ? mo_tiles - odd_i : 0;                    // edge column: tiles (0 .., no_tiles - 1) above it
+  const int ntiles = nfull + nrow + ncol;
+  const int rounds = (ntiles + NW - 1) / NW;
+#pragma nounroll
+  for (int q = 0; q < rounds; ++q) {
+    const int t = q * NW + ((q & 1) ? NW - 1 - wave : wave);
+    if (t >= ntiles) continue;
+    if (t >= nfull) {  // 32 x 32 edge tiles (TU = 4 only), a quarter of a full tile's work each
+      const int e = t - nfull;
+      const int i32 = e < nrow ? mo_tiles - 1 : e - nrow, j32 = e < nrow ? e : no_tiles - 1;
+      tile(std::integral_constant<int, TE>{}, 32 * i32, 32 * j32);
+      continue;
+    }
+    int ti, tj;
+    if (lower_only) {
+      ti = 0;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      tj = t - ti * (ti + 1) / 2;
+    } else if (ORD == ORD_ROWS_DESC) {
+      ti = t / fn;
+      tj = t - ti * fn;
+      ti = fo - 1 - ti;
+    } else if (ORD == ORD_COLMAJOR) {
+      tj = t / fo;
+      ti = t - tj * fo;
+    } else if (ORD == ORD_SHELLS) {
+      int m = 0;
+      while ((m + 1) * (m + 1) <= t) ++m;
+      const int r = t - m * m;
+      ti = r <= m ? m : r - m - 1;
+      tj = r <= m ? r : m;
+    } else {
+      ti = t / fn;
+      tj = t - ti * fn;
+    }
+    tile(std::integral_constant<int, TU>{}, 16 * TU * ti, 16 * TU * tj);
   }
 }
 
@@ -1184,7 +1178,8 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   Shared& sh = g_sh;
   const int M = f.M, Mp = f.Mp, D = DC ? DC : f.D, T = f.T;
   constexpr int TS = 16 * TU;
-  const int mt = Mp / TS;
+  constexpr int TSB = TU >= 4 ? 32 : TS;  // unit of gemm_tn's extents (TU = 4: 32 x 32, see there)
+  const int mt = Mp / TSB;
   const double Nd = (double)M;  // num_data = train_y.numel() (gaussian_process_utils.py:414)
   const double jitter = opt.jitter;
   gd* LS = f.mat[B_LS];
@@ -1249,7 +1244,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   gd* gpart_b = gpart_a + (size_t)(Mp / 16) * Mp;
   // A = LI * KX (+ AT) and BMT = A^T LS (+ BM) over ncols columns; then mu (without c) and var
   auto forward_products = [&](int ncols, double s_, double jitter_) {
-    const int nt = (ncols + TS - 1) / TS;
+    const int nt = (ncols + TSB - 1) / TSB;
     // A[i][n] = sum_k U[k][i] KX[k][n],  U[k][i] = LI[i][k] = 0 for k > i
     gemm_tn<TU, false, 2, ORD_ROWS_DESC, true>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
@@ -1301,7 +1296,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                          }
                        });
     __syncthreads();
-    for (int n = threadIdx.x; n < nt * TS; n += NT) {
+    for (int n = threadIdx.x; n < nt * TSB; n += NT) {
       double sm = 0.0, sa = 0.0, sb = 0.0;
       if (fuse) {
         for (int tq = 0; tq < Mp / 16; ++tq) {
@@ -1650,7 +1645,9 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
 #define GAPRO_FIT_BODY(DM, DCV)                                                                              \
   do {                                                                                                       \
-    if (Mp >= 128 && Mp % 32 == 0)                                                                           \
+    if (WPS == 2 && DM == 6 && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096))                          \
+      fit_body<(WPS == 2 && DM == 6) ? 4 : 2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
+    else if (Mp >= 128 && Mp % 32 == 0)                                                                      \
       fit_body<2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
     else                                                                                                     \
       fit_body<1, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \

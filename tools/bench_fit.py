@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--cluster-all", action="store_true", help="the cluster kernel for every fit it can take (A/B)")
     ap.add_argument("--wide-tiles", action="store_true", help="64 x 64 wave tiles in the cluster kernel (A/B)")
     ap.add_argument("--full-barriers", action="store_true", help="cluster barriers always with the L2 write-back (A/B)")
+    ap.add_argument("--flags", type=int, default=0, help="further gapro_fit_options.reserved debug bits (A/B)")
     args = ap.parse_args()
     if args.profile:
         import os
@@ -130,6 +131,7 @@ def main():
         pipe.opt.reserved |= 32
     if args.full_barriers:
         pipe.opt.reserved |= 256
+    pipe.opt.reserved |= args.flags
     if args.mix:
         run_mix(pipe, args)
         return
