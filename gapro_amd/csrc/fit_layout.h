@@ -21,7 +21,7 @@ inline __host__ __device__ int round_up(int x, int a) { return (x + a - 1) / a *
 constexpr int kClMaxG = 32;                      // largest cluster (workgroups per fit)
 constexpr int kClThreads = 512;                  // threads per cluster workgroup
 constexpr int kClusterMinMp = 64;                // smallest padded M the cluster kernel takes (64-wide panels)
-constexpr int kClusterDefaultMinMp = 480;        // default routing threshold (gapro_cluster_min_mp)
+constexpr int kClusterDefaultMinMp = 512;        // default routing threshold (gapro_cluster_min_mp)
 // workgroups a fit of padded size Mp is spread over: the work grows with Mp^3 while a launch's other fits finish in
 // a fraction of a second, so the largest fits get the most CUs (powers of two; one CU up to Mp = 384)
 inline int cluster_g(int Mp, double unit = 384.0, bool pow2 = true) {

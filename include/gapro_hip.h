@@ -360,9 +360,9 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t f
                          float* d_mu, float* d_var, int32_t* d_fit_status, double* d_fit_loss);
 
 /* Which kernel gapro_svgp_fit_batch routes a fit of m = m1 + m2 inducing points to: 0 = strip-streaming
- * kernel (64 < M_p <= 128), 1 = LDS-staged kernel (128 < M_p < 480 while Z and X fit the LDS: M_p <= 192 at
+ * kernel (64 < M_p <= 128), 1 = LDS-staged kernel (128 < M_p < 512 while Z and X fit the LDS: M_p <= 192 at
  * feat_dim 32), 2 = generic kernel (feat_dim > 32), 3 = the small-fit strip kernel (M_p <= 64: 256 threads per fit,
- * two fits per CU), 4 = the cluster kernel (M_p >= 480: one fit spread over 2..32 workgroups with cluster barriers;
+ * two fits per CU), 4 = the cluster kernel (M_p >= 512: one fit spread over 4..32 workgroups with cluster barriers;
  * also, on one workgroup, every fit that fits neither LDS kernel).  M_p = m padded to the MFMA tile. */
 int gapro_fit_route(int32_t m, int32_t feat_dim);
 

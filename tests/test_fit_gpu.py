@@ -67,13 +67,15 @@ def test_fit_matches_oracle(m1, m2, t, d, iters):
     _compare(out, _oracle(feats, b1, b2, it, iters))
 
 
-@pytest.mark.parametrize("m1,m2,t,iters,route", [(150, 170, 60, 50, 1), (200, 210, 90, 50, 1), (230, 245, 40, 50, 4),
-                                                  (260, 270, 90, 50, 4), (340, 360, 50, 50, 4), (260, 270, 90, 5, 2)])
+@pytest.mark.parametrize("m1,m2,t,iters,route", [(150, 170, 60, 50, 1), (200, 210, 90, 50, 1), (230, 245, 40, 50, 1),
+                                                  (250, 262, 30, 50, 4), (260, 270, 90, 50, 4), (340, 360, 50, 50, 4),
+                                                  (260, 270, 90, 5, 2)])
 def test_fit_large_inducing_sets(m1, m2, t, iters, route):
-    """BASELINE configs[3] territory (large overlap regions): M_p = 320 and 416 run the LDS-staged kernel on one CU; from
-    M_p >= 480 on a fit is spread over 2, 4, 8, ... workgroups by the cluster kernel (route 4; here G = 2, 4, 8), checked
-    against the float64 oracle at the full 50 Adam steps; route 2 = the same fit kept on one workgroup in the generic
-    kernel (debug bit 3 of gapro_fit_options.reserved)."""
+    """BASELINE configs[3] territory (large overlap regions): M_p = 320, 416 and 480 run the LDS-staged kernel on one CU
+    (32 x 32 wave tiles at 320; 64 x 64 from 352 on, with a last row / column of 32 x 32 tiles at M_p = 416 and 480);
+    from M_p >= 512 on a fit is spread over 4, 8, ... workgroups by the cluster kernel (route 4), checked against the
+    float64 oracle at the full 50 Adam steps; route 2 = the same fit kept on one workgroup in the generic kernel (debug
+    bit 3 of gapro_fit_options.reserved)."""
     import torch
     from gapro_amd import _lib
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
@@ -297,7 +299,7 @@ def test_small_fit_kernel_and_strip_kernel_agree():
                                            (120, 136, 25, 2), (250, 262, 30, 4)])
 def test_fit_matches_oracle_with_deep_features_on_every_route(m1, m2, t, route):
     """D = 32 (--use_deepfeat) against the float64 oracle on each kernel: small-fit strip (3), 512-thread strip (0),
-    LDS-staged (1), the cluster kernel (4: on ONE workgroup for 192 < M_p < 480, where 2 x 32 x M_p staged point
+    LDS-staged (1), the cluster kernel (4: on ONE workgroup for 192 < M_p < 512, where 2 x 32 x M_p staged point
     coordinates do not fit the LDS beside the Cholesky block column, and over 4 at M_p = 512) and the generic kernel
     (2, debug bit 3), 50 Adam steps, the tolerances of D = 6."""
     import torch
