@@ -1350,8 +1350,9 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
     const double bc1 = 1.0 - pow(b1, (double)step), bc2s = sqrt(1.0 - pow(b2, (double)step));
     const double step_size = opt.lr / bc1;
-    // G_m = A g_mu (+ m / N, added with the Adam update below): fused into the G_A epilogue, or through AT
-    if (!fuse) weighted_colsum(AT, gmu, Mp, f.vec[V_GM], scratch);
+    // G_m = A g_mu (+ m / N, added with the Adam update below): fused into the G_A epilogue; the partials of the
+    // 16-column tiles go to LDS, or beyond M_p = kFuseMaxMp to the G_KX slot (written two phases later)
+    gd* gpart_g = f.mat[B_GKX];
     // G_A[i][n] = 2 g_v[n] sum_j LS[i][j] BM[j][n] + m[i] g_mu[n] - 2 A[i][n] g_v[n]
     gemm_tn<TU, false, 2, ORD_ROWS_DESC, true>(mt, mt, false, LST, BM, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
@@ -1364,25 +1365,28 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            const int i = i0 + lq + 4 * r;
                            const double a = A[(size_t)i * Mp + n];
                            GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
-                           if (fuse) {
-                             double pg = a * gmn;
-                             pg += __shfl_xor(pg, 1, 64);
-                             pg += __shfl_xor(pg, 2, 64);
-                             pg += __shfl_xor(pg, 4, 64);
-                             pg += __shfl_xor(pg, 8, 64);
-                             if (lr == 0) part_m[(n0 >> 4) * Mp + i] = pg;
+                           double pg = a * gmn;
+                           pg += __shfl_xor(pg, 1, 64);
+                           pg += __shfl_xor(pg, 2, 64);
+                           pg += __shfl_xor(pg, 4, 64);
+                           pg += __shfl_xor(pg, 8, 64);
+                           if (lr == 0) {
+                             if (fuse) part_m[(n0 >> 4) * Mp + i] = pg;
+                             else gpart_g[(size_t)(n0 >> 4) * Mp + i] = pg;
                            }
                          }
                        });
     __syncthreads();
-    if (fuse) {
-      for (int i = threadIdx.x; i < Mp; i += NT) {
-        double sg = 0.0;
+    for (int i = threadIdx.x; i < Mp; i += NT) {
+      double sg = 0.0;
+      if (fuse) {
         for (int tq = 0; tq < Mp / 16; ++tq) sg += part_m[tq * Mp + i];
-        f.vec[V_GM][i] = sg;
+      } else {
+        for (int tq = 0; tq < Mp / 16; ++tq) sg += gpart_g[(size_t)tq * Mp + i];
       }
-      __syncthreads();
+      f.vec[V_GM][i] = sg;
     }
+    __syncthreads();
     stamp(7);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL', Adam on LS fused in the epilogue
     gemm_tn<TU, true, 2, ORD_ROWMAJOR, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
