@@ -413,20 +413,24 @@ class Pipeline:
         var f32[S]) as device tensors (same lengths as the reference returns)."""
         return self._finish(self._start(jobs, keep_debug))
 
+    kSlots = 3  # pipeline streams = slots of per-batch buffers (see _stream_batches)
+
+    def _ensure_streams(self):
+        if not hasattr(self, "_streams"):
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(self.kSlots)]
+            for st in self._streams:
+                self._ws.setdefault("s%x" % int(st.cuda_stream), None)
+
     def run_pipelined(self, batches: Sequence[Sequence[SceneJob]]):
         """Several batches back to back, software-pipelined.  The fit workgroups fill every CU for the whole
         launch and the short partition / broadcast kernels cannot be dispatched beside them (measured: they
-        wait for the launch to drain, whatever the stream priorities), so the order is built around that:
+        wait until CUs drain, whatever the stream priorities), so the order is built around that (_stream_batches):
 
-            partition(i+1) on the idle GPU -> launch fit(i) -> while it runs, on the host: schedule(i+1),
+            partition(i+1) in the tail of fit(i-1) -> launch fit(i) -> while it runs, on the host: schedule(i+1),
             merge(i-1); broadcast(i-1) is enqueued without waiting for it
 
-        Only the partition kernels (and their two host round trips) are left between two fit launches.
         Same results as run() batch by batch."""
-        if not hasattr(self, "_streams"):
-            self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-            for st in self._streams:
-                self._ws.setdefault("s%x" % int(st.cuda_stream), None)
+        self._ensure_streams()
         outs = []
         # inputs produced on the caller's stream are ordered before both pipeline streams ONCE: an event on
         # the (legacy default) stream recorded per batch would also wait for every blocking stream
@@ -456,26 +460,37 @@ class Pipeline:
         """run_pipelined for an ITERATOR of batches (e.g. a dataset being read from disk): yields the outputs of
         every batch, in order, one batch behind the one being launched.  The consumer may use the yielded
         tensors on the current stream right away (they are ordered after the pipeline's streams)."""
-        if not hasattr(self, "_streams"):
-            self._streams = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-            for st in self._streams:
-                self._ws.setdefault("s%x" % int(st.cuda_stream), None)
+        self._ensure_streams()
         ready = torch.cuda.current_stream(self.device).record_event()
         for st in self._streams:
             st.wait_event(ready)
         for i, out in enumerate(self._stream_batches(iter(batches))):
-            torch.cuda.current_stream(self.device).wait_stream(self._streams[i % 2])
+            torch.cuda.current_stream(self.device).wait_stream(self._streams[i % self.kSlots])
             yield out
 
     def _stream_batches(self, it):
-        """The software pipeline of run_pipelined / run_stream over an iterator (lookahead of one batch)."""
-        def on(i, fn, *a):
-            with torch.cuda.stream(self._streams[i % 2]):
+        """The software pipeline of run_pipelined / run_stream over an iterator (lookahead of one batch).
+
+        Batch k lives on stream / buffer slot k % kSlots.  Iteration i, entered while fit(i-1) runs:
+            partition(i+1)   the host blocks on its two round trips; the kernels cannot be dispatched beside a fit that
+                             holds every CU: by the host-side trace (bench.py --trace) they complete when the last
+                             workgroups of fit(i-1) end, also on a stream that is not ordered behind that fit (three
+                             slots; with two, batch i+1 shared the stream of batch i-1, which gapro_svgp_fit_batch
+                             joins its kernels back into) and with more hardware queues (GPU_MAX_HW_QUEUES = 8 / 16:
+                             slower); ~10 ms of partition kernels and round trips stay between two fits
+            launch fit(i)
+            pull batch i+2, schedule(i+1), finish(i-1): host work while fit(i) runs
+        Queueing fit(i+1) behind fit(i) instead (two fits in flight, five slots) starves the partition kernels until
+        BOTH have drained: measured, 64 ms of idle GPU every second step, 287 vs 300 scenes/s."""
+        S = self.kSlots
+
+        def on(k, fn, *a):
+            with torch.cuda.stream(self._streams[k % S]):
                 return fn(*a)
 
-        # a batch is pulled from the iterator under the pipeline stream that will process it (batch k -> stream
-        # k % 2): whatever device work building its jobs enqueues (a dtype cast, .contiguous() of a strided input in
-        # make_job) is then ordered before its partition kernels, for every batch and not only the first
+        # a batch is pulled from the iterator under the pipeline stream that will process it: whatever device work
+        # building its jobs enqueues (a dtype cast, .contiguous() of a strided input in make_job) is then ordered
+        # before its partition kernels, for every batch and not only the first
         cur = on(0, next, it, None)
         if cur is None:
             return
@@ -490,7 +505,7 @@ class Pipeline:
             # everything below is host work that runs while the fit just launched occupies the GPU: fetching the
             # batch after next from the iterator (building jobs, reading / uploading scenes), the schedule of the
             # next batch, the merge of the previous one
-            nxt = on(i, next, it, None) if nxt is not None else None  # batch i + 2 -> stream i % 2
+            nxt = on(i + 2, next, it, None) if nxt is not None else None
             if nxt_state is not None:
                 on(i + 1, self._schedule_all, nxt_state)
             if prev_state is not None:
