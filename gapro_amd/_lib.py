@@ -117,6 +117,7 @@ SIGNATURES = {
     "gapro_fit_timing_destroy": (None, [_P]),
     "gapro_fit_timing_arm": (C.c_int, [_P, _P]),
     "gapro_fit_timing_read": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "gapro_fit_timing_offsets": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "gapro_debug_stream": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
     "gapro_debug_mfma_peak": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),

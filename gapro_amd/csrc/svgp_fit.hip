@@ -2840,6 +2840,31 @@ int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5) {
   return GAPRO_OK;
 }
 
+int gapro_fit_timing_offsets(gapro_ctx* ctx, gapro_fit_timing* ref, gapro_fit_timing* t, float* out_ms2) {
+  if (!ctx || !ref || !t || !out_ms2) return GAPRO_ERR_BAD_ARG;
+  out_ms2[0] = out_ms2[1] = 0.f;
+  int rk = -1;
+  for (int k = 0; k < 4 && rk < 0; ++k)
+    if (ref->used[k]) rk = k;
+  if (rk < 0) return GAPRO_OK;
+  GAPRO_HIP_CHECK(ctx, hipEventSynchronize(ref->ev[2 * rk]));
+  bool any = false;
+  float lo = 0.f, hi = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    if (!t->used[k]) continue;
+    float a = 0.f, b = 0.f;
+    GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[2 * k + 1]));
+    GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&a, ref->ev[2 * rk], t->ev[2 * k]));
+    GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&b, ref->ev[2 * rk], t->ev[2 * k + 1]));
+    lo = (!any || a < lo) ? a : lo;
+    hi = (!any || b > hi) ? b : hi;
+    any = true;
+  }
+  out_ms2[0] = lo;
+  out_ms2[1] = hi;
+  return GAPRO_OK;
+}
+
 // Debug: C = P^T Q for 16-column operands with K rows (K % 4 == 0); checks the MFMA lane maps.
 int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream_, const double* d_P, const double* d_Q, double* d_C, int32_t K) {
   if (!ctx || !d_P || !d_Q || !d_C || K <= 0 || (K & 3)) return GAPRO_ERR_BAD_ARG;

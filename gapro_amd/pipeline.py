@@ -178,9 +178,24 @@ class FitTiming:
             out = (C.c_float * 5)()
             self.ctx.check(self.ctx.lib.gapro_fit_timing_read(self.ctx.handle, self.handle, out))
             self.ms = (float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]))
+        return self.ms
+
+    def offsets(self, ref):
+        """(first kernel start, last kernel end) of this launch in ms after the start of launch `ref`."""
+        out = (C.c_float * 2)()
+        self.ctx.check(self.ctx.lib.gapro_fit_timing_offsets(self.ctx.handle, ref.handle, self.handle, out))
+        return float(out[0]), float(out[1])
+
+    def close(self):
+        if self.handle is not None:
             self.ctx.lib.gapro_fit_timing_destroy(self.handle)
             self.handle = None
-        return self.ms
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 class Pipeline:

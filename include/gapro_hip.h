@@ -377,6 +377,11 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out);
 void gapro_fit_timing_destroy(gapro_fit_timing* t);
 int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t);
 int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5);
+/* Where launch t lies on the time axis of launch ref: out_ms2 = {first kernel start, last kernel end} of t in ms after
+ * the start event of ref's first kernel.  Consecutive launches of a pipeline overlap (the next one is enqueued while
+ * the tail of the previous one runs, and a start event fires when its stream reaches it, not when the kernel gets
+ * CUs): bench.py counts the overlapped time once when it averages launch durations.  Blocks until t has finished. */
+int gapro_fit_timing_offsets(gapro_ctx* ctx, gapro_fit_timing* ref, gapro_fit_timing* t, float* out_ms2);
 
 /* ------------------------------------------------------------------------------------------
  * Debug / test entry points (not needed by a caller of the path).
