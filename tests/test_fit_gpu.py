@@ -454,3 +454,35 @@ def test_mixed_precision_mode_tracks_the_oracles_restatement_of_the_reference_sp
     # (b): the same class as the restatement -- both are rounding noise amplified by Adam, not a fixed offset
     assert e_kernel < max(10 * e_oracle, 0.1), (e_kernel, e_oracle)
     assert np.max(np.abs(k50[0] - p64)) < max(10 * float(np.max(np.abs(pm - p64))), 0.1)
+
+
+def test_fit_timing_spans_and_offsets_of_two_launches():
+    """gapro_fit_timing: the device-side duration of a launch (HIP events on the library's own streams) and where a
+    second launch lies on the time axis of the first -- what bench.py's roofline figure is made of."""
+    import torch
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.gen_ps_utils import _pipeline
+    from gapro_amd.synth import make_gp_problem
+
+    parts, probs, base = [], [], 0
+    for i, (m1, m2, t) in enumerate([(20, 25, 9), (60, 50, 11), (90, 100, 7)]):
+        f, b1, b2, it = make_gp_problem(900 + i, m1, m2, t, 6)
+        parts.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(parts)
+    pipe = _pipeline(torch.device("cuda", 0), 10)
+    pipe.profile_fit, pipe.fit_events = True, []
+    try:
+        fit_gp_spp_batch(feats, probs, training_iter=10)
+        fit_gp_spp_batch(feats, probs, training_iter=10)
+        a, b = pipe.fit_events[-2:]
+        ms_a, ms_b = a.read(), b.read()
+        assert ms_a[2] > 0 and ms_b[2] > 0 and ms_a[4] == 0  # no cluster kernel in these launches
+        assert ms_a[2] >= max(ms_a[0], ms_a[1], ms_a[3]) - 1e-3  # first start -> last end covers every kernel
+        lo_a, hi_a = a.offsets(a)
+        lo_b, hi_b = b.offsets(a)
+        assert abs(lo_a) < 1e-3 and abs((hi_a - lo_a) - ms_a[2]) < 0.05
+        assert lo_b >= hi_a - 0.05 and abs((hi_b - lo_b) - ms_b[2]) < 0.05  # the second launch was issued after the first
+    finally:
+        pipe.profile_fit, pipe.fit_events = False, []
