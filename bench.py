@@ -362,21 +362,25 @@ def run_workload(args, pipe, dev, rank, world, workload, B, distinct, steps, war
                 n_distinct=n_distinct, trace=pipe.trace, stage_times=dict(pipe.stage_times))
 
 
+def union_length(intervals):
+    """Total length of the union of [lo, hi] intervals (time in which at least one launch was in flight)."""
+    total, cur_lo, cur_hi = 0.0, None, None
+    for lo, hi in sorted(intervals):
+        if cur_hi is None or lo > cur_hi:
+            total += (cur_hi - cur_lo) if cur_hi is not None else 0.0
+            cur_lo, cur_hi = lo, hi
+        else:
+            cur_hi = max(cur_hi, hi)
+    return total + ((cur_hi - cur_lo) if cur_hi is not None else 0.0)
+
+
 def summarize(args, res, B, world, steps, workload, peak):
     """Bench keys of one measured workload."""
     fit_ms3, evs, elapsed = res["fit_ms3"], res["fit_events"], res["elapsed"]
     fit_ms = [t[2] for t in fit_ms3]
     fit_fl = [ev.flops for ev in evs]
     span_ms = float(np.mean(fit_ms)) if fit_ms else 0.0  # mean first start -> last end, overlaps counted twice
-    union = 0.0
-    cur_lo = cur_hi = None
-    for lo, hi in sorted(res.get("fit_iv") or []):
-        if cur_hi is None or lo > cur_hi:
-            union += (cur_hi - cur_lo) if cur_hi is not None else 0.0
-            cur_lo, cur_hi = lo, hi
-        else:
-            cur_hi = max(cur_hi, hi)
-    union += (cur_hi - cur_lo) if cur_hi is not None else 0.0
+    union = union_length(res.get("fit_iv") or [])
     avg_ms = union / len(fit_ms) if fit_ms and union > 0 else span_ms
     launch_tflops = (float(np.mean(fit_fl)) / (avg_ms * 1e-3) / 1e12) if avg_ms > 0 else 0.0
     # the kernel that holds the largest share of the launch's algorithmic FLOPs is the one priced in `roofline`

@@ -146,3 +146,18 @@ def test_claim_queue_hands_every_scene_to_exactly_one_worker(tmp_path):
     for g in got:  # each worker sees the common order: non-increasing cost
         c = [cost[f] for f in g]
         assert c == sorted(c, reverse=True)
+
+
+def test_bench_counts_overlapped_launch_time_once():
+    """bench.py's launch duration: union of the launches' [first start, last end] intervals / number of launches."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    assert bench.union_length([]) == 0.0
+    assert bench.union_length([(0.0, 10.0)]) == 10.0
+    assert bench.union_length([(0.0, 10.0), (12.0, 20.0)]) == 18.0           # a gap is not launch time
+    assert bench.union_length([(5.0, 20.0), (0.0, 10.0)]) == 20.0            # overlap counted once, any order
+    assert bench.union_length([(0.0, 30.0), (5.0, 10.0), (29.0, 31.0)]) == 31.0
