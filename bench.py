@@ -628,7 +628,7 @@ def main():
     return 0
 
 
-def driver_line(scenes=384, unique=24, procs=16):
+def driver_line(scenes=1536, unique=24, procs=16):
     """Disk- and PCIe-inclusive rate of the gen_ps driver (torch.load of ScanNet-layout .pth files, host
     preprocessing, upload, generation, torch.save of the 5-tuples) on a small on-disk dataset, as a child process
     (tools/bench_driver.py).  Never `value`: an extra key."""
