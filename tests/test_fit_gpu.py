@@ -220,6 +220,26 @@ def test_stale_cholesky_switch_matches_oracle():
     _compare(out, ref)
 
 
+@pytest.mark.parametrize("m1,m2,t,route", [(180, 190, 21, 1), (260, 275, 17, 4)])
+def test_stale_cholesky_and_initial_mean_on_the_large_fit_kernels(m1, m2, t, route):
+    """The reference's two unverifiable knobs (SURVEY B.3 U1: prediction with the last training step's Cholesky factor;
+    the 1e-3 randn initial variational mean) on the staged kernel's 64 x 64-tile path (M_p = 384) and on the cluster
+    kernel (M_p = 544 over 4 workgroups), against the oracle with the same switches."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+    from oracle import svgp_oracle as so
+
+    assert _lib.load().gapro_fit_route(m1 + m2, 6) == route
+    feats, b1, b2, it = make_gp_problem(300 + m1, m1, m2, t, 6)
+    im = 1e-3 * np.random.default_rng(5).standard_normal(m1 + m2)
+    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=50, eval_stale_chol=True, init_mean=[im])[0]
+    X = np.concatenate([feats[b1], feats[b2]]).astype(np.float64)
+    y = np.r_[-np.ones(m1), np.ones(m2)]
+    ref = so.svgp_fit_predict_autograd(X, y, feats[it].astype(np.float64), 50, "f64", eval_chol="stale", init_mean=im)
+    _compare(out, ref)
+
+
 def test_fit_rejects_empty_side():
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
 
