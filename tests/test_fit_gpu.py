@@ -376,6 +376,27 @@ def test_fit_status_is_per_fit_and_a_failed_fit_does_not_touch_its_neighbours():
             np.testing.assert_array_equal(a, b)
 
 
+def test_failed_cluster_fit_does_not_touch_its_neighbours():
+    """The same isolation on the cluster kernel (one fit over several workgroups, status reduced over the cluster): a
+    NaN feature row in one of three large fits flags that fit only; the others equal a launch without it, bit for bit."""
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    parts, probs, base = [], [], 0
+    for i, (m1, m2, t) in enumerate([(260, 270, 9), (300, 330, 5), (256, 262, 7), (40, 30, 6)]):
+        f, b1, b2, it = make_gp_problem(650 + i, m1, m2, t, 6)
+        parts.append(f.copy())
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    clean = fit_gp_spp_batch(np.concatenate(parts), probs, training_iter=8)
+    parts[1][17, 4] = np.nan
+    outs, status = fit_gp_spp_batch(np.concatenate(parts), probs, training_iter=8, return_status=True)
+    assert status[1] in (-4, -5) and (np.delete(status, 1) == 0).all()
+    for i in (0, 2, 3):
+        for a, b in zip(outs[i], clean[i]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_psd_safe_cholesky_jitter_retries():
     """gpytorch's psd_safe_cholesky: K_ZZ with duplicated inducing points and no variational jitter is
     singular, and whether a pivot of its factorisation comes out <= 0 is decided by the last bit.  Variations of the
