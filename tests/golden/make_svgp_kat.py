@@ -29,6 +29,8 @@ CASES = {
     "m100_d6": (903, 40, 60, 33, 6, 1.0),
     "m150_d6": (904, 70, 80, 100, 6, 1.0),
     "m256_d6": (905, 120, 136, 40, 6, 1.0),
+    "m370_d6": (909, 185, 185, 20, 6, 1.0),   # staged kernel, 64 x 64 wave tiles (M_p = 384)
+    "m530_d6": (910, 265, 265, 15, 6, 1.0),   # cluster kernel over 4 workgroups (M_p = 544)
     "m22_d32": (906, 10, 12, 75, 32, 0.3),
     "m90_d32": (907, 40, 50, 33, 32, 0.3),
     "m190_d32": (908, 90, 100, 20, 32, 0.3),
