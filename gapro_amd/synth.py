@@ -91,7 +91,11 @@ def make_scene(
     scan_name: Optional[str] = None,
     p_kinds=(0.30, 0.05, 0.02),
     p_wall: float = 0.0,
+    mesh_order: bool = False,
 ) -> Scene:
+    """mesh_order: vertices of a face in Z-order (consecutive vertices are spatial neighbours and mostly share a
+    superpoint, as in a reconstructed mesh) instead of the order they were sampled in (random within the face); the set
+    of points, their superpoints and every output of the generator are the same, only the vertex order differs."""
     rng = np.random.default_rng(seed)
     ex, ey, ez = rng.uniform(4.0, 8.0), rng.uniform(3.0, 7.0), rng.uniform(2.4, 3.0)
     K = int(rng.integers(10, 41)) if n_objects is None else int(n_objects)
@@ -160,6 +164,8 @@ def make_scene(
     all_xyz, all_rgb, all_sem, all_inst, all_spp = [], [], [], [], []
     spp_base = 0
 
+    all_face = []
+
     def add(pts, rgb0, sem, inst, pid, npatch):
         nonlocal spp_base
         all_xyz.append(pts)
@@ -167,6 +173,7 @@ def make_scene(
         all_sem.append(np.full(len(pts), float(sem)))
         all_inst.append(np.full(len(pts), float(inst)))
         all_spp.append(pid + spp_base)
+        all_face.append(np.full(len(pts), len(all_face), np.int64))
         spp_base += npatch
 
     # floor
@@ -223,6 +230,15 @@ def make_scene(
     inst = np.concatenate(all_inst, 0)
     spp = np.concatenate(all_spp, 0)
 
+    if mesh_order:  # Z-order within every face (10 bits per axis over the scene's extent), faces in generation order
+        lo, hi = xyz_al.min(0), xyz_al.max(0)
+        q = np.clip(((xyz_al - lo) / np.maximum(hi - lo, 1e-9) * 1023.0).astype(np.int64), 0, 1023)
+        code = np.zeros(len(xyz_al), np.int64)
+        for bit in range(10):
+            for ax in range(3):
+                code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+        o = np.lexsort((code, np.concatenate(all_face)))
+        xyz_al, rgb, sem, inst, spp = xyz_al[o], rgb[o], sem[o], inst[o], spp[o]
     # shuffle vertex order a little (mesh order is locally coherent, not sorted by patch)
     N = xyz_al.shape[0]
     blk = 256
