@@ -36,6 +36,7 @@
 
 #include "common.h"
 #include "fit_layout.h"
+#include "mfma64.h"
 
 void gapro_launch_fit_large(hipStream_t stream, int n_fits, int feat_dim, const float* d_feats_spp, const int* d_idx,
                             const gapro_fit_desc* d_descs, const double* d_init_mean, const gapro_fit_options& opt,
@@ -61,7 +62,7 @@ constexpr int kWavesPerSimd = GAPRO_WAVES_PER_SIMD;
 #define GAPRO_GEMM_RING 2
 #endif
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+using gapro_mfma::d4;
 // LDS pointers carry their address space explicitly: ds_read/ds_write instead of flat accesses, and no
 // generic->local casts for the optimiser to trip over.
 typedef __attribute__((address_space(3))) double ldsd;
@@ -86,11 +87,21 @@ __constant__ double c_gh_w[10] = {0.4622436696006101,     0.28667550536283415,  
 // dynamic LDS of the staged kernel: Zt[D][Mp] | Pt[D][Mp] | scratch
 constexpr int kTileDoubles = NW * 16 * 17;  // per-wave transpose tiles at the start of the scratch
 constexpr int kFuseMaxMp = 128;            // up to this size column sums are fused into GEMM epilogues
+// workgroup-tiled products (gemm_wg, beyond kFuseMaxMp): operand chunks in LDS
+constexpr int kWgTile = 128;                  // output tile edge of the workgroup
+constexpr int kWgKC = 8;                      // k rows per chunk
+constexpr int kWgRow = kWgTile + 16;          // LDS row stride of a chunk (doubles): the two k rows a 32-lane group of a
+                                              // fragment read touches start 128 bytes apart modulo the 256-byte bank row
+constexpr int kWgStage = 2 * kWgKC * kWgRow;  // doubles per LDS stage: P chunk | Q chunk
+constexpr int kWgRingDoubles = 2 * kWgStage;  // two stages
 inline __host__ __device__ int part_doubles(int Mp) { return Mp <= kFuseMaxMp ? 3 * (Mp / 16) * Mp : 0; }
 inline __host__ __device__ int scratch_doubles(int Mp) {
   const int a = kRedSlots * NT;                   // cross-group reductions / quadrature partials
   const int b = Mp * 17 + 64 * 17;                // Cholesky block column (row stride 17) + slack
-  const int c = kTileDoubles + part_doubles(Mp);  // transpose tiles + per-tile-row column sums
+  // transpose tiles + per-tile-row column sums (M_p <= kFuseMaxMp), or the products' operand ring (beyond it; the
+  // transpose tiles then sit inside the ring's second stage, which is idle while a tile's epilogue runs)
+  static_assert(kTileDoubles <= kWgStage, "the transpose tiles alias one stage of the operand ring");
+  const int c = Mp <= kFuseMaxMp ? kTileDoubles + part_doubles(Mp) : kWgRingDoubles;
   int m = a > b ? a : b;
   return m > c ? m : c;
 }
@@ -368,6 +379,209 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
       tj = t - ti * fn;
     }
     tile(std::integral_constant<int, TU>{}, 16 * TU * ti, 16 * TU * tj);
+  }
+}
+
+// ---- TN-form MFMA product, workgroup-tiled through an LDS ring (round 3) ---------------------------------
+// The same contract as gemm_tn at TU = 1 -- extents in 16 x 16 blocks, kr(i0, j0) = the contraction range of the block
+// at (i0, j0), epi(i0, j0, block) per block, every block accumulated over ascending k in steps of 4 -- and therefore
+// the same bits.  What changes is where the operand fragments come from.  With one tile per wave fed from global
+// memory every wave fetches its own fragments: 4 FLOP per byte at 32 x 32, and the 256 .. 512 concurrent fits of a
+// launch, whose working sets (17 matrices each) hit neither L2 nor the Infinity Cache, move 6.3 TB/s at M = 256 -- the
+// staged kernel sat ON the HBM roof (profiles/r03_probe1.md).  Here the eight waves of the workgroup share one
+// 128 x 128 output tile: an 8-row chunk of both operands (8 KiB each) is fetched ONCE per workgroup, one 16-byte load
+// per thread and operand (wave w fetches row w: 1 KiB contiguous), held in registers for two iterations (the
+// prefetch distance), written to one of two LDS stages and read from there as MFMA fragments by every wave: 16 FLOP
+// per byte of global traffic.  One barrier per chunk.  Wave w owns the 32 x 64 piece at rows 32 r, columns 64 (w >> 2)
+// of the tile, r = w & 3 for the first four waves and 3 - (w & 3) for the others: waves w and w + 4 share a SIMD, so
+// with triangular operands every SIMD gets a long and a short contraction range.  A piece skips the chunks outside the
+// hull of its blocks' ranges (the extra rows inside the hull multiply structural zeros of a triangular operand: x + 0 y
+// = x, the bits stay).
+// LDS image of a chunk: row k at k * 128 doubles, and inside a row the element i at i ^ (16 (k & 1)): the two k rows
+// a 32-lane group of a fragment read touches land in different halves of the 256-byte bank row (conflict-free
+// ds_read_b64) without padding.
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) d2 lds_d2;
+typedef __attribute__((address_space(1))) d2 g_d2;
+
+template <bool SCALE, bool TRIM, int PF, typename KRange, typename Epi>
+__device__ __noinline__ void gemm_wg(int rows16, int cols16, bool lower_only, const gd* __restrict__ P,
+                                     const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+                                     Epi epi, ldsd* ring) {
+  static_assert(NT == 512 || !sizeof(Epi), "gemm_wg: eight waves, one k row of a chunk per wave");
+  static_assert(PF == 2 || PF == 4, "gemm_wg: register stages");
+  rows16 = uni(rows16);
+  cols16 = uni(cols16);
+  lower_only = uni((int)lower_only) != 0;
+  ld = uni(ld);
+  P = uni_ptr(P);
+  Q = uni_ptr(Q);
+  qscale = uni_ptr(qscale);
+  const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int rows = 16 * rows16, cols = 16 * cols16;
+  const int nti = (rows + kWgTile - 1) / kWgTile, ntj = (cols + kWgTile - 1) / kWgTile;
+  const int wi = wave < 4 ? wave : 7 - wave, wj = wave >> 2;
+  const int kmax = TRIM ? uni((g_sh.f.M + 7) / 8 * 8) : ld;
+  // loader: wave w moves k row w of a chunk, lane l the 16 bytes at columns 2 l, 2 l + 1 of the tile
+  const int lcol = 2 * lane;
+  const int lds_wr = wave * kWgRow + lcol;
+  // fragment reads: element (k = 4 s + lq, column c + lr) of a chunk; block, k-step and stage are immediate offsets
+  const int fa = lq * kWgRow + 32 * wi + lr;
+  const int fb = kWgKC * kWgRow + lq * kWgRow + 64 * wj + lr;
+#pragma nounroll
+  for (int ti = 0; ti < nti; ++ti) {
+#pragma nounroll
+    for (int tj = 0; tj < (lower_only ? ti + 1 : ntj); ++tj) {
+      const int I0 = kWgTile * ti, J0 = kWgTile * tj;
+      // contraction range of the workgroup tile = hull of its blocks' ranges; of this wave's piece likewise
+      int klo = 1 << 30, khi = 0, plo = 1 << 30, phi = 0;
+      unsigned on_mask = 0;  // bit 4 u + v: block (u, v) of this wave's piece is part of the output
+#pragma nounroll
+      for (int bi = 0; bi < kWgTile / 16; ++bi) {
+        const int ib = I0 + 16 * bi;
+        if (ib >= rows) break;
+#pragma nounroll
+        for (int bj = 0; bj < kWgTile / 16; ++bj) {
+          const int jb = J0 + 16 * bj;
+          if (jb >= cols) break;
+          if (lower_only && ib < jb) continue;
+          const bool mine = (bi >> 1) == wi && (bj >> 2) == wj;
+          if (mine) on_mask |= 1u << (4 * (bi & 1) + (bj & 3));  // also with an empty range: epi sees a zero block
+          int lo, hi;
+          kr(ib, jb, &lo, &hi);
+          hi = hi < kmax ? hi : kmax;
+          if (lo >= hi) continue;
+          klo = lo < klo ? lo : klo;
+          khi = hi > khi ? hi : khi;
+          if (mine) {
+            plo = lo < plo ? lo : plo;
+            phi = hi > phi ? hi : phi;
+          }
+        }
+      }
+      klo = uni(klo) & ~(kWgKC - 1);
+      khi = uni(khi);
+      plo = uni(plo) & ~(kWgKC - 1);
+      phi = uni(phi);
+      on_mask = (unsigned)uni((int)on_mask);
+      const int nch = klo < khi ? (khi - klo + kWgKC - 1) / kWgKC : 0;  // workgroup-uniform
+      d4 acc[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
+      if (nch > 0) {
+        const bool pin = I0 + lcol < ld, qin = J0 + lcol < ld;  // columns beyond the matrix: blocks that are dropped
+        const gd* pg = P + (size_t)wave * ld + (pin ? I0 + lcol : 0);
+        const gd* qg = Q + (size_t)wave * ld + (qin ? J0 + lcol : 0);
+        // Register stages: chunk n of the tile waits in stage n % PF from its request until it goes to LDS, PF - 1 .. PF
+        // iterations later (the chunk index is clamped to the last one, so that every load is unconditional and the
+        // waits stay counted).  An iteration cannot be shorter than the memory latency / PF: with one workgroup per CU
+        // and two stages the loop ran at the HBM latency, not at the matrix rate.  With SCALE the row's scale rides
+        // along (one address per wave) and is applied when the row goes to LDS: b * scale, the same product the
+        // per-wave form computes on every fragment.
+        d2 rp[PF], rq[PF];
+        double rs[PF];
+        auto gload = [&](int n, d2& p, d2& q, double& sc) {
+          n = n < nch ? n : nch - 1;
+          const size_t o = (size_t)(klo + kWgKC * n) * ld;
+#ifdef GAPRO_WG_NOLOAD  // timing experiment: no operand traffic (results are wrong)
+          p = (d2){1.0 + (double)o, 2.0};
+          q = (d2){0.5, 0.25};
+#else
+          p = *(const g_d2*)(pg + o);
+          q = *(const g_d2*)(qg + o);
+#endif
+          if (SCALE) sc = qscale[klo + kWgKC * n + wave];
+        };
+        auto lstore = [&](int stage, const d2& p, const d2& q, double sc) {
+          ldsd* base = ring + stage * kWgStage + lds_wr;
+          *(lds_d2*)base = p;
+          *(lds_d2*)(base + kWgKC * kWgRow) = SCALE ? (d2){q[0] * sc, q[1] * sc} : q;
+        };
+        // Fragments of one k-step: 2 of A, 4 of B.  Two sets alternate, software-pipelined across the barrier: the
+        // second step's set is requested before the first step's MFMAs, the NEXT chunk's first step right behind the
+        // barrier, under the second step's MFMAs -- the matrix pipe never waits for an LDS round trip, and a barrier
+        // costs what the waves' skew costs (tools/wgloop_peak.py: 47 -> 64 TFLOP/s for this loop with every CU running
+        // it).  Every block of a piece that has work is computed, also the ones whose result is dropped (columns
+        // beyond the matrix, blocks above the diagonal of a lower-triangular output): a guard per block costs two
+        // taken branches per MFMA, and a block's result depends on its own accumulator only.
+        double fa0[2], fb0[4], fa1[2], fb1[4];
+        auto rd = [&](int stage, int s, double (&a)[2], double (&b)[4]) {
+          const ldsd* st = ring + stage * kWgStage + 4 * s * kWgRow;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) b[v] = st[fb + 16 * v];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) a[u] = st[fa + 16 * u];
+        };
+        auto mm = [&](int k0, const double (&a)[2], const double (&b)[4]) {
+          if (k0 < plo || k0 >= phi) return;  // wave-uniform: the piece's own contraction range
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#ifdef GAPRO_WG_NOMFMA  // timing experiment: no matrix work (results are wrong)
+              acc[u][v][0] += a[u] * b[v];
+#else
+              acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+#endif
+        };
+        // chunk c: CUR = its LDS stage, SLOT = the register stage holding chunk c + 1, refilled with chunk c + 1 + PF
+        auto chunk = [&](auto cur_tag, auto slot_tag, int c) {
+          constexpr int CUR = decltype(cur_tag)::value, SLOT = decltype(slot_tag)::value;
+          const int k0 = klo + kWgKC * c;
+          lstore(CUR ^ 1, rp[SLOT], rq[SLOT], rs[SLOT]);
+          gload(c + 1 + PF, rp[SLOT], rq[SLOT], rs[SLOT]);
+          rd(CUR, 1, fa1, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(k0, fa0, fb0);
+          __builtin_amdgcn_sched_barrier(0);
+          __syncthreads();
+          rd(CUR ^ 1, 0, fa0, fb0);
+          __builtin_amdgcn_sched_barrier(0);
+          mm(k0, fa1, fb1);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0t = std::integral_constant<int, 0>;
+        using I1t = std::integral_constant<int, 1>;
+        using I2t = std::integral_constant<int, 2>;
+        using I3t = std::integral_constant<int, 3>;
+        // prologue: chunks 0 .. PF - 1 requested, chunk 0 on to LDS, chunk PF requested, first fragments read
+#pragma unroll
+        for (int n = 0; n < PF; ++n) gload(n, rp[n], rq[n], rs[n]);
+        lstore(0, rp[0], rq[0], rs[0]);
+        gload(PF, rp[0], rq[0], rs[0]);
+        __syncthreads();
+        rd(0, 0, fa0, fb0);
+        int c = 0;
+        if (PF == 2) {
+#pragma nounroll
+          for (; c + 1 < nch; c += 2) {  // the LDS stages and the register stages alternate by name
+            chunk(I0t{}, I1t{}, c);
+            chunk(I1t{}, I0t{}, c + 1);
+          }
+          if (c < nch) chunk(I0t{}, I1t{}, c);
+        } else {
+#pragma nounroll
+          for (; c + 3 < nch; c += 4) {
+            chunk(I0t{}, I1t{}, c);
+            chunk(I1t{}, I2t{}, c + 1);
+            chunk(I0t{}, I3t{}, c + 2);
+            chunk(I1t{}, I0t{}, c + 3);
+          }
+          if (c < nch) chunk(I0t{}, I1t{}, c);
+          if (c + 1 < nch) chunk(I1t{}, I2t{}, c + 1);
+          if (c + 2 < nch) chunk(I0t{}, I3t{}, c + 2);
+        }
+      }
+      // (no barrier here: what slower waves may still do with the ring is the read-ahead of a chunk that does not
+      // exist, and the next tile's prologue has a barrier between its first LDS store and everything else)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (on_mask & (1u << (4 * u + v))) epi(I0 + 32 * wi + 16 * u, J0 + 64 * wj + 16 * v, acc[u][v]);
+    }
   }
 }
 
@@ -1170,7 +1384,17 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
   }
 }
 
-template <int TU, int DMAX, int DC>
+// one product of the staged kernel: workgroup-tiled through LDS (WG; extents and ranges per 16 x 16 block) or one
+// tile per wave from global memory (gemm_tn)
+template <int WG, int TU, bool SCALE, int ORD, typename KRange, typename Epi>
+__device__ inline void product(int mo, int no, bool lower, const gd* __restrict__ P, const gd* __restrict__ Q, int ld,
+                               const gd* __restrict__ qs, KRange kr, Epi epi, ldsd* ring) {
+  if constexpr (WG != 0) gemm_wg<SCALE, true, WG>(mo, no, lower, P, Q, ld, qs, kr, epi, ring);
+  else gemm_tn<TU, SCALE, 2, ORD, true>(mo, no, lower, P, Q, ld, qs, kr, epi);
+}
+
+// WG: 0 = one tile per wave (gemm_tn), 2 / 4 = workgroup-tiled products with that many register stages (gemm_wg)
+template <int TU, int DMAX, int DC, int WG = 0>
 __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* scratch, const gapro_fit_desc& desc, float* __restrict__ o_probs, float* __restrict__ o_probs_new,
                          unsigned char* __restrict__ o_labels, float* __restrict__ o_mu, float* __restrict__ o_var,
                          double* loss_out) {
@@ -1195,7 +1419,11 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   gd* vm = f.vec[V_M];
   gd* gmu = f.vec[V_GMU];
   gd* gv = f.vec[V_GV];
-  ldsd* tile = scratch + (threadIdx.x >> 6) * 16 * 17;  // per-wave transpose tile
+  // per-wave transpose tile; with the workgroup-tiled products the operand ring starts the scratch and the tiles alias
+  // its second stage (gemm_wg: no stage is live while epilogues run, and a barrier precedes the next use of that stage)
+  ldsd* ring = scratch;
+  ldsd* tile = scratch + (WG ? kWgStage : 0) + (threadIdx.x >> 6) * 16 * 17;
+  static_assert(WG == 0 || TU == 1, "workgroup-tiled products take their extents and ranges per 16 x 16 block");
   double last_loss = 0.0;
 #ifdef GAPRO_PROFILE
   // diagnostic build only: per-phase wall-clock shares (100 MHz ticks), see tools/bench_fit.py --profile
@@ -1246,7 +1474,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   auto forward_products = [&](int ncols, double s_, double jitter_) {
     const int nt = (ncols + TSB - 1) / TSB;
     // A[i][n] = sum_k U[k][i] KX[k][n],  U[k][i] = LI[i][k] = 0 for k > i
-    gemm_tn<TU, false, 2, ORD_ROWS_DESC, true>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
+    product<WG, TU, false, ORD_ROWS_DESC>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                        [=](int i, int n, const d4& v) {
                          store_tile(v, A, AT, Mp, i, n, tile);
@@ -1272,10 +1500,10 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                              }
                            }
                          }
-                       });
+                       }, ring);
     __syncthreads();
     // BMT[n][j] = sum_i A[i][n] LS[i][j],  LS[i][j] = 0 for i < j
-    gemm_tn<TU, false, 2, ORD_COLMAJOR, true>(nt, mt, false, A, LS, Mp, nullptr,
+    product<WG, TU, false, ORD_COLMAJOR>(nt, mt, false, A, LS, Mp, nullptr,
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                        [=](int n, int j, const d4& v) {
                          store_tile(v, BMT, BM, Mp, n, j, tile);
@@ -1294,7 +1522,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                              }
                            }
                          }
-                       });
+                       }, ring);
     __syncthreads();
     for (int n = threadIdx.x; n < nt * TSB; n += NT) {
       double sm = 0.0, sa = 0.0, sb = 0.0;
@@ -1354,7 +1582,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     // 16-column tiles go to LDS, or beyond M_p = kFuseMaxMp to the G_KX slot (written two phases later)
     gd* gpart_g = f.mat[B_GKX];
     // G_A[i][n] = 2 g_v[n] sum_j LS[i][j] BM[j][n] + m[i] g_mu[n] - 2 A[i][n] g_v[n]
-    gemm_tn<TU, false, 2, ORD_ROWS_DESC, true>(mt, mt, false, LST, BM, Mp, nullptr,
+    product<WG, TU, false, ORD_ROWS_DESC>(mt, mt, false, LST, BM, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                        [=](int i0, int n0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -1375,7 +1603,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                              else gpart_g[(size_t)(n0 >> 4) * Mp + i] = pg;
                            }
                          }
-                       });
+                       }, ring);
     __syncthreads();
     for (int i = threadIdx.x; i < Mp; i += NT) {
       double sg = 0.0;
@@ -1389,7 +1617,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(7);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL', Adam on LS fused in the epilogue
-    gemm_tn<TU, true, 2, ORD_ROWMAJOR, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+    product<WG, TU, true, ORD_ROWMAJOR>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                       [=](int i0, int j0, const d4& v) {
                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                         const int j = j0 + lr;
@@ -1412,18 +1640,18 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                           newv[r] = lnew;
                         }
                         store_tile(newv, nullptr, LST, Mp, i0, j0, tile);  // LST[j][i]; zeros above the diagonal
-                      });
+                      }, ring);
     __syncthreads();
     stamp(8);
     // G_KX = LI^T G_A   (P = LI[k][i], non-zero for k >= i)
-    gemm_tn<TU, false, 2, ORD_ROWMAJOR, true>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
+    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                       [=](int i, int n, const d4& v) { store_tile(v, nullptr, GKXT, Mp, i, n, tile); });
+                       [=](int i, int n, const d4& v) { store_tile(v, nullptr, GKXT, Mp, i, n, tile); }, ring);
     __syncthreads();
     stamp(9);
     // G_L = -tril(G_KX A^T)  -> BM buffer (lower tiles; strict upper of diagonal tiles zeroed)
     gd* GL = BM;
-    gemm_tn<TU, false, 2, ORD_ROWMAJOR, true>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                        [=](int i0, int j0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
 #pragma unroll
@@ -1431,12 +1659,15 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            const int i = i0 + lq + 4 * r, j = j0 + lr;
                            GL[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
                          }
-                       });
+                       }, ring);
     __syncthreads();
     stamp(10);
     // Pm = Phi(tril(L^T G_L)) -> GA buffer   (k >= max(i0, j0) = i0 on lower tiles)
-    gd* Pm = GA;
-    gemm_tn<TU, false, 2, ORD_ROWMAJOR, true>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
+    // (workgroup-tiled products contract over the hull of a piece's block ranges: the rows T1 skips in Pm because Pm is
+    // lower triangular have to BE zero there, so Pm goes to a slot that nothing else writes -- G_LS never leaves the
+    // registers in this kernel -- instead of on top of G_A, whose upper blocks would still hold G_A)
+    gd* Pm = WG ? f.mat[B_GLS] : GA;
+    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                        [=](int i0, int j0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
@@ -1445,22 +1676,22 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            const int i = i0 + lq + 4 * r, j = j0 + lr;
                            Pm[(size_t)i * Mp + j] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
                          }
-                       });
+                       }, ring);
     __syncthreads();
     stamp(11);
     // T1 = LI^T Pm, stored transposed -> BMT buffer   (k >= max(i0, j0))
     gd* T1T = BMT;
-    gemm_tn<TU, false, 2, ORD_SHELLS, true>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+    product<WG, TU, false, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
                        [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
-                       [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
+                       [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); }, ring);
     __syncthreads();
     stamp(12);
     // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the A buffer   (k >= j0)
     gd* G = BM;
     gd* GT = A;
-    gemm_tn<TU, false, 2, ORD_COLMAJOR, true>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
+    product<WG, TU, false, ORD_COLMAJOR>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
-                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j, tile); });
+                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j, tile); }, ring);
     __syncthreads();
     stamp(13);
     // kernel gradients + Adam on Z
@@ -1649,7 +1880,11 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
 #define GAPRO_FIT_BODY(DM, DCV)                                                                              \
   do {                                                                                                       \
-    if (WPS == 2 && DM == 6 && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096))                          \
+    if (Mp > kFuseMaxMp && (opt.reserved & 8192) && !(WPS == 2 && (opt.reserved & 16384)))                   \
+      /* experiment bit 13: workgroup-tiled products (gemm_wg; bit-identical, 3x fewer operand bytes, 9 % slower  \
+         on the stream workload: DESIGN 6.0); bit 14 restricts it to the two-per-CU build */                 \
+      fit_body<1, DM, DCV, (WPS == 2 ? 4 : 2)>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
+    else if (WPS == 2 && DM == 6 && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096))                     \
       fit_body<(WPS == 2 && DM == 6) ? 4 : 2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
     else if (Mp >= 128 && Mp % 32 == 0)                                                                      \
       fit_body<2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
@@ -2458,6 +2693,12 @@ __global__ void k_mfma_selftest(const double* __restrict__ P, const double* __re
   for (int k = 0; k < K; k += 4)
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(k + lq) * 16 + lr], Q[(k + lq) * 16 + lr], acc, 0, 0, 0);
   for (int r = 0; r < 4; ++r) C[(lq + 4 * r) * 16 + lr] = acc[r];
+  if (K < 0) {  // never taken: keeps the four-block form of mfma64.h (an experiment of round 3) compiling
+    d4 t = (d4){0.0, 0.0, 0.0, 0.0};
+    gapro_mfma::mma16(P[lr], Q[lr], t);
+    t = gapro_mfma::unrotate(t);
+    C[lane] = t[0];
+  }
 }
 
 }  // namespace
@@ -2639,7 +2880,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   all.insert(all.end(), clus.begin(), clus.end());
   if (!clus.empty()) {  // staging of the cluster kernel: block table + one barrier counter line per fit
     const size_t need_stage = gapro_cluster_stage_bytes((int)clus.size());
-    if (need_stage > ctx->cl_stage_bytes) {
+    if (2 * need_stage > ctx->cl_stage_bytes) {  // cl_stage_bytes counts BOTH halves; a launch uses one of them
       if (ctx->h_cl_stage) (void)hipHostFree(ctx->h_cl_stage);
       if (ctx->d_cl_stage) (void)hipFree(ctx->d_cl_stage);
       ctx->h_cl_stage = ctx->d_cl_stage = nullptr;

@@ -14,6 +14,7 @@ torch is used only to own device memory and streams; all arithmetic happens in l
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -221,6 +222,8 @@ class Pipeline:
         self.opt.precision = 1 if precision == "mixed" else 0
         if cluster_all:
             self.opt.reserved |= 16
+        # A/B runs only: further debug bits of gapro_fit_options.reserved (include/gapro_hip.h) from the environment
+        self.opt.reserved |= int(os.environ.get("GAPRO_FIT_FLAGS", "0"), 0)
         self.init_mean_std = float(init_mean_std)
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap

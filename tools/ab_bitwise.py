@@ -31,7 +31,8 @@ def main():
     feats_l, probs, base = [], [], 0
     for i, (m1, m2, t) in enumerate([(1, 2, 1), (7, 9, 5), (15, 17, 40), (20, 28, 33), (31, 33, 64), (40, 39, 7),
                                      (45, 50, 90), (60, 52, 31), (64, 64, 100), (70, 74, 12), (80, 96, 50),
-                                     (130, 126, 20), (200, 190, 77)]):
+                                     (130, 126, 20), (200, 190, 77), (72, 70, 9), (100, 60, 300),
+                                     (88, 87, 40), (230, 250, 33), (301, 100, 450)]):
         f, b1, b2, it = make_gp_problem(300 + i, m1, m2, t, 6)
         feats_l.append(f)
         probs.append((b1 + base, b2 + base, it + base))

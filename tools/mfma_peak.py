@@ -18,9 +18,9 @@ def measure(device=0, iters=20000):
     from gapro_amd._lib import Context
 
     ctx = Context.get(device)
-    sink = torch.zeros(4, dtype=torch.float64, device="cuda:%d" % device)
+    sink = torch.ones(32, dtype=torch.float64, device="cuda:%d" % device)
     out = {}
-    for kind, name in ((0, "f64_16x16x4"), (1, "f32_16x16x4")):
+    for kind, name in ((0, "f64_16x16x4"), (1, "f32_16x16x4"), (2, "f64_4x4x4_4b"), (3, "f64_4x4x4_4b_tile")):
         best = 0.0
         for wps in (1, 2, 4):
             tf = C.c_double()
