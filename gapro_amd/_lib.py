@@ -16,7 +16,7 @@ GAPRO_OK = 0
 GAPRO_ERR_NOT_FINITE = -4
 GAPRO_ERR_CHOLESKY = -5
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "OOM", -3: "HIP", -4: "NOT_FINITE", -5: "CHOLESKY", -6: "SPP_RANGE",
-                -7: "WORKSPACE"}
+                -7: "WORKSPACE", -8: "TIMEOUT"}
 
 
 class GaproError(RuntimeError):

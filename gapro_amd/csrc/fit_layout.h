@@ -34,7 +34,12 @@ inline int cluster_g(int Mp, double unit = 384.0, bool pow2 = true) {
   }
   return g;
 }
-inline __host__ __device__ bool cluster_capable(int Mp) { return Mp >= kClusterMinMp && Mp % 32 == 0; }
+// largest padded M the cluster kernel takes: its pairwise-merge inverse keeps one record per pair of 64-wide panels in
+// LDS (kMaxPairs = 40 in svgp_fit_cluster.hip: ceil((M_p - 64) / 128) pairs at the first level)
+constexpr int kClusterMaxMp = 5120;
+inline __host__ __device__ bool cluster_capable(int Mp) {
+  return Mp >= kClusterMinMp && Mp % 32 == 0 && Mp <= kClusterMaxMp;
+}
 // a plane of the ordered two-stage column sums: sized for the largest cluster, so that the layout does not depend on
 // the cluster size policy
 inline __host__ __device__ long long cluster_plane_doubles(int Mp) {

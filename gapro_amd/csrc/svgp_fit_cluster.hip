@@ -67,6 +67,7 @@ struct Fit {
 };
 
 constexpr int kMaxPairs = 40;
+static_assert((kClusterMaxMp - 64 + 127) / 128 <= kMaxPairs, "pair table of the merge inverse");
 struct Shared {
   Fit f;
   int G, g;
@@ -82,6 +83,8 @@ struct Shared {
   double c, rho_s, rho_l, s, ell, inv_l2;
   double mc, vc, mrs, vrs, mrl, vrl;  // Adam moments of the scalars: every workgroup applies the same updates
   int status, chol_bad;
+  int dead;                        // a cluster barrier timed out (here or on another member): barriers fall through
+  unsigned long long bar_ticks;    // longest wait at one cluster barrier, 100 MHz ticks (0 = unbounded)
   int pr_lo[kMaxPairs], pr_mid[kMaxPairs], pr_hi[kMaxPairs], pr_t0[kMaxPairs + 1];
 #ifdef GAPRO_PROFILE
   unsigned long long prof[28];
@@ -160,10 +163,18 @@ __device__ inline int cl_waves() { return uni(g_sh.G * NW - g_sh.wave_off); }
 // behind a full barrier, never assumed from the block ids), the members share one L2: a store is visible to them once
 // it has been acknowledged (vmcnt(0)), and the write-back -- the expensive half of the barrier, it grows with the dirty
 // bytes of the whole XCD -- is skipped.  The acquire (buffer_inv sc1: drop this CU's stale L1 lines) stays.
+// The wait is BOUNDED: the launch is a plain one (a cooperative launch of thousands of workgroups of four kernels is not
+// an option), so that all G members of a cluster are resident together rests on in-order dispatch -- a cluster's
+// members are adjacent in block order and the kernel's occupancy is one workgroup per CU -- and on nothing starving a
+// member of its CU (CU masks, several processes on one GPU).  If that ever fails, a member that has polled for bar_ticks
+// (default 5 s, GAPRO_CLUSTER_BARRIER_TIMEOUT_MS) raises the cluster's give-up word (counter line, third word); every
+// member sees it at its next poll, marks itself dead and falls through this and all later barriers; the step loop
+// ends, and the fit reports GAPRO_ERR_TIMEOUT like a failed factorisation reports GAPRO_ERR_CHOLESKY: the host maps
+// it to the scene, the other fits of the launch are unaffected.
 __device__ __noinline__ void cbar() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
   __syncthreads();
-  if (g_sh.G > 1) {
+  if (g_sh.G > 1 && !g_sh.dead) {
     if (threadIdx.x == 0) {
       if (!g_sh.same_xcd) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -171,8 +182,22 @@ __device__ __noinline__ void cbar() {
       }
       const unsigned target = (unsigned)g_sh.G * (++g_sh.epoch);
       __hip_atomic_fetch_add(g_sh.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (__hip_atomic_load(g_sh.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+      unsigned polls = 0;
+      unsigned long long t0 = 0;
+      while (__hip_atomic_load(g_sh.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 255u) == 0) {  // every ~20 us of waiting: has somebody given up, or is it our turn to?
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          const bool gave_up = __hip_atomic_load(g_sh.count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+          if (gave_up || (g_sh.bar_ticks != 0 && now - t0 > g_sh.bar_ticks)) {
+            __hip_atomic_store(g_sh.count + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g_sh.dead = 1;
+            if (g_sh.status == GAPRO_OK) g_sh.status = GAPRO_ERR_TIMEOUT;
+            break;
+          }
+        }
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // buffer_inv sc1: drop this CU's stale L1 lines
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // holds the barrier below until the invalidate is done
     }
@@ -1301,7 +1326,8 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
   };
 
   for (int step = 1; step <= opt.training_iter; ++step) {
-    refresh_hypers();
+    refresh_hypers();  // (workgroup barriers inside: sh.dead below is read uniformly)
+    if (sh.dead) break;  // a cluster barrier timed out: nothing after it is synchronised, stop computing
     const double s = sh.s, ell = sh.ell, inv_l2 = sh.inv_l2, c = sh.c;
     // ------------------------------- forward -------------------------------
     factorize();
@@ -1664,9 +1690,12 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
                                                           float* __restrict__ o_probs, float* __restrict__ o_probs_new,
                                                           unsigned char* __restrict__ o_labels, float* __restrict__ o_mu,
                                                           float* __restrict__ o_var, int* __restrict__ o_status,
-                                                          double* __restrict__ o_loss) {
+                                                          double* __restrict__ o_loss, unsigned long long bar_ticks) {
   const ClBlock cb = blocks[blockIdx.x];
   if (cb.fit < 0) return;
+  // test bit 15 of gapro_fit_options.reserved: the last member of every cluster never arrives (as if it had not been
+  // given a CU) -- the others must time out and report GAPRO_ERR_TIMEOUT instead of hanging
+  if ((opt.reserved & 32768) && cb.G > 1 && cb.g == cb.G - 1) return;
   const gapro_fit_desc desc = descs[cb.fit];
   Shared& sh = g_sh;
   Fit& f = sh.f;
@@ -1703,6 +1732,8 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
     sh.mc = sh.vc = sh.mrs = sh.vrs = sh.mrl = sh.vrl = 0.0;
     sh.status = GAPRO_OK;
     sh.chol_bad = 0;
+    sh.dead = 0;
+    sh.bar_ticks = bar_ticks;
 #ifdef GAPRO_PROFILE
     for (int i = 0; i < 28; ++i) sh.prof[i] = 0;
     sh.t_last = wall_clock64();
@@ -1754,6 +1785,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
   __syncthreads();
   if (sh.g == 0 && threadIdx.x == 0) {
     int st = sh.status;
+    if (sh.dead) st = GAPRO_ERR_TIMEOUT;
     if (st == GAPRO_OK && !isfinite(o_loss[desc.slot]) && opt.training_iter > 0) st = GAPRO_ERR_NOT_FINITE;
     o_status[desc.slot] = st;
     f.scal[S_STATUS] = (double)st;
@@ -1844,11 +1876,18 @@ int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, co
         hb[nb++] = b;
       }
   }
+  // longest wait at one cluster barrier before the cluster gives up (cbar): 5 s unless the environment says otherwise
+  static long long timeout_ms = -1;
+  if (timeout_ms < 0) {
+    const char* e = getenv("GAPRO_CLUSTER_BARRIER_TIMEOUT_MS");
+    timeout_ms = e && atoll(e) >= 0 ? atoll(e) : 5000;
+  }
+  const unsigned long long bar_ticks = (unsigned long long)timeout_ms * 100000ull;  // wall_clock64: 100 MHz
   if (hipMemsetAsync(d_ctl, 0, (size_t)n * 128, stream) != hipSuccess) return GAPRO_ERR_HIP;
   if (hipMemcpyAsync(d_stage, h_stage, (size_t)nb * sizeof(ClBlock), hipMemcpyHostToDevice, stream) != hipSuccess)
     return GAPRO_ERR_HIP;
   hipLaunchKernelGGL(k_svgp_fit_cluster, dim3(nb), dim3(NT), 0, stream, (const ClBlock*)d_stage, feat_dim, d_feats_spp,
                      d_idx, d_descs, d_init_mean, opt, d_workspace, d_ctl, d_probs, d_probs_new, d_labels, d_mu, d_var,
-                     d_fit_status, d_fit_loss);
+                     d_fit_status, d_fit_loss, bar_ticks);
   return hipGetLastError() == hipSuccess ? GAPRO_OK : GAPRO_ERR_HIP;
 }

@@ -39,7 +39,10 @@ typedef enum {
   GAPRO_ERR_NOT_FINITE = -4,   /* a fit produced NaN/Inf */
   GAPRO_ERR_CHOLESKY = -5,     /* K_ZZ + jitter*I not positive definite */
   GAPRO_ERR_SPP_RANGE = -6,    /* superpoint id range exceeds the rank-table capacity */
-  GAPRO_ERR_WORKSPACE = -7     /* workspace too small */
+  GAPRO_ERR_WORKSPACE = -7,    /* workspace too small */
+  GAPRO_ERR_TIMEOUT = -8       /* a fit spread over several workgroups gave up at a cluster barrier: a member was
+                                * not resident within GAPRO_CLUSTER_BARRIER_TIMEOUT_MS (default 5000); per-fit
+                                * status like GAPRO_ERR_CHOLESKY, the launch's other fits are unaffected */
 } gapro_status;
 
 typedef struct gapro_ctx gapro_ctx;
@@ -317,7 +320,10 @@ typedef struct {
                               * 32 = 64 x 64 wave tiles in the cluster kernel, 64 = the full-register build for every
                               * staged launch, 128 = the staged fits as ONE launch (not split by their LDS need),
                               * 256 = cluster barriers always with the L2 write-back, 512 = plain longest-first order
-                              * (no serpentine over the XCDs) -- A/B switches of tools/bench_fit.py / fit_timeline.py */
+                              * (no serpentine over the XCDs), 8192 = workgroup-tiled products through LDS in the staged
+                              * kernel (round-3 experiment, bit-identical), 16384 = those in the two-per-CU build only,
+                              * 32768 = TEST: the last member of every cluster never arrives (cluster barrier timeout)
+                              * -- A/B switches of tools/bench_fit.py / fit_timeline.py */
   int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive
                               *      pivot is repeated on K + psd_jitter 10^i I, i < psd_retries (psd_safe_cholesky,
                               *      reached from gaussian_process_utils.py:417); 0 = fail at once */

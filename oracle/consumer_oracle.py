@@ -5,8 +5,9 @@ The expressions are the reference's own lines (no third-party code involved), ev
   count is clamped at 1), used as isbnet.py:387-389 does.
 * ``weighted_bce``      -- ISBNet/isbnet/model/criterion.py:287-288.
 * ``kl_to_gp``          -- ISBNet/isbnet/model/criterion.py:435-463.
-Parity unpinned against a reference run (torch_scatter / spconv are not installed here); the formulas are short
-enough to be checked by eye against the cited lines, and gradients are checked against torch autograd of these.
+Pinned (round 3): tests/golden/make_golden_consumer.py imports the reference's ``custom_scatter_mean`` and executes
+the two blocks of criterion.py in the build container (stubs only for the uninstalled torch_scatter / isbnet.ops);
+tests/test_consumer_golden.py holds these restatements to its fixtures, values and autograd gradients.
 """
 from __future__ import annotations
 

@@ -93,3 +93,53 @@ def test_generated_labels_feed_the_consumer_ops(golden):
     np.testing.assert_allclose(p_spp[inv_t].cpu().numpy(), prob.cpu().numpy(), rtol=1e-6)
     np.testing.assert_allclose(mu_spp[inv_t].cpu().numpy(), mu.cpu().numpy(), rtol=1e-6)
     np.testing.assert_allclose(var_spp[inv_t].cpu().numpy(), var.cpu().numpy(), rtol=1e-6)
+
+
+# ---- the same ops against outputs of the REFERENCE's own functions (tests/golden/make_golden_consumer.py) ----------
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def test_pool_matches_the_reference_custom_scatter_mean():
+    import torch
+    from gapro_amd.consumer_ops import pool_labels_to_superpoints
+
+    z = _golden("consumer_pool.npz")
+    got = pool_labels_to_superpoints(torch.from_numpy(z["prob"]).cuda(), torch.from_numpy(z["mu"]).cuda(),
+                                     torch.from_numpy(z["var"]).cuda(), torch.from_numpy(z["idx"]).cuda())
+    for a, k in zip(got, ("ref_prob", "ref_mu", "ref_var")):
+        assert len(a) == len(z[k])
+        # the kernel sums in float64 and rounds once; torch_scatter's CPU path sums float32 sequentially
+        np.testing.assert_allclose(a.cpu().numpy(), z[k], rtol=2e-6, atol=2e-6)
+
+
+def test_bce_matches_the_reference_lines():
+    import torch
+    from gapro_amd.consumer_ops import prob_weighted_bce_with_logits
+
+    z = _golden("consumer_losses.npz")
+    for k in range(int(z["bce_cases"])):
+        x = torch.from_numpy(z["bce%d_logits" % k]).cuda().requires_grad_(True)
+        got = prob_weighted_bce_with_logits(x, torch.from_numpy(z["bce%d_target" % k]).cuda(),
+                                            torch.from_numpy(z["bce%d_w" % k]).cuda())
+        got.backward()
+        np.testing.assert_allclose(float(got.detach()), float(z["bce%d_loss" % k]), rtol=3e-6)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), z["bce%d_grad" % k], rtol=3e-5, atol=1e-9)
+
+
+def test_kl_matches_the_reference_lines_every_branch():
+    import torch
+    from gapro_amd.consumer_ops import kl_to_gp_loss
+
+    z = _golden("consumer_losses.npz")
+    w = float(z["kl_weight"])
+    for k in range(int(z["kl_cases"])):
+        a = torch.from_numpy(z["kl%d_mu_p" % k]).cuda().requires_grad_(True)
+        b = torch.from_numpy(z["kl%d_lv_p" % k]).cuda().requires_grad_(True)
+        got = kl_to_gp_loss(a, b, torch.from_numpy(z["kl%d_mu_l" % k]).cuda(),
+                            torch.from_numpy(z["kl%d_var_l" % k]).cuda(), weight=w)
+        got.backward()
+        np.testing.assert_allclose(float(got.detach()), float(z["kl%d_loss" % k]), rtol=1e-5, atol=1e-30)
+        np.testing.assert_allclose(a.grad.cpu().numpy(), z["kl%d_gmu" % k], rtol=3e-5, atol=1e-9)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), z["kl%d_glv" % k], rtol=3e-5, atol=1e-9)

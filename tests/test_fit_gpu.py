@@ -527,3 +527,92 @@ def test_fit_timing_spans_and_offsets_of_two_launches():
         assert lo_b >= hi_a - 0.05 and abs((hi_b - lo_b) - ms_b[2]) < 0.05  # the second launch was issued after the first
     finally:
         pipe.profile_fit, pipe.fit_events = False, []
+
+
+_TIMEOUT_CHILD = r'''
+import sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+from gapro_amd.synth import make_gp_problem
+parts, probs, base = [], [], 0
+for i, (m1, m2, t) in enumerate([(265, 265, 9), (40, 30, 6), (300, 330, 5)]):
+    f, b1, b2, it = make_gp_problem(660 + i, m1, m2, t, 6)
+    parts.append(f); probs.append((b1 + base, b2 + base, it + base)); base += len(f)
+t0 = time.time()
+outs, status = fit_gp_spp_batch(np.concatenate(parts), probs, training_iter=5, return_status=True)
+dt = time.time() - t0
+print("STATUS", list(int(s) for s in status), "SECONDS %.2f" % dt, "FINITE", bool(np.isfinite(outs[1][3]).all()))
+'''
+
+
+def test_cluster_barrier_gives_up_instead_of_hanging():
+    """VERDICT r02 item 5: the cluster barrier is bounded.  With the test bit that keeps the last member of every
+    cluster from ever arriving (as if it had not been given a CU), the cluster fits of the launch report
+    GAPRO_ERR_TIMEOUT (-8) after the configured wait instead of spinning forever, and the launch's single-workgroup
+    fit is untouched.  In a child process: the timeout is read from the environment once per process."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAPRO_CLUSTER_BARRIER_TIMEOUT_MS="400", GAPRO_FIT_FLAGS=str(32768))
+    r = subprocess.run([sys.executable, "-c", _TIMEOUT_CHILD, root], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("STATUS")][0]
+    assert "STATUS [-8, 0, -8]" in line and "FINITE True" in line, line
+    assert float(line.split("SECONDS")[1].split()[0]) < 10.0, line
+
+
+def test_cluster_staging_buffer_grows_with_the_launch():
+    """ADVICE r02 (medium): the pinned / device block-table buffers hold two halves; a launch whose table needs up to
+    twice the previous one must reallocate (it used to write past its half).  One small cluster launch, then one with
+    ten 32-workgroup fits; both must come back clean, and a repeat of the first must reproduce its bits."""
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    f1, b1, b2, it = make_gp_problem(700, 265, 265, 7, 6)
+    first = fit_gp_spp_batch(f1, [(b1, b2, it)], training_iter=2)
+    parts, probs, base = [], [], 0
+    for i in range(10):
+        f, a, b, c = make_gp_problem(710 + i, 500, 500, 5, 6)  # M_p = 1024: 32 workgroups each
+        parts.append(f)
+        probs.append((a + base, b + base, c + base))
+        base += len(f)
+    outs, status = fit_gp_spp_batch(np.concatenate(parts), probs, training_iter=1, return_status=True)
+    assert (status == 0).all() and all(np.isfinite(o[4]).all() for o in outs)
+    again = fit_gp_spp_batch(f1, [(b1, b2, it)], training_iter=2)
+    for a, b in zip(first[0], again[0]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_workgroup_tiled_products_are_bit_identical_to_the_per_wave_products():
+    """Round-3 experiment (gapro_fit_options.reserved bit 13, DESIGN 6.0): the staged kernel's products through an LDS
+    ring shared by the workgroup accumulate every 16 x 16 block over the same k in the same order as the per-wave
+    products, so the outputs are the same bits -- for full tiles, ragged edges (M_p = 144, 176), lower-triangular
+    outputs, trimmed ranges and prediction batches larger than M_p."""
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    parts, probs, base = [], [], 0
+    for i, (m1, m2, t) in enumerate([(70, 74, 12), (80, 96, 50), (130, 126, 20), (100, 60, 300), (200, 190, 77),
+                                     (230, 250, 33)]):
+        f, b1, b2, it = make_gp_problem(300 + i, m1, m2, t, 6)
+        parts.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(parts)
+    ref = fit_gp_spp_batch(feats, probs, training_iter=12)
+    import torch
+    from gapro_amd import gen_ps_utils
+
+    pipe = gen_ps_utils._pipeline(torch.device("cuda:0"), 12)  # the cached pipeline fit_gp_spp_batch uses
+    old = int(pipe.opt.reserved)
+    try:
+        pipe.opt.reserved = old | 8192
+        got = fit_gp_spp_batch(feats, probs, training_iter=12)
+    finally:
+        pipe.opt.reserved = old
+    for a, b in zip(ref, got):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
