@@ -336,6 +336,9 @@ def _save_arrays(save_path, arrays, spp_inv=None):
     os.replace(tmp, save_path)
 
 
+_T_IMPORT = time.time()
+
+
 def run_worker(filenames, args, device_index):
     """One GPU: scenes are read from disk by a pool of loader threads or processes (two batches ahead), go
     through the software-pipelined generator batch by batch (Pipeline.run_stream), and are written by the
@@ -344,8 +347,13 @@ def run_worker(filenames, args, device_index):
     import threading
 
     n_procs = int(getattr(args, "loader_procs", 0))
-    if n_procs < 0:  # auto: a quarter of the host's cores, at most 16 (more only adds start-up time)
-        n_procs = min(16, (os.cpu_count() or 1) // 4)
+    n_workers = max(1, int(getattr(args, "n_workers", 1)))  # GPU workers sharing this host (--devices)
+    if n_procs < 0:
+        # auto: at most 16 per worker (more only adds start-up time: 16 -> 32 -> 64 loaders: 223 -> 200 -> 159 scenes/s),
+        # and all workers' loaders together at most half the physical cores -- eight workers x 16 loaders on one host
+        # oversubscribe it long before eight GPUs are fed
+        phys = max(1, (os.cpu_count() or 2) // 2)
+        n_procs = min(16, max(2, phys // (2 * n_workers)), (os.cpu_count() or 1) // 4)
         if n_procs < 2:  # a small host: one loader process is no faster than the threads
             n_procs = 0
     procs = None
@@ -499,8 +507,26 @@ def run_worker(filenames, args, device_index):
             meta.append((scenes, jobs))
             yield jobs
 
+    def host_only_stream(batch_iter):
+        """GAPRO_DRIVER_HOST_ONLY=1 (tools/bench_driver.py --host-only): everything the host does for a scene -- read,
+        unpickle, upload, GT boxes, device -> host, pickle, write -- with the generation replaced by zero outputs of
+        the right shapes.  Measures what the host can feed W workers, whatever the GPUs do; never a product mode."""
+        for jobs in batch_iter:
+            outs = []
+            for j in jobs:
+                n = int(j.coords.shape[0])
+                outs.append((torch.zeros(n, dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+                             torch.ones(n, dtype=torch.float32, device=dev),
+                             torch.full((max(1, n // 50),), -100.0, dtype=torch.float32, device=dev),
+                             torch.full((max(1, n // 50),), -100.0, dtype=torch.float32, device=dev)))
+            yield outs
+
+    host_only = bool(os.environ.get("GAPRO_DRIVER_HOST_ONLY"))
     writes = []
-    for outs in pipe.run_stream(batches()):
+    t_first = None
+    for outs in (host_only_stream(batches()) if host_only else pipe.run_stream(batches())):
+        if t_first is None:
+            t_first = time.time()
         scenes, jobs = meta.pop(0)
         t_exp = time.time()
         ready = torch.cuda.current_stream(dev).record_event()  # run_stream ordered the outputs on this stream
@@ -539,6 +565,11 @@ def run_worker(filenames, args, device_index):
     print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)%s"
           % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0,
              ", %d from the raw cache" % cache_hits[0] if raw_cache else ""))
+    # start-up is reported apart from the rate: at ~300 scenes/s a 1201-scene split is a few seconds of work, and the
+    # spawned interpreters / library loads of a worker and its loaders take longer than that
+    print("[gen_ps] device %d: start-up %.1f s (process start -> generator ready), first batch out after %.1f s more, "
+          "%d loader processes%s" % (device_index, t0 - _T_IMPORT, (t_first - t0) if t_first else 0.0, n_procs,
+                                     ", host-only measurement mode" if host_only else ""))
     if os.environ.get("GAPRO_DRIVER_TIMES"):
         print("[gen_ps] main-thread seconds: " + ", ".join("%s %.2f" % kv for kv in spent.items()))
     return done, failed
@@ -569,6 +600,14 @@ def main(argv=None):
     os.makedirs(args.save_folder, exist_ok=True)
     filenames = sorted(glob(osp.join(args.data_root, args.split, "*_inst_nostuff.pth")))  # :27-32
     devices = [int(d) for d in args.devices.split(",") if d != ""]
+    args.n_workers = len(devices)
+    if len(devices) > 1 and args.raw_cache is None:
+        # several workers on one host: unpickling the .pth files caps the HOST at ~350 scenes/s whatever the number of
+        # loaders, one GPU alone takes ~300 -- the memory-mapped raw cache (first pass writes it, every later pass and
+        # every restart reads it) is what keeps more than one GPU fed.  `--raw_cache none` switches it off.
+        args.raw_cache = osp.join(args.save_folder, ".raw_cache")
+    if args.raw_cache in ("none", "None", ""):
+        args.raw_cache = None
     if args.worker_rank >= 0 or len(devices) == 1:
         r = max(args.worker_rank, 0)
         # independent scenes, no collective: the shared queue hands out the common list; the static farms shard it

@@ -408,7 +408,9 @@ int gapro_debug_stream(gapro_ctx* ctx, void* stream, int64_t n, const double* d_
                        int32_t mode);
 /* Matrix-core peak of this device, measured: every CU runs waves_per_simd waves per SIMD, each a loop of
  * `iters` x 8 independent 16x16x4 MFMA chains with no memory traffic (kind 0: v_mfma_f64_16x16x4_f64,
- * kind 1: v_mfma_f32_16x16x4_f32); timed with HIP events on `stream`, blocking.  d_sink: one device double.
+ * kind 1: v_mfma_f32_16x16x4_f32, kind 2: 16 chains of v_mfma_f64_4x4x4_4b_f64, kind 3: that instruction with a
+ * different A / B register pair per instruction, 8 x 4 accumulators; d_sink then >= 32 device doubles, read); timed
+ * with HIP events on `stream`, blocking.  d_sink: one device double.
  * The roofline peak the fit kernels are priced against (the local guide has no FP64 row). */
 int gapro_debug_mfma_peak(gapro_ctx* ctx, void* stream, int32_t kind, int32_t iters, int32_t waves_per_simd,
                           double* d_sink, double* out_tflops);
@@ -417,6 +419,17 @@ int gapro_debug_mfma_peak(gapro_ctx* ctx, void* stream, int32_t kind, int32_t it
  * the matrix cores sustain when only a part of the chip is busy (tools/mfma_peak.py --clock). */
 int gapro_debug_mfma_clock(gapro_ctx* ctx, void* stream, int32_t iters, int32_t waves_per_simd, int32_t n_blocks,
                            double* d_sink, double* out_tflops, double* out_shader_mhz);
+
+/* The chunk loop of the staged kernel's workgroup-tiled products piece by piece (round 3): `blocks` workgroups of 512
+ * threads, every wave re-reads the MFMA fragments of a 32 x 64 piece from LDS for two k-steps per iteration and issues
+ * 16 v_mfma_f64_16x16x4_f64.  mode bits: 1 = + a workgroup barrier per iteration, 2 = + two 16-byte LDS stores per
+ * thread, 4 = + two 16-byte global loads per thread (prefetch distance two iterations), 8 = the 16x16x4 form in the
+ * plain loop (0 = four v_mfma_f64_4x4x4_4b_f64 per step, A rotated by DPP), 16 = the 16x16x4 form software-pipelined
+ * across the barrier as gemm_wg does it, 32 / 64 = variants of where the loads and stores sit.  d_src: >= (blocks + 1)
+ * * 65536 doubles, d_sink: one double.  What the FP64 matrix cores sustain in a loop shaped like the products:
+ * ~73 TFLOP/s, against ~48 for chains that feed every instruction the same registers (gapro_debug_mfma_peak). */
+int gapro_debug_wgloop(gapro_ctx* ctx, void* stream, int32_t iters, int32_t mode, int32_t blocks, const double* d_src,
+                       double* d_sink, double* out_tflops);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,12 @@
 upload + generation + file writes), for the "PCIe-inclusive" figure of DESIGN.md.
 
     python tools/bench_driver.py [--scenes 96] [--points 150000] [--batch 32] [--threads 8]
+    python tools/bench_driver.py --workers 1,2,4,8 --host-only --raw-cache     # host ceiling of the multi-GPU farm
+
+`--workers W,...`: for every W, gen_ps --devices 0,0,..,0 (W workers on GPU 0: what is measured is the HOST side of
+a W-GPU farm on one box; with --host-only the generation itself is replaced by zero outputs so that the one shared GPU
+is not what limits the run).  Prints one "farm" line per W and source (.pth files / raw cache): delivered scenes/s =
+scenes / slowest worker's own clock (start-up excluded), start-up seconds apart.
 """
 import argparse
 import os
@@ -24,6 +30,8 @@ def main():
     ap.add_argument("--procs", type=int, default=0, help="loader processes (0 = threads)")
     ap.add_argument("--raw-cache", action="store_true",
                     help="also time a run over the opt-in raw scene cache (gen_ps --raw_cache), written by the warm run")
+    ap.add_argument("--workers", default="", help="comma-separated worker counts: farm runs with --devices 0,0,...")
+    ap.add_argument("--host-only", action="store_true", help="GAPRO_DRIVER_HOST_ONLY=1: no generation (host ceiling)")
     args = ap.parse_args()
     from gapro_amd import gen_ps
     from gapro_amd.synth import make_scene, write_scannet_layout
@@ -50,18 +58,43 @@ def main():
         # run warms the page cache and the code-object cache, the second one is timed on fresh outputs
         import subprocess
 
-        def run(save, cache=None):
+        def run(save, cache=None, workers=1, procs=None, host_only=False):
             cmd = [sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", data,
                    "--batch_scenes", str(args.batch), "--loader_threads", str(args.threads), "--loader_procs",
-                   str(args.procs)] + (["--raw_cache", cache] if cache else [])
+                   str(args.procs if procs is None else procs), "--devices", ",".join(["0"] * workers),
+                   "--raw_cache", cache if cache else "none"]
+            env = dict(os.environ)
+            if host_only:
+                env["GAPRO_DRIVER_HOST_ONLY"] = "1"
             t = time.time()
             out = subprocess.run(cmd, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                 capture_output=True, text=True, check=True).stdout
+                                 capture_output=True, text=True, check=True, env=env).stdout
             lines = out.strip().splitlines()
             return time.time() - t, "\n".join(l for l in lines if l.startswith("[gen_ps]"))
 
+        def farm(workers, cache, tag):
+            import re
+
+            wall, txt = run(os.path.join(root, "farm_%s_%d" % (tag, workers)), cache, workers, procs=-1,
+                            host_only=args.host_only)
+            done = [(int(a), float(b)) for a, b in re.findall(r"(\d+) scenes written, \d+ skipped/failed, ([\d.]+) s", txt)]
+            start = [float(a) for a in re.findall(r"start-up ([\d.]+) s", txt)]
+            loaders = re.findall(r"(\d+) loader processes", txt)
+            n = sum(d for d, _ in done)
+            slow = max((t for _, t in done), default=0.0)
+            print("farm %s workers %d: %d scenes, %.1f scenes/s delivered (slowest worker %.1f s), start-up %.1f s, "
+                  "wall %.1f s, loaders per worker %s%s" % (tag, workers, n, n / slow if slow > 0 else 0.0, slow,
+                                                           max(start, default=0.0), wall, loaders[0] if loaders else "?",
+                                                           ", host-only" if args.host_only else ""), flush=True)
+
         cache = os.path.join(root, "rawcache") if args.raw_cache else None
         run(os.path.join(root, "warm"), cache)  # also writes the raw cache when asked
+        if args.workers:
+            for w in [int(x) for x in args.workers.split(",") if x]:
+                farm(w, None, "pth")
+                if cache:
+                    farm(w, cache, "raw")
+            return
         dt, line = run(os.path.join(root, "labels"))
         print(line)
         if cache:

@@ -29,6 +29,21 @@ def measure(device=0, iters=20000):
             out["%s_wps%d" % (name, wps)] = tf.value
             best = max(best, tf.value)
         out[name] = best
+    # Round 3: the chains above feed every instruction the SAME A / B registers, and in that form v_mfma_f64_16x16x4
+    # tops out at ~48 TFLOP/s -- rounds 1 and 2 took that for the matrix cores' ceiling.  In a loop shaped like the fit
+    # kernels' products (fragments re-read from LDS every k-step, 8 accumulator blocks per wave, 512-thread workgroups)
+    # the same instruction sustains ~73: that is the ceiling the products are priced against in DESIGN.md.
+    n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+    src = torch.ones(2 * n_cu * 65536 + 65536, dtype=torch.float64, device="cuda:%d" % device)
+    for key, mode, per_cu in (("f64_16x16x4_lds_loop", 8, 2), ("f64_16x16x4_lds_loop_1wg", 8, 1),
+                              ("f64_16x16x4_wg_tiled_loop", 16 | 7, 2), ("f64_4x4x4_4b_lds_loop", 0, 2)):
+        tf = C.c_double()
+        try:
+            ctx.check(ctx.lib.gapro_debug_wgloop(ctx.handle, None, 4000, mode, per_cu * n_cu, C.c_void_p(src.data_ptr()),
+                                                 C.c_void_p(sink.data_ptr()), C.byref(tf)))
+            out[key] = tf.value
+        except Exception as e:  # noqa: BLE001 - diagnostic
+            out[key] = repr(e)
     return out
 
 

@@ -11,7 +11,6 @@ from gapro_amd._lib import Context  # noqa: E402
 
 ctx = Context.get(0)
 lib = ctx.lib
-lib.gapro_debug_wgloop.restype = C.c_int
 n_cu = torch.cuda.get_device_properties(0).multi_processor_count
 src = torch.ones(2 * n_cu * 65536 + 65536, dtype=torch.float64, device="cuda")
 sink = torch.zeros(8, dtype=torch.float64, device="cuda")
