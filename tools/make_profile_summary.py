@@ -105,8 +105,9 @@ def main():
     md = ["# rocprofv3 summary, %s" % a.tag, "",
           "Commands (on the MI355X box, see tools/run_measure.sh):", "",
           "    python bench.py                                   -> %s_bench.json" % a.tag,
-          "    rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline   -> %s_kernel_stats.csv" % a.tag,
-          "    rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+          "    L=\"--no-cpu-baseline --no-fixed-line --no-driver-line --no-extra-lines\"",
+          "    rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 $L   -> %s_kernel_stats.csv" % a.tag,
+          "    rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 5 --warmup 0 $L",
           "    rocprofv3 --kernel-trace --pmc WRITE_SIZE -- (same)            -> %s_pmc_summary.txt, %s_pmc_traffic.json" % (a.tag, a.tag),
           "    rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 tools/pmc_calib.py   (calibration, same file)", "",
           "Workload: %s" % bench["config"]["workload"], "",
@@ -116,12 +117,14 @@ def main():
     md += ["",
            "bench.py (un-profiled run): %.1f scenes/s, %.1f ms per step of %d scenes; fit launch (%s): first kernel "
            "start -> last kernel end %.2f ms by HIP events on the kernels' streams, %.3g algorithmic FLOP per launch -> "
-           "%.2f TFLOP/s = %.1f %% of the %.1f TFLOP/s FP64 MFMA datasheet peak (%.1f %% of the %.1f TFLOP/s measured on "
-           "this box by tools/mfma_peak.py)."
+           "%.2f TFLOP/s = %.1f %% of the %.1f TFLOP/s FP64 MFMA datasheet peak (%.1f %% of the %.1f TFLOP/s that "
+           "v_mfma_f64_16x16x4 sustains on this box in a loop shaped like the kernels' products, fragments re-read from "
+           "LDS: tools/mfma_peak.py, key f64_16x16x4_lds_loop; the register-constant chains of rounds 1-2 read %.1f)."
            % (bench["value"], bench["ms_per_step"], bench["config"]["scenes_per_step_per_gpu"],
               ", ".join("%s %.0f ms" % (k, v["avg_ms"]) for k, v in fl.get("kernels", {}).items() if v["flops"] > 0),
               rl["avg_launch_ms"], rl["flops_per_launch"], rl["achieved"], 100 * rl["frac"], rl["peak"],
-              100 * rl["achieved"] / max((bench.get("peak_measured") or {}).get("f64_16x16x4", rl["peak"]), 1e-9),
+              100 * rl["achieved"] / max((bench.get("peak_measured") or {}).get("f64_16x16x4_lds_loop", rl["peak"]), 1e-9),
+              (bench.get("peak_measured") or {}).get("f64_16x16x4_lds_loop", float("nan")),
               (bench.get("peak_measured") or {}).get("f64_16x16x4", float("nan"))), ""]
     if "fit_launch" in traffic:
         t = traffic["fit_launch"]
