@@ -324,3 +324,47 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rec["value"] > 0 and abs(rec["value"] - 2 * 8 * 2 / (rec["ms_per_step"] * 2 * 1e-3)) < 1e-6 * rec["value"]
     assert rec["roofline"]["bound"] == "mfma" and rec["roofline"]["achieved"] > 0 and rec["partition"]["GB/s"] > 0
     assert "test mode" in rec["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_cli_files_equal_the_oracle_end_to_end(tmp_path):
+    """what the CLI WRITES, compared with the CPU oracle run on what the reference's driver
+    would have fed it -- files on disk in the ScanNet layout -> gen_ps (loader processes, batched generator, export)
+    -> the 5-tuples; against oracle/gen_ps_oracle.py on inputs prepared by the host mirror of gen_ps.py:45-111
+    (features from the UN-aligned xyz, axis alignment, GT boxes, wall boxes).  Integer masks bit-exact, probabilities to
+    float32 rounding, GP mean / variance within the north-star tolerance, superpoint-length mu / var."""
+    from gapro_amd import gen_ps
+    from gapro_amd.gen_ps import read_scene
+    from gapro_amd.gen_ps_utils import getInstanceInfo
+    from oracle import gen_ps_oracle as O
+    from oracle.svgp_oracle import fit_gp_spp_oracle
+
+    root, scenes = _dataset(tmp_path, 3)
+    save = str(tmp_path / "labels")
+    gen_ps.main(["--save_folder", save, "--data_root", root, "--batch_scenes", "2", "--loader_procs", "2"])
+    n_gp = 0
+    for s in scenes:
+        fn = os.path.join(root, "train", s.scan_name + "_inst_nostuff.pth")
+        sc = read_scene(fn, root)  # the disk / host half of the driver, device-free
+        _, cls, box, vol, _ = getInstanceInfo(sc["coords_float"], sc["instance_label"].astype(np.int32),
+                                              sc["semantic_label"].astype(np.int32))
+        ref, dbg = O.gen_pseudo_label_gaussian_process(
+            coords_float=sc["coords_float"], mask_feats=sc["mask_feats"].astype(np.float32), spp=sc["spp"],
+            instance_cls=cls.astype(np.int64), instance_box=box.astype(np.float32),
+            instance_box_volume=vol.astype(np.float32), wall_box=sc["wall_box"], wall_box_volume=sc["wall_box_volume"],
+            instance_classes=18, dataset_name="scannetv2", ground_h=0.1, training_iter=50, thresh_spp_occu=0.999,
+            fit_fn=lambda f, b1, b2, it: fit_gp_spp_oracle(f, b1, b2, it, 50, impl="autograd", dtype="f64"),
+            return_debug=True)
+        sem, ins, prob, mu, var = torch.load(os.path.join(save, s.scan_name + ".pth"), weights_only=False)
+        tie = [np.min(np.abs(np.asarray(r[0], np.float64) - 0.5)) for r in dbg["results"]]
+        assert not tie or min(tie) > 1e-5, "fixture has a GP tie; pick another seed"
+        np.testing.assert_array_equal(sem, ref[0])
+        np.testing.assert_array_equal(ins, ref[1])
+        np.testing.assert_allclose(prob, ref[2], rtol=0, atol=3e-7)
+        gp = ref[3] != -100
+        assert len(mu) == len(ref[3]) == dbg["part"].n_spps
+        np.testing.assert_array_equal(mu == -100, ~gp)
+        np.testing.assert_allclose(var[gp], ref[4][gp], rtol=1e-4)
+        np.testing.assert_allclose(mu[gp], ref[3][gp], rtol=1e-4, atol=1e-6)
+        n_gp += int(gp.sum())
+    assert n_gp > 0, "no GP-labelled superpoint in the fixture scenes"
