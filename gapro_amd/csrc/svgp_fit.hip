@@ -388,7 +388,7 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 // the same bits.  What changes is where the operand fragments come from.  With one tile per wave fed from global
 // memory every wave fetches its own fragments: 4 FLOP per byte at 32 x 32, and the 256 .. 512 concurrent fits of a
 // launch, whose working sets (17 matrices each) hit neither L2 nor the Infinity Cache, move 6.3 TB/s at M = 256 -- the
-// staged kernel sat ON the HBM roof (profiles/r03_probe1.md).  Here the eight waves of the workgroup share one
+// staged kernel sat ON the HBM roof (profiles/r03_probes.md).  Here the eight waves of the workgroup share one
 // 128 x 128 output tile: an 8-row chunk of both operands (8 KiB each) is fetched ONCE per workgroup, one 16-byte load
 // per thread and operand (wave w fetches row w: 1 KiB contiguous), held in registers for two iterations (the
 // prefetch distance), written to one of two LDS stages and read from there as MFMA fragments by every wave: 16 FLOP

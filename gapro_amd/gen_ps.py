@@ -22,14 +22,17 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
     --init_mean_std S      std of the random initial variational mean (gpytorch: 1e-3 unseeded;
                            default 0 = deterministic), --seed seeds it
     --broadcast_mu_var     write mu/var at point length (what the released data loaders index)
-    --raw_cache DIR        opt-in raw scene cache: the first run writes, next to nothing else, one flat file per scene
+    --raw_cache DIR        raw scene cache (opt-in with one device; ON by default, at <save_folder>.raw_cache, with
+                           several: unpickling caps the whole host below what ONE GPU takes, `--raw_cache none`
+                           refuses): the first run writes, next to nothing else, one flat file per scene
                            (<DIR>/<scan>.gaproraw: the arrays of read_scene exactly as they are uploaded, 64-byte
                            aligned, with the sizes and mtimes of the source files in its header); later runs map it
                            (np.memmap) and upload straight from the page cache -- no unpickling, no loader process,
                            no shared-memory copy.  A cache whose source files changed is rebuilt.  Unpickling the
                            ScanNet .pth tuples is what caps the loaders at ~350 scenes/s per host
     --loader_threads T     threads that read scenes from disk a batch ahead and write the results (default 4)
-    --loader_procs P       read and write in P loader PROCESSES (default -1 = min(16, cores/4); 0 = threads only).
+    --loader_procs P       read and write in P loader PROCESSES (default -1 = min(16, physical cores / (2 W)) per
+                           worker for W workers, at most cores/4; 0 = threads only).
                            Unpickling a ScanNet .pth holds the GIL, so threads top out near one core; processes
                            hand the arrays over in POSIX shared memory (through the pipe when /dev/shm is full)
                            and the loader threads only upload from it.  The pool is started before the worker
@@ -605,7 +608,7 @@ def main(argv=None):
         # several workers on one host: unpickling the .pth files caps the HOST at ~350 scenes/s whatever the number of
         # loaders, one GPU alone takes ~300 -- the memory-mapped raw cache (first pass writes it, every later pass and
         # every restart reads it) is what keeps more than one GPU fed.  `--raw_cache none` switches it off.
-        args.raw_cache = osp.join(args.save_folder, ".raw_cache")
+        args.raw_cache = osp.normpath(args.save_folder) + ".raw_cache"  # next to the label folder, never inside it
     if args.raw_cache in ("none", "None", ""):
         args.raw_cache = None
     if args.worker_rank >= 0 or len(devices) == 1:
