@@ -123,6 +123,8 @@ SIGNATURES = {
     "gapro_debug_mfma_peak": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     "gapro_debug_mfma_clock": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]),
+    "gapro_debug_product_bench": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                            C.POINTER(C.c_float)]),
     "gapro_debug_wgloop": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_double)]),
 }
 

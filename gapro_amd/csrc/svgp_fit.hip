@@ -433,29 +433,54 @@ __device__ __noinline__ void gemm_wg(int rows16, int cols16, bool lower_only, co
 #pragma nounroll
     for (int tj = 0; tj < (lower_only ? ti + 1 : ntj); ++tj) {
       const int I0 = kWgTile * ti, J0 = kWgTile * tj;
-      // contraction range of the workgroup tile = hull of its blocks' ranges; of this wave's piece likewise
+      // Contraction range of the workgroup tile and of this wave's piece: the hull of their blocks' ranges.  Every kr
+      // of the fit is monotone (lo and hi never decrease with the block row or the block column), so a rectangle's
+      // hull is [lo of its first block, hi of its last block]: two calls instead of one per block (64 per tile and
+      // wave cost ~3 us of scalar work per tile, a quarter of a tile's time at M_p = 256).  For a lower-triangular
+      // output the blocks above the diagonal are not part of it; leaving them in the hull only widens it, and what a
+      // wider hull adds are products with structural zeros.
       int klo = 1 << 30, khi = 0, plo = 1 << 30, phi = 0;
       unsigned on_mask = 0;  // bit 4 u + v: block (u, v) of this wave's piece is part of the output
-#pragma nounroll
-      for (int bi = 0; bi < kWgTile / 16; ++bi) {
-        const int ib = I0 + 16 * bi;
-        if (ib >= rows) break;
-#pragma nounroll
-        for (int bj = 0; bj < kWgTile / 16; ++bj) {
-          const int jb = J0 + 16 * bj;
-          if (jb >= cols) break;
-          if (lower_only && ib < jb) continue;
-          const bool mine = (bi >> 1) == wi && (bj >> 2) == wj;
-          if (mine) on_mask |= 1u << (4 * (bi & 1) + (bj & 3));  // also with an empty range: epi sees a zero block
-          int lo, hi;
-          kr(ib, jb, &lo, &hi);
+      if (rows - I0 >= kWgTile && cols - J0 >= kWgTile) {  // a full tile: every piece, every block inside the matrix
+        int lo, hi, d;
+        kr(I0, J0, &lo, &d);
+        kr(I0 + kWgTile - 16, J0 + kWgTile - 16, &d, &hi);
+        hi = hi < kmax ? hi : kmax;
+        if (lo < hi) { klo = lo; khi = hi; }
+        const int pi0 = I0 + 32 * wi, pj0 = J0 + 64 * wj;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v)
+            if (!(lower_only && pi0 + 16 * u < pj0 + 16 * v)) on_mask |= 1u << (4 * u + v);
+        if (on_mask) {
+          kr(pi0, pj0, &lo, &d);
+          kr(pi0 + 16, pj0 + 48, &d, &hi);
           hi = hi < kmax ? hi : kmax;
-          if (lo >= hi) continue;
-          klo = lo < klo ? lo : klo;
-          khi = hi > khi ? hi : khi;
-          if (mine) {
-            plo = lo < plo ? lo : plo;
-            phi = hi > phi ? hi : phi;
+          if (lo < hi) { plo = lo; phi = hi; }
+        }
+      } else {  // a tile at the matrix edge: block by block
+#pragma nounroll
+        for (int bi = 0; bi < kWgTile / 16; ++bi) {
+          const int ib = I0 + 16 * bi;
+          if (ib >= rows) break;
+#pragma nounroll
+          for (int bj = 0; bj < kWgTile / 16; ++bj) {
+            const int jb = J0 + 16 * bj;
+            if (jb >= cols) break;
+            if (lower_only && ib < jb) continue;
+            const bool mine = (bi >> 1) == wi && (bj >> 2) == wj;
+            if (mine) on_mask |= 1u << (4 * (bi & 1) + (bj & 3));  // also with an empty range: epi sees a zero block
+            int lo, hi;
+            kr(ib, jb, &lo, &hi);
+            hi = hi < kmax ? hi : kmax;
+            if (lo >= hi) continue;
+            klo = lo < klo ? lo : klo;
+            khi = hi > khi ? hi : khi;
+            if (mine) {
+              plo = lo < plo ? lo : plo;
+              phi = hi > phi ? hi : phi;
+            }
           }
         }
       }
@@ -1389,8 +1414,42 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
 template <int WG, int TU, bool SCALE, int ORD, typename KRange, typename Epi>
 __device__ inline void product(int mo, int no, bool lower, const gd* __restrict__ P, const gd* __restrict__ Q, int ld,
                                const gd* __restrict__ qs, KRange kr, Epi epi, ldsd* ring) {
-  if constexpr (WG != 0) gemm_wg<SCALE, true, WG>(mo, no, lower, P, Q, ld, qs, kr, epi, ring);
-  else gemm_tn<TU, SCALE, 2, ORD, true>(mo, no, lower, P, Q, ld, qs, kr, epi);
+  if constexpr (WG == 0) {
+    gemm_tn<TU, SCALE, 2, ORD, true>(mo, no, lower, P, Q, ld, qs, kr, epi);
+  } else {
+    // Workgroup-tiled products take the part of the output that whole 128 x 128 tiles cover; what is left at the
+    // matrix edge (an L of up to 96 rows / columns, M_p a multiple of 32) goes to the per-wave products as 32 x 32
+    // tiles: a workgroup tile with 32 valid rows costs as much as a full one (one wave strip in four has work), which
+    // made M_p = 288 25 % slower than the per-wave form.  Same blocks, same k order: the split does not change a bit.
+    // (extents rounded up to the strips' 32: the per-wave 32 x 32 form computes a last half-filled tile in full, M_p is
+    // a multiple of 32 here)
+    const int rows = (16 * mo + 31) / 32 * 32, cols = (16 * no + 31) / 32 * 32;
+    const int R = rows / kWgTile * kWgTile, Cc = cols / kWgTile * kWgTile;
+    if (R > 0 && Cc > 0) {
+      gemm_wg<SCALE, true, WG>(R / 16, Cc / 16, lower, P, Q, ld, qs, kr, epi, ring);
+    }
+    auto strip = [&](int r0, int c0, int nr, int nc, bool low) {  // rows [r0, r0 + nr) x columns [c0, c0 + nc)
+      if (nr <= 0 || nc <= 0) return;
+      // (row-major tile order: the shell order of some products enumerates SQUARE tile grids only)
+      gemm_tn<2, SCALE, 2, ORD_ROWMAJOR, true>(
+          nr / 32, nc / 32, low, P + r0, Q + c0, ld, qs,
+          [=](int i0, int j0, int* lo, int* hi) {
+            int l0, h0, l1, h1;  // a 32 x 32 tile's range: the hull of its 16 x 16 blocks' (kr is monotone)
+            kr(r0 + i0, c0 + j0, &l0, &h0);
+            kr(r0 + i0 + 16, c0 + j0 + 16, &l1, &h1);
+            *lo = l0;
+            *hi = h1;
+          },
+          [=](int i, int j, const d4& v) { epi(r0 + i, c0 + j, v); });
+    };
+    if (lower) {  // square output: the rows below the tiled part, left of and on the diagonal
+      strip(R, 0, rows - R, R, false);
+      strip(R, R, rows - R, cols - R, true);
+    } else {
+      strip(R, 0, rows - R, cols, false);   // bottom strip, full width
+      strip(0, Cc, R, cols - Cc, false);    // right strip above it
+    }
+  }
 }
 
 // WG: 0 = one tile per wave (gemm_tn), 2 / 4 = workgroup-tiled products with that many register stages (gemm_wg)
@@ -1880,7 +1939,7 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
 #define GAPRO_FIT_BODY(DM, DCV)                                                                              \
   do {                                                                                                       \
-    if (Mp > kFuseMaxMp && (opt.reserved & 8192) && !(WPS == 2 && (opt.reserved & 16384)))                   \
+    if (Mp > kFuseMaxMp && Mp % 32 == 0 && (opt.reserved & 8192) && !(WPS == 2 && (opt.reserved & 16384)))     \
       /* experiment bit 13: workgroup-tiled products (gemm_wg; bit-identical, 3x fewer operand bytes, 9 % slower  \
          on the stream workload: DESIGN 6.0); bit 14 restricts it to the two-per-CU build */                 \
       fit_body<1, DM, DCV, (WPS == 2 ? 4 : 2)>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
@@ -2684,6 +2743,45 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, con
   fit_epilogue(desc, opt, o_status, o_loss);
 }
 
+// ---- product engines side by side (debug entry, tools/product_bench.py) --------------------------------
+// Every workgroup owns three M_p x M_p matrices (P, Q, C) of a slab and computes C = P^T Q `reps` times with one of the
+// staged kernel's product engines, plain-store epilogue: engine 0 = gemm_tn with 32 x 32 wave tiles, 1 = 64 x 64 wave
+// tiles, 2 = the workgroup-tiled form (gemm_wg on whole 128 x 128 tiles + per-wave strips at the edge).  shape 0: full contraction range; 1: the
+// range [0, i0 + 16) of a lower-triangular P (the A = L^-1 K product's); 2: lower-triangular output, full range.
+template <int ENGINE>
+__global__ __launch_bounds__(NT, 2) void k_product_bench(int Mp, int reps, int shape, double* __restrict__ slab) {
+  extern __shared__ double dyn_lds[];
+  ldsd* scratch = (ldsd*)dyn_lds;
+  gd* P = (gd*)slab + (size_t)blockIdx.x * 3 * Mp * Mp;
+  gd* Q = P + (size_t)Mp * Mp;
+  gd* Cm = Q + (size_t)Mp * Mp;
+  if (threadIdx.x == 0) {
+    g_sh.f.M = Mp;
+    g_sh.f.Mp = Mp;
+  }
+  __syncthreads();
+  const int shp = shape;
+  constexpr int TSZ = ENGINE == 0 ? 32 : ENGINE == 1 ? 64 : 16;  // the engine's own tile: kr is asked per tile
+  auto kr = [=](int i0, int j0, int* lo, int* hi) {
+    // shapes 3 .. 5 (the caller zeroes the matching triangles of P and Q, so that any superset of a range gives the
+    // same bits): 3 = [max(i0, j0), Mp) (T1), 4 = [j0, Mp) (B, G), 5 = [i0, Mp) (G_KX, Pm; with a lower output)
+    *lo = shp == 3 ? (i0 > j0 ? i0 : j0) : shp == 4 ? j0 : shp == 5 ? i0 : 0;
+    *hi = shp == 1 ? i0 + TSZ : Mp;
+  };
+  auto epi = [=](int i0, int j0, const d4& v) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Cm[(size_t)(i0 + lq + 4 * r) * Mp + j0 + lr] = v[r];
+  };
+  for (int r = 0; r < reps; ++r) {
+    if (ENGINE == 0) gemm_tn<2, false, 2, ORD_ROWS_DESC, true>(Mp / 32, Mp / 32, shp == 2 || shp == 5, P, Q, Mp, nullptr, kr, epi);
+    else if (ENGINE == 1) gemm_tn<4, false, 2, ORD_ROWS_DESC, true>(Mp / 32, Mp / 32, shp == 2 || shp == 5, P, Q, Mp, nullptr, kr, epi);
+    else if (ENGINE == 2) product<4, 1, false, ORD_ROWS_DESC>(Mp / 16, Mp / 16, shp == 2 || shp == 5, P, Q, Mp, nullptr, kr, epi, scratch);
+    else return;  // (engine 3 was a two-team form of engine 2: no faster, taken out again -- DESIGN 6.0)
+    __syncthreads();
+  }
+}
+
 // ---- MFMA layout self-test (debug entry, used by tests/test_fit_gpu.py) ------------------------------
 __global__ void k_mfma_selftest(const double* __restrict__ P, const double* __restrict__ Q, double* __restrict__ C,
                                 int K) {
@@ -3103,6 +3201,43 @@ int gapro_fit_timing_offsets(gapro_ctx* ctx, gapro_fit_timing* ref, gapro_fit_ti
   }
   out_ms2[0] = lo;
   out_ms2[1] = hi;
+  return GAPRO_OK;
+}
+
+// Debug: the staged kernel's product engines side by side (k_product_bench); d_slab: n_wg * 3 * mp * mp doubles,
+// filled by the caller.  Returns the launch's milliseconds (HIP events on `stream`, blocking) in *out_ms.
+int gapro_debug_product_bench(gapro_ctx* ctx, void* stream_, int32_t engine, int32_t shape, int32_t mp, int32_t reps,
+                              int32_t n_wg, double* d_slab, float* out_ms) {
+  if (!ctx || !d_slab || !out_ms || engine < 0 || engine > 2 || shape < 0 || shape > 5 || mp < 128 || mp % 32 ||
+      reps <= 0 || n_wg <= 0)
+    return GAPRO_ERR_BAD_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int lds = 8 * kWgRingDoubles + 1024;
+  hipEvent_t e0, e1;
+  GAPRO_HIP_CHECK(ctx, hipEventCreate(&e0));
+  GAPRO_HIP_CHECK(ctx, hipEventCreate(&e1));
+  auto launch = [&](int n) -> int {
+#define GAPRO_PB(E)                                                                                              \
+  do {                                                                                                           \
+    GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_product_bench<E>,                                    \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));                 \
+    hipLaunchKernelGGL(k_product_bench<E>, dim3(n_wg), dim3(NT), (size_t)lds, stream, (int)mp, n, (int)shape, d_slab); \
+  } while (0)
+    if (engine == 0) GAPRO_PB(0);
+    else if (engine == 1) GAPRO_PB(1);
+    else GAPRO_PB(2);
+#undef GAPRO_PB
+    return GAPRO_OK;
+  };
+  if (launch(1) != GAPRO_OK) return GAPRO_ERR_HIP;
+  GAPRO_HIP_CHECK(ctx, hipEventRecord(e0, stream));
+  if (launch(reps) != GAPRO_OK) return GAPRO_ERR_HIP;
+  GAPRO_HIP_CHECK(ctx, hipEventRecord(e1, stream));
+  GAPRO_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(out_ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
 }
 

@@ -431,6 +431,15 @@ int gapro_debug_mfma_clock(gapro_ctx* ctx, void* stream, int32_t iters, int32_t 
 int gapro_debug_wgloop(gapro_ctx* ctx, void* stream, int32_t iters, int32_t mode, int32_t blocks, const double* d_src,
                        double* d_sink, double* out_tflops);
 
+/* The staged fit kernel's product engines side by side (round 3): n_wg workgroups, each C = P^T Q on its own three
+ * mp x mp matrices of d_slab (n_wg * 3 * mp * mp doubles, filled by the caller), `reps` times.  engine 0: one 32 x 32
+ * tile per wave from global memory, 1: 64 x 64 tiles, 2: workgroup-tiled through an LDS ring (gemm_wg) with per-wave
+ * strips at the matrix edge.  shape 0: full range, 1: triangular P (range [0, i0 + tile)), 2: lower-triangular output,
+ * 3: [max(i0, j0), mp), 4: [j0, mp), 5: lower output with [i0, mp) (the caller zeroes the matching triangles of P / Q).
+ * mp a multiple of 32, >= 128.  *out_ms: the launch, HIP events on `stream`, blocking. */
+int gapro_debug_product_bench(gapro_ctx* ctx, void* stream, int32_t engine, int32_t shape, int32_t mp, int32_t reps,
+                              int32_t n_wg, double* d_slab, float* out_ms);
+
 #ifdef __cplusplus
 }
 #endif

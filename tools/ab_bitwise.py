@@ -20,6 +20,9 @@ def main():
         a, b = np.load(args.compare[0]), np.load(args.compare[1])
         bad = [k for k in a.files if not np.array_equal(a[k], b[k], equal_nan=True)]
         print("arrays %d, differing %d %s" % (len(a.files), len(bad), bad[:8]))
+        for k in bad[:12]:
+            x, y = a[k].astype(np.float64), b[k].astype(np.float64)
+            print("   %s: max abs diff %.3e, max rel %.3e" % (k, np.max(np.abs(x - y)), np.max(np.abs(x - y) / np.maximum(np.abs(x), 1e-30))))
         sys.exit(1 if bad else 0)
     from gapro_amd import _lib
 

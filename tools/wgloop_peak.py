@@ -16,7 +16,10 @@ src = torch.ones(2 * n_cu * 65536 + 65536, dtype=torch.float64, device="cuda")
 sink = torch.zeros(8, dtype=torch.float64, device="cuda")
 names = {0: "lds reads + mfma", 1: "+ barrier", 3: "+ barrier + lds stores", 7: "+ barrier + stores + global loads",
          4: "+ global loads only", 2: "+ lds stores only"}
-extra = [(16 | 7 | 32, "16x16x4 sp", "all, stores independent of loads"), (16 | 7 | 64, "16x16x4 sp", "all, loads at the end"),
+src.uniform_(-1.0, 1.0)
+extra = [(8 | 128, "16x16x4", "lds reads + mfma, RANDOM operands"), (16 | 128, "16x16x4 sp", "lds reads + mfma, RANDOM operands"),
+         (16 | 7 | 128, "16x16x4 sp", "all, RANDOM operands"), (0 | 128, "4x4x4_4b", "lds reads + mfma, RANDOM operands"),
+(16 | 7 | 32, "16x16x4 sp", "all, stores independent of loads"), (16 | 7 | 64, "16x16x4 sp", "all, loads at the end"),
          (16 | 5, "16x16x4 sp", "barrier + global loads (no stores)"), (16 | 6, "16x16x4 sp", "stores + global loads (no barrier)")]
 for per_cu in (1, 2):
     for m, f, nm in extra:
