@@ -1425,27 +1425,42 @@ __device__ inline void product(int mo, int no, bool lower, const gd* __restrict_
     // a multiple of 32 here)
     const int rows = (16 * mo + 31) / 32 * 32, cols = (16 * no + 31) / 32 * 32;
     const int R = rows / kWgTile * kWgTile, Cc = cols / kWgTile * kWgTile;
-    if (R > 0 && Cc > 0) {
-      gemm_wg<SCALE, true, WG>(R / 16, Cc / 16, lower, P, Q, ld, qs, kr, epi, ring);
+    if (R > 0 && Cc > 0 && !lower) {
+      gemm_wg<SCALE, true, WG>(R / 16, Cc / 16, false, P, Q, ld, qs, kr, epi, ring);
     }
-    auto strip = [&](int r0, int c0, int nr, int nc, bool low) {  // rows [r0, r0 + nr) x columns [c0, c0 + nc)
+    auto strip_t = [&](auto tu_tag, int r0, int c0, int nr, int nc, bool low) {
+      constexpr int TUS = decltype(tu_tag)::value;  // 2: 32 x 32 wave tiles, 4: 64 x 64 (extents still in 32-units)
       if (nr <= 0 || nc <= 0) return;
       // (row-major tile order: the shell order of some products enumerates SQUARE tile grids only)
-      gemm_tn<2, SCALE, 2, ORD_ROWMAJOR, true>(
+      gemm_tn<TUS, SCALE, 2, ORD_ROWMAJOR, true>(
           nr / 32, nc / 32, low, P + r0, Q + c0, ld, qs,
           [=](int i0, int j0, int* lo, int* hi) {
-            int l0, h0, l1, h1;  // a 32 x 32 tile's range: the hull of its 16 x 16 blocks' (kr is monotone)
+            int l0, h0, l1, h1;  // a wave tile's range: the hull of its 16 x 16 blocks' (kr is monotone; gemm_tn trims hi)
             kr(r0 + i0, c0 + j0, &l0, &h0);
-            kr(r0 + i0 + 16, c0 + j0 + 16, &l1, &h1);
+            kr(r0 + i0 + 16 * TUS - 16, c0 + j0 + 16 * TUS - 16, &l1, &h1);
             *lo = l0;
             *hi = h1;
           },
           [=](int i, int j, const d4& v) { epi(r0 + i, c0 + j, v); });
     };
-    if (lower) {  // square output: the rows below the tiled part, left of and on the diagonal
-      strip(R, 0, rows - R, R, false);
-      strip(R, R, rows - R, cols - R, true);
-    } else {
+    auto strip = [&](int r0, int c0, int nr, int nc, bool low) {  // rows [r0, r0 + nr) x columns [c0, c0 + nc)
+      strip_t(std::integral_constant<int, 2>{}, r0, c0, nr, nc, low);
+    };
+    if (lower) {
+      // Lower-triangular outputs (G_LS with its Adam epilogue, G_L, Pm) stay per-wave as a whole: a diagonal workgroup
+      // tile computes 64 blocks for the 36 it needs, and these are the products with the heaviest epilogues, which the
+      // eight waves of a tile then run in lockstep (fit-level, M = 256 two per CU: G_LS 15.6 -> 22.5, Pm 4.0 -> 5.3 ms
+      // per fit with the tiled form; G_KX, G, G_A the other way).  64 x 64 wave tiles where round 2 used them.
+      if constexpr (WG == 4) {
+        if (rows >= 352) {
+          strip_t(std::integral_constant<int, 4>{}, 0, 0, rows, cols, true);
+          return;
+        }
+      }
+      strip(0, 0, rows, cols, true);
+      return;
+    }
+    {
       strip(R, 0, rows - R, cols, false);   // bottom strip, full width
       strip(0, Cc, R, cols - Cc, false);    // right strip above it
     }
@@ -1939,9 +1954,12 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
 #define GAPRO_FIT_BODY(DM, DCV)                                                                              \
   do {                                                                                                       \
-    if (Mp > kFuseMaxMp && Mp % 32 == 0 && (opt.reserved & 8192) && !(WPS == 2 && (opt.reserved & 16384)))     \
-      /* experiment bit 13: workgroup-tiled products (gemm_wg; bit-identical, 3x fewer operand bytes, 9 % slower  \
-         on the stream workload: DESIGN 6.0); bit 14 restricts it to the two-per-CU build */                 \
+    if (Mp > kFuseMaxMp && Mp % 32 == 0 && !(opt.reserved & 131072) &&                                       \
+        ((opt.reserved & 8192) ? !(WPS == 2 && (opt.reserved & 16384)) : Mp % 128 == 0))                      \
+      /* workgroup-tiled products (gemm_wg; bit-identical to the per-wave ones) where whole 128 x 128 tiles   \
+         cover the matrix: M_p = 256, 384 (+6 % / +4 % fits/s, a quarter less traffic; neutral to -7 % at     \
+         the other sizes: DESIGN 6.0).  Bit 13: every M_p > 128 that is a multiple of 32 (bit 14: not in the  \
+         one-per-CU build); bit 17: nowhere */                                                                \
       fit_body<1, DM, DCV, (WPS == 2 ? 4 : 2)>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
     else if (WPS == 2 && DM == 6 && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096))                     \
       fit_body<(WPS == 2 && DM == 6) ? 4 : 2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \

@@ -321,7 +321,8 @@ typedef struct {
                               * staged launch, 128 = the staged fits as ONE launch (not split by their LDS need),
                               * 256 = cluster barriers always with the L2 write-back, 512 = plain longest-first order
                               * (no serpentine over the XCDs), 8192 = workgroup-tiled products through LDS in the staged
-                              * kernel (round-3 experiment, bit-identical), 16384 = those in the two-per-CU build only,
+                              * kernel at every M_p > 128 (default: M_p = 256, 384 only; bit-identical either way),
+                              * 16384 = with 8192: in the two-per-CU build only, 131072 = never (round 2's products),
                               * 32768 = TEST: the last member of every cluster never arrives (cluster barrier timeout)
                               * -- A/B switches of tools/bench_fit.py / fit_timeline.py */
   int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive

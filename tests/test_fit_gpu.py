@@ -587,10 +587,11 @@ def test_cluster_staging_buffer_grows_with_the_launch():
 
 
 def test_workgroup_tiled_products_are_bit_identical_to_the_per_wave_products():
-    """Round-3 experiment (gapro_fit_options.reserved bit 13): the staged kernel's products through an LDS
-    ring shared by the workgroup accumulate every 16 x 16 block over the same k in the same order as the per-wave
-    products, so the outputs are the same bits -- for full tiles, ragged edges (M_p = 144, 176), lower-triangular
-    outputs, trimmed ranges and prediction batches larger than M_p."""
+    """Round 3: the staged kernel's products through an LDS ring shared by the workgroup (default at
+    M_p = 256, 384; everywhere with gapro_fit_options.reserved bit 13; nowhere with bit 17) accumulate every 16 x 16
+    block over the same k in the same order as the per-wave products, so the outputs are the same bits -- whole tiles,
+    per-wave strips at ragged edges, lower-triangular outputs kept per-wave, trimmed ranges, prediction batches larger
+    than M_p."""
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
     from gapro_amd.synth import make_gp_problem
 
@@ -609,10 +610,16 @@ def test_workgroup_tiled_products_are_bit_identical_to_the_per_wave_products():
     pipe = gen_ps_utils._pipeline(torch.device("cuda:0"), 12)  # the cached pipeline fit_gp_spp_batch uses
     old = int(pipe.opt.reserved)
     try:
-        pipe.opt.reserved = old | 8192
+        pipe.opt.reserved = old | 131072  # the per-wave products everywhere
+        ref = fit_gp_spp_batch(feats, probs, training_iter=12)
+        pipe.opt.reserved = old | 8192    # the workgroup-tiled ones wherever they can run
         got = fit_gp_spp_batch(feats, probs, training_iter=12)
     finally:
         pipe.opt.reserved = old
+    dflt = fit_gp_spp_batch(feats, probs, training_iter=12)  # and the default mix of the two
+    for a, b in zip(ref, dflt):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
     for a, b in zip(ref, got):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x, y)
