@@ -17,7 +17,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o bench -
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/calib_fetch -o calib --output-format csv -- python3 $R/tools/pmc_calib.py > $O/calib_fetch.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/calib_write -o calib --output-format csv -- python3 $R/tools/pmc_calib.py > $O/calib_write.log 2>&1
 # staged kernel, per-wave products (default) against the workgroup-tiled ones (experiment bit 13): bytes and time
-for c in FETCH_SIZE WRITE_SIZE; do for f in 0 8192; do for m in 256 384; do
+for c in FETCH_SIZE WRITE_SIZE; do for f in 0 131072; do for m in 256 384; do
 timeout 300 rocprofv3 --kernel-trace --pmc $c -d $O/ab_${c}_${f}_${m} -o f --output-format csv -- python3 $R/tools/bench_fit.py --sizes $m --fits 256 --reps 1 --flags $f > $O/ab_${c}_${f}_${m}.log 2>&1
 done; done; done
 cd $R
