@@ -623,3 +623,29 @@ def test_workgroup_tiled_products_are_bit_identical_to_the_per_wave_products():
     for a, b in zip(ref, got):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x, y)
+
+
+def test_fit_stress_m2048_against_the_oracle():
+    """BASELINE configs[4] at the size bench.py's `stress_m2048` key runs (M = 2048 pooled superpoints per
+    region): four concurrent fits (two problems, each twice) on the cluster kernel, 32 workgroups each, three Adam
+    steps -- enough for every phase of the forward and backward pass at 128 x 128 blocks of 16 -- against the float64
+    autograd oracle; the copies must agree bit for bit."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    m1, m2, t = 1000, 1048, 64
+    assert _lib.load().gapro_fit_route(m1 + m2, 6) == 4
+    parts, probs, base = [], [], 0
+    for i in range(2):
+        f, b1, b2, it = make_gp_problem(950 + i, m1, m2, t, 6)
+        parts.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(parts)
+    out = fit_gp_spp_batch(feats, [probs[0], probs[1], probs[0], probs[1]], training_iter=3)
+    for i in (0, 1):
+        for a, b in zip(out[i], out[i + 2]):
+            np.testing.assert_array_equal(a, b)
+    b1, b2, it = probs[0]
+    _compare(out[0], _oracle(feats, b1, b2, it, 3))

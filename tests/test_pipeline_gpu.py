@@ -258,3 +258,51 @@ def test_scenes_without_any_gp_fit_and_mixed_batches():
         assert torch.equal(x.cpu(), y.cpu())
     for x, y in zip(both[1], alone):
         assert torch.equal(x.cpu(), y.cpu())
+
+
+@pytest.mark.parametrize("n_points", [500_000, 2_000_000, 4_000_000])
+def test_s3dis_sizes_size_independent_properties(n_points):
+    """BASELINE configs[3]'s other sizes (N in {0.5, 1, 2, 4} M points; 1 M is compared with the oracle
+    above).  At these sizes the CPU oracle is out of reach, so the size-independent properties: repeatable bit for bit,
+    one value per superpoint, value ranges, point-order invariance (the pooled sums are exact integers), and the
+    partition's per-superpoint occupancy re-derived on the host for a sample of superpoints."""
+    import torch
+    from gapro_amd import gen_pseudo_label_gaussian_process
+    from gapro_amd.gen_ps_utils import getInstanceInfo
+    from gapro_amd.synth import make_scene
+
+    sc = make_scene(seed=5, n_points=n_points, n_objects=50, with_walls_json=False, obj_patch=150, plane_patch=400)
+    xyz = sc.aligned_xyz()
+    _, cls, box, vol, _ = getInstanceInfo(xyz, sc.inst, sc.sem)
+    kw = dict(coords_float=xyz, mask_feats=sc.default_feats().astype(np.float32), spp=sc.spp,
+              instance_cls=cls.astype(np.int64), instance_box=box.astype(np.float32),
+              instance_box_volume=vol.astype(np.float32), wall_box=[], wall_box_volume=[], instance_classes=13,
+              dataset_name="s3dis", ground_h=0.1, training_iter=50, thresh_spp_occu=0.999)
+    a = [o.cpu().numpy() for o in gen_pseudo_label_gaussian_process(**kw)]
+    b = [o.cpu().numpy() for o in gen_pseudo_label_gaussian_process(**kw)]
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    sem, ins, prob, mu, var = a
+    uniq, inv = np.unique(sc.spp, return_inverse=True)
+    assert len(sem) == n_points and len(mu) == len(uniq) == len(var)
+    for arr in (sem, ins, prob):
+        first = np.zeros(len(uniq), dtype=arr.dtype)
+        first[inv] = arr
+        np.testing.assert_array_equal(arr, first[inv])  # one value per superpoint
+    assert ins.max() < len(cls) and ((ins >= 0) | (ins == -100)).all()
+    assert set(np.unique(sem).tolist()) <= set(cls.tolist()) | {13, -100}  # a box's class, background, or ignore
+    assert ((prob >= 0) & (prob <= 1)).all() and np.isfinite(prob).all()
+    gp = mu != -100
+    assert gp.any() and (var[gp] > 0).all() and np.isfinite(mu[gp]).all() and (var[~gp] == -100).all()
+    # point-order invariance
+    perm = np.random.default_rng(1).permutation(n_points)
+    kwp = dict(kw, coords_float=xyz[perm], mask_feats=kw["mask_feats"][perm], spp=sc.spp[perm])
+    p = [o.cpu().numpy() for o in gen_pseudo_label_gaussian_process(**kwp)]
+    for x, y in zip(a[:3], p[:3]):
+        np.testing.assert_array_equal(x[perm], y)
+    np.testing.assert_array_equal(a[3], p[3])
+    np.testing.assert_array_equal(a[4], p[4])
+    # a superpoint labelled with an instance lies inside that instance's box (+- the 0.005 margin of the membership test)
+    lab = np.flatnonzero(ins >= 0)[:: max(1, n_points // 2000)]
+    bx = box[ins[lab]].astype(np.float64)
+    assert ((xyz[lab] >= bx[:, :3] - 0.0051) & (xyz[lab] <= bx[:, 3:] + 0.0051)).all()
