@@ -579,7 +579,7 @@ __device__ __noinline__ void gemm_wg(int rows16, int cols16, bool lower_only, co
         __syncthreads();
         rd(0, 0, fa0, fb0);
         int c = 0;
-        if (PF == 2) {
+        if constexpr (PF == 2) {
 #pragma nounroll
           for (; c + 1 < nch; c += 2) {  // the LDS stages and the register stages alternate by name
             chunk(I0t{}, I1t{}, c);
@@ -1736,35 +1736,46 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                        }, ring);
     __syncthreads();
     stamp(10);
-    // Pm = Phi(tril(L^T G_L)) -> GA buffer   (k >= max(i0, j0) = i0 on lower tiles)
-    // (workgroup-tiled products contract over the hull of a piece's block ranges: the rows T1 skips in Pm because Pm is
-    // lower triangular have to BE zero there, so Pm goes to a slot that nothing else writes -- G_LS never leaves the
-    // registers in this kernel -- instead of on top of G_A, whose upper blocks would still hold G_A)
-    gd* Pm = WG ? f.mat[B_GLS] : GA;
+    // G_Kzz (unsymmetrised) = L^-T Pm L^-1 with Pm = Phi(tril(L^T G_L)), associated as L^-T (Pm L^-1) (round 3):
+    // W = Pm L^-1 is a product of two lower-triangular matrices (M^3 / 3, lower-triangular itself), S = L^-T W then
+    // costs 2 M^3 / 3 -- 1.0 M^3 where (L^-T Pm) L^-1, rounds 1-2's order, spends 2/3 + 1: 0.67 of the step's 8.67 M^3
+    // less, and one full matrix less to write.  Same value in exact arithmetic; the rounding differs at 1e-16.
+    // Pm^T -> GA buffer (P operand of W: Pm^T[k][i] = Pm[i][k], non-zero for k <= i)   (k >= i0 on lower tiles)
+    gd* PmT = GA;
     product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                       [=](int i0, int j0, const d4& v) {
+                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+                         d4 pv;
+#pragma unroll
+                         for (int r = 0; r < 4; ++r) {
+                           const int i = i0 + lq + 4 * r, j = j0 + lr;
+                           pv[r] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                         }
+                         store_tile(pv, nullptr, PmT, Mp, i0, j0, tile);
+                       }, ring);
+    __syncthreads();
+    stamp(11);
+    // W = Pm L^-1 (lower) -> the G_LS slot, which nothing else writes in this kernel: its upper blocks ARE zero, as the
+    // hulls of S's ranges assume   (j0 <= k < i0 + tile: Pm^T[k][i] = 0 for k > i, L^-1[k][j] = 0 for k < j)
+    gd* Wm = f.mat[B_GLS];
+    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, PmT, f.mat[B_LI], Mp, nullptr,
+                       [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; },
                        [=](int i0, int j0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
 #pragma unroll
                          for (int r = 0; r < 4; ++r) {
                            const int i = i0 + lq + 4 * r, j = j0 + lr;
-                           Pm[(size_t)i * Mp + j] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                           Wm[(size_t)i * Mp + j] = (j <= i) ? v[r] : 0.0;
                          }
                        }, ring);
     __syncthreads();
-    stamp(11);
-    // T1 = LI^T Pm, stored transposed -> BMT buffer   (k >= max(i0, j0))
-    gd* T1T = BMT;
-    product<WG, TU, false, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
-                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
-                       [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); }, ring);
-    __syncthreads();
     stamp(12);
-    // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the A buffer   (k >= j0)
+    // S = L^-T W -> G in the BM buffer, G^T in the A buffer   (k >= max(i0, j0))
     gd* G = BM;
     gd* GT = A;
-    product<WG, TU, false, ORD_COLMAJOR>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
-                       [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+    product<WG, TU, false, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Wm, Mp, nullptr,
+                       [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                        [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j, tile); }, ring);
     __syncthreads();
     stamp(13);
@@ -2617,28 +2628,40 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
     __syncthreads();
     stamp(8);
 
-    // ---- tail: G_Kzz = LI^T Phi(L^T G_L) LI through global memory (three TN products)
+    // ---- tail: G_Kzz = LI^T Phi(L^T G_L) LI through global memory, three TN products associated as LI^T (Pm LI):
+    // W = Pm LI is lower (M^3 / 3), S = LI^T W costs 2 M^3 / 3 (fit_body of the staged kernel has the derivation)
     auto tail = [&](auto tu_tag) {
       constexpr int TU = decltype(tu_tag)::value;
       constexpr int TS = 16 * TU;
       const int mt = Mp / TS;
+      gd* PmT = Pm;   // Pm^T: the upper and diagonal tiles are written, W reads exactly those
+      gd* Wm = T1T;   // W: the lower and diagonal tiles are written, S reads exactly those
       gemm_tn<TU, false, 4>(mt, mt, true, f.mat[B_L], GLb, Mp, nullptr,
                          [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                         [=](int i0, int j0, const d4& v) {
+                           const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
+                           d4 pv;
+#pragma unroll
+                           for (int r = 0; r < 4; ++r) {
+                             const int i = i0 + g4 + 4 * r, j = j0 + c;
+                             pv[r] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                           }
+                           store_tile(pv, nullptr, PmT, Mp, i0, j0, tile);
+                         });
+      __syncthreads();
+      gemm_tn<TU, false, 4>(mt, mt, true, PmT, f.mat[B_LI], Mp, nullptr,
+                         [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; },
                          [=](int i0, int j0, const d4& v) {
                            const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
 #pragma unroll
                            for (int r = 0; r < 4; ++r) {
                              const int i = i0 + g4 + 4 * r, j = j0 + c;
-                             Pm[(size_t)i * Mp + j] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                             Wm[(size_t)i * Mp + j] = (j <= i) ? v[r] : 0.0;
                            }
                          });
       __syncthreads();
-      gemm_tn<TU, false, 4, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
+      gemm_tn<TU, false, 4, ORD_SHELLS>(mt, mt, false, f.mat[B_LI], Wm, Mp, nullptr,
                          [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
-                         [=](int i, int j, const d4& v) { store_tile(v, nullptr, T1T, Mp, i, j, tile); });
-      __syncthreads();
-      gemm_tn<TU, false, 4, ORD_COLMAJOR>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
-                         [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
                          [=](int i, int j, const d4& v) { store_tile(v, Gb, GTb, Mp, i, j, tile); });
       __syncthreads();
     };

@@ -1532,32 +1532,46 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     stamp(12);
     }
     gd* GL = BM;
-    // Pm = Phi(tril(L^T G_L)) -> GA buffer
-    gd* Pm = GA;
+    // G_Kzz (unsymmetrised) = L^-T Pm L^-1, Pm = Phi(tril(L^T G_L)), associated as L^-T (Pm L^-1): W = Pm L^-1 is a
+    // product of two lower-triangular matrices (M^3 / 3, lower itself), S = L^-T W costs 2 M^3 / 3 -- 1.0 M^3 where
+    // (L^-T Pm) L^-1 spends 2/3 + 1 (svgp_fit.hip has the same order).
+    // Pm^T -> GA buffer (the P operand of W: Pm^T[k][i] = Pm[i][k])
+    gd* PmT = GA;
     gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                      [=](int i0, int j0, const d4& v) {
+                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+                        d4 pv;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                          const int i = i0 + lq + 4 * r, j = j0 + lr;
+                          pv[r] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                        }
+                        store_tile(pv, (gd*)nullptr, PmT, Mp, i0, j0);
+                      });
+    cbar();
+    stamp(13);
+    // W = Pm L^-1 (lower tiles only; zeros above the diagonal inside them) -> BMT buffer.  S reads W[k][j] for
+    // k >= max(i0, j0) only, i.e. lower tiles: what the upper tiles of the buffer hold does not matter.
+    // (j0 <= k < i0 + tile: Pm^T[k][i] = 0 for k > i, L^-1[k][j] = 0 for k < j)
+    gd* Wm = BMT;
+    gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, PmT, f.mat[B_LI], Mp, nullptr,
+                      [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; },
                       [=](int i0, int j0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                           const int i = i0 + lq + 4 * r, j = j0 + lr;
-                          Pm[(size_t)i * Mp + j] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                          Wm[(size_t)i * Mp + j] = (j <= i) ? v[r] : 0.0;
                         }
                       });
     cbar();
-    stamp(13);
-    // T1 = LI^T Pm, stored transposed -> BMT buffer
-    gd* T1T = BMT;
-    gemm_tn<TU, false, gd, gd, ORD_SHELLS, true>(mt, mt, false, f.mat[B_LI], Pm, Mp, nullptr,
-                      [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
-                      [=](int i, int j, const d4& v) { store_tile(v, (gd*)nullptr, T1T, Mp, i, j); });
-    cbar();
     stamp(14);
-    // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer
+    // S = L^-T W -> G in the BM buffer, G^T in the GKXT buffer
     gd* G = BM;
     gd* GT = GKXT;
-    gemm_tn<TU, false, gd, gd, ORD_COLMAJOR, true>(mt, mt, false, T1T, f.mat[B_LI], Mp, nullptr,
-                      [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+    gemm_tn<TU, false, gd, gd, ORD_SHELLS, true>(mt, mt, false, f.mat[B_LI], Wm, Mp, nullptr,
+                      [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; },
                       [=](int i, int j, const d4& v) { store_tile(v, G, GT, Mp, i, j); });
     cbar();
     stamp(15);

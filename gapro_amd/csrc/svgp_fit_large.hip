@@ -609,25 +609,28 @@ __device__ void fit_body(const Fit& f, const gapro_fit_options& opt, Shared& sh,
                 [=](int i, int j, double v) { GL[(size_t)i * Mp + j] = (j <= i) ? -v : 0.0; });
     __syncthreads();
     stamp(10);
-    // Pm = Phi(tril(L^T G_L)) -> GA buffer   (k >= max(i0, j0) = i0 on lower tiles)
-    double* Pm = GA;
+    // G_Kzz (unsymmetrised) = L^-T Pm L^-1, Pm = Phi(tril(L^T G_L)), associated as L^-T (Pm L^-1) like the MFMA kernels
+    // (svgp_fit.hip): W = Pm L^-1 is lower (M^3 / 3), S = L^-T W costs 2 M^3 / 3.
+    // Pm^T -> GA buffer   (k >= i0 on lower tiles)
+    double* PmT = GA;
     gemm_tn<TU>(mt, mt, true, f.mat[B_L], GL, Mp, [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
                 NoScale(),
-                [=](int i, int j, double v) { Pm[(size_t)i * Mp + j] = (j < i) ? v : (j == i ? 0.5 * v : 0.0); });
+                [=](int i, int j, double v) { PmT[(size_t)j * Mp + i] = (j < i) ? v : (j == i ? 0.5 * v : 0.0); });
     __syncthreads();
     stamp(11);
-    // T1 = LI^T Pm, stored transposed -> BMT buffer   (k >= max(i0, j0))
-    double* T1T = BMT;
-    gemm_tn<TU>(mt, mt, false, f.mat[B_LI], Pm, Mp,
-                [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; }, NoScale(),
-                [=](int i, int j, double v) { T1T[(size_t)j * Mp + i] = v; });
+    // W = Pm L^-1 (lower tiles, zeros above the diagonal inside them) -> BMT buffer   (j0 <= k < i0 + tile)
+    double* Wm = BMT;
+    gemm_tn<TU>(mt, mt, true, PmT, f.mat[B_LI], Mp,
+                [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; }, NoScale(),
+                [=](int i, int j, double v) { Wm[(size_t)i * Mp + j] = (j <= i) ? v : 0.0; });
     __syncthreads();
     stamp(12);
-    // G_Kzz (unsymmetrised) = T1 LI -> G in the BM buffer, G^T in the GKXT buffer   (k >= j0)
+    // S = L^-T W -> G in the BM buffer, G^T in the GKXT buffer   (k >= max(i0, j0): lower tiles of W only)
     double* G = BM;
     double* GT = GKXT;
-    gemm_tn<TU>(mt, mt, false, T1T, f.mat[B_LI], Mp, [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
-                NoScale(), [=](int i, int j, double v) { G[(size_t)i * Mp + j] = v; GT[(size_t)j * Mp + i] = v; });
+    gemm_tn<TU>(mt, mt, false, f.mat[B_LI], Wm, Mp,
+                [=](int i0, int j0, int* lo, int* hi) { *lo = i0 > j0 ? i0 : j0; *hi = Mp; }, NoScale(),
+                [=](int i, int j, double v) { G[(size_t)i * Mp + j] = v; GT[(size_t)j * Mp + i] = v; });
     __syncthreads();
     stamp(13);
     // kernel weights: Wzz = sym(G) o (s Ezz) -> BM buffer in place, Wzx = G_KX o KX -> GKX in place;
