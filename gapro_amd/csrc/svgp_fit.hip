@@ -1490,6 +1490,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   gd* BMT = f.mat[B_BMT];
   gd* GA = f.mat[B_GA];
   gd* GKXT = f.mat[B_GKXT];
+  gd* GAT = GKXT;  // G_A^T lives in the G_KX^T slot until G_KX is formed
   gd* vm = f.vec[V_M];
   gd* gmu = f.vec[V_GMU];
   gd* gv = f.vec[V_GV];
@@ -1662,11 +1663,12 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                          const int n = n0 + lr;
                          const double gvn = gv[n], gmn = gmu[n];
+                         d4 ga;
 #pragma unroll
                          for (int r = 0; r < 4; ++r) {
                            const int i = i0 + lq + 4 * r;
                            const double a = A[(size_t)i * Mp + n];
-                           GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
+                           ga[r] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
                            double pg = a * gmn;
                            pg += __shfl_xor(pg, 1, 64);
                            pg += __shfl_xor(pg, 2, 64);
@@ -1677,6 +1679,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                              else gpart_g[(size_t)(n0 >> 4) * Mp + i] = pg;
                            }
                          }
+                         store_tile(ga, GA, GAT, Mp, i0, n0, tile);
                        }, ring);
     __syncthreads();
     for (int i = threadIdx.x; i < Mp; i += NT) {
@@ -1717,44 +1720,35 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                       }, ring);
     __syncthreads();
     stamp(8);
-    // G_KX = LI^T G_A   (P = LI[k][i], non-zero for k >= i)
-    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
-                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                       [=](int i, int n, const d4& v) { store_tile(v, nullptr, GKXT, Mp, i, n, tile); }, ring);
-    __syncthreads();
-    stamp(9);
-    // G_L = -tril(G_KX A^T)  -> BM buffer (lower tiles; strict upper of diagonal tiles zeroed)
-    gd* GL = BM;
-    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
-                       [=](int i0, int j0, const d4& v) {
-                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
-#pragma unroll
-                         for (int r = 0; r < 4; ++r) {
-                           const int i = i0 + lq + 4 * r, j = j0 + lr;
-                           GL[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
-                         }
-                       }, ring);
-    __syncthreads();
-    stamp(10);
-    // G_Kzz (unsymmetrised) = L^-T Pm L^-1 with Pm = Phi(tril(L^T G_L)), associated as L^-T (Pm L^-1) (round 3):
-    // W = Pm L^-1 is a product of two lower-triangular matrices (M^3 / 3, lower-triangular itself), S = L^-T W then
-    // costs 2 M^3 / 3 -- 1.0 M^3 where (L^-T Pm) L^-1, rounds 1-2's order, spends 2/3 + 1: 0.67 of the step's 8.67 M^3
-    // less, and one full matrix less to write.  Same value in exact arithmetic; the rounding differs at 1e-16.
-    // Pm^T -> GA buffer (P operand of W: Pm^T[k][i] = Pm[i][k], non-zero for k <= i)   (k >= i0 on lower tiles)
-    gd* PmT = GA;
-    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
-                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+    // The Cholesky backward pass needs Pm = Phi(L^T G_L) with G_L = -tril(L^-T G_A A^T) = -tril(G_KX A^T).  Row i of
+    // L^T X only reads rows k >= i of X, so the lower triangle of L^T tril(X) is the lower triangle of L^T X, and with
+    // X = -L^-T G_A A^T:   Pm = Phi(-G_A A^T)   -- no G_L, no product with L^T (rounds 1-2 and the first half of round 3
+    // formed G_L and L^T G_L: 1.33 M^3 where this is 1.0 M^3, one phase and one matrix write more).
+    // Pm^T -> BM buffer (B is dead after G_A; P operand of W: Pm^T[k][i] = Pm[i][k], non-zero for k <= i)
+    gd* PmT = BM;
+    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, GAT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                        [=](int i0, int j0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                          d4 pv;
 #pragma unroll
                          for (int r = 0; r < 4; ++r) {
                            const int i = i0 + lq + 4 * r, j = j0 + lr;
-                           pv[r] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                           pv[r] = (j < i) ? -v[r] : (j == i ? -0.5 * v[r] : 0.0);
                          }
                          store_tile(pv, nullptr, PmT, Mp, i0, j0, tile);
                        }, ring);
     __syncthreads();
+    stamp(9);
+    // G_KX^T = G_A^T LI (only the transposed form is used: kernel gradients) -> over G_A^T; formed as the product whose
+    // output IS the transposed matrix, so that the epilogue is plain row stores   (Q = LI[k][i], non-zero for k >= i)
+    product<WG, TU, false, ORD_COLMAJOR>(mt, mt, false, GA, f.mat[B_LI], Mp, nullptr,
+                       [=](int, int i0, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                       [=](int n, int i, const d4& v) { store_tile(v, GKXT, nullptr, Mp, n, i, tile); }, ring);
+    __syncthreads();
+    stamp(10);
+    // G_Kzz (unsymmetrised) = L^-T Pm L^-1, associated as L^-T (Pm L^-1) (round 3): W = Pm L^-1 is a product of two
+    // lower-triangular matrices (M^3 / 3, lower-triangular itself), S = L^-T W then costs 2 M^3 / 3 -- 1.0 M^3 where
+    // (L^-T Pm) L^-1, rounds 1-2's order, spends 2/3 + 1.  Same value in exact arithmetic; the rounding differs at 1e-16.
     stamp(11);
     // W = Pm L^-1 (lower) -> the G_LS slot, which nothing else writes in this kernel: its upper blocks ARE zero, as the
     // hulls of S's ranges assume   (j0 <= k < i0 + tile: Pm^T[k][i] = 0 for k > i, L^-1[k][j] = 0 for k < j)
@@ -2241,7 +2235,7 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
 // the 256-thread build): a function of its own so that its registers (a tile in flight, a tile being updated, the
 // division and square-root sequences) are allocated apart from the strip loop, whose accumulator tiles arrive here
 // by value.  R = rounds of the workgroup; a slot past the wave's last tile works on the wave's first tile with
-// its stores redirected to Pm, which is dead until the first tail product rewrites it in full.
+// its stores redirected to the B slot of the workspace, which this kernel never uses (its B lives in LDS).
 template <int R>
 __device__ __noinline__ void adam_ls_tiles(d4 g0, d4 g1, d4 g2, d4 g3, d4 g4, double Nd, double step_size, double bc2s,
                                            ldsd* tile) {
@@ -2251,7 +2245,7 @@ __device__ __noinline__ void adam_ls_tiles(d4 g0, d4 g1, d4 g2, d4 g3, d4 g4, do
   gd* LST = f.mat[B_LST];
   gd* MLS = f.mat[B_MLS];
   gd* VLS = f.mat[B_VLS];
-  gd* Pm = f.mat[B_GA];
+  gd* Pm = f.mat[B_BM];  // the dead buffer
   const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
   const d4 gls[5] = {g0, g1, g2, g3, g4};
@@ -2339,8 +2333,10 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   gd* MLS = f.mat[B_MLS];
   gd* VLS = f.mat[B_VLS];
 #endif
-  gd* GLb = f.mat[B_BM];    // G_L (lower) for the tail products
-  gd* Pm = f.mat[B_GA];
+#if GAPRO_NT < 320
+  gd* dead = f.mat[B_BM];   // never read: target of the redirected stores of the straight-line Adam code
+#endif
+  gd* Pm = f.mat[B_GA];     // Pm^T for the tail products
   gd* T1T = f.mat[B_BMT];
   gd* Gb = f.mat[B_A];
   gd* GTb = f.mat[B_AT];
@@ -2471,20 +2467,23 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
 #pragma unroll
         for (int r = 0; r < 4; ++r) Bs[(16 * rb + g4 + 4 * r) * RS + 16 * ct + c] = v[r];
       });
-      __syncthreads();
-      stamp(15);
-      // ---- G_L -= G_KX A^T (register tiles)
+      // ---- L^T G_L -= G_A A^T (register tiles).  The Cholesky backward pass needs Phi(L^T G_L) with
+      // G_L = -tril(L^-T G_A A^T); row i of L^T X reads rows k >= i of X only, so the lower triangle of L^T tril(X) is
+      // the lower triangle of L^T X = -G_A A^T: no G_L, no product with L^T (the staged kernel has the same identity).
+      // Reads the G_A and A strips, not G_KX: no barrier between the G_KX product and this.
 #pragma unroll
       for (int q = 0; q < kAccTiles; ++q) {
         const int t = wave + NW * q;
         if (t < nt_acc) {
-          const ldsd* pa = Bs + offA[q];
+          const ldsd* pa = Cs + offA[q];
           const ldsd* pb = As + offB[q];
 #pragma unroll
           for (int ks = 0; ks < SW / 4; ++ks)
             gl[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * ks], pb[4 * ks], gl[q], 0, 0, 0);
         }
       }
+      __syncthreads();
+      stamp(15);
       // ---- G_KX^T rows of the strip -> global (the only intermediate that leaves the chip): the kernel
       // gradient pass after the loop reads G_KX[k][n] as GKXT[n][k], contiguous in k
       for (int idx = threadIdx.x; idx < Mp * nc; idx += NT) {
@@ -2556,13 +2555,13 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         if (q + 1 < R) load_tile(q + 1, lsn, m1n, m2n);
         int ti, tj;
         const bool valid = slot_tile(q, &ti, &tj);
-        gd* wLS = uni_ptr(valid ? LS : Pm);
-        gd* wMLS = uni_ptr(valid ? MLS : Pm);
-        gd* wVLS = uni_ptr(valid ? VLS : Pm);
-        gd* wGL = uni_ptr(valid ? GLb : Pm);
-        gd* wLST = uni_ptr(valid ? LST : Pm);
+        gd* wLS = uni_ptr(valid ? LS : dead);
+        gd* wMLS = uni_ptr(valid ? MLS : dead);
+        gd* wVLS = uni_ptr(valid ? VLS : dead);
+        gd* wPmT = uni_ptr(valid ? Pm : dead);
+        gd* wLST = uni_ptr(valid ? LST : dead);
         const int j = 16 * tj + lr;
-        d4 newv;
+        d4 newv, pv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * ti + lq + 4 * r;
@@ -2577,9 +2576,10 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
           wVLS[o] = act ? m2 : m2v[r];
           wLS[o] = act ? lnew : lsv[r];
           newv[r] = act ? lnew : 0.0;
-          wGL[o] = (j <= i) ? gl[q][r] : 0.0;
+          pv[r] = (j < i) ? gl[q][r] : (j == i ? 0.5 * gl[q][r] : 0.0);
         }
         store_tile(newv, nullptr, wLST, Mp, 16 * ti, 16 * tj, tile);
+        store_tile(pv, nullptr, wPmT, Mp, 16 * ti, 16 * tj, tile);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           lsv[r] = lsn[r];
@@ -2609,7 +2609,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         default: adam_ls_tiles<5>(gls[0], gls[1], gls[2], gls[3], gls[4], Nd, step_size, bc2s, tile); break;
       }
     }
-    // G_L tiles -> global for the tail products
+    // Pm^T = Phi(L^T G_L)^T tiles -> global for the tail products
 #pragma unroll
     for (int q = 0; q < kAccTiles; ++q) {
       const int t = wave + NW * q;
@@ -2617,38 +2617,27 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
         int ti, tj;
         lower_tile(t, &ti, &tj);
         const int j = 16 * tj + lr;
+        d4 pv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * ti + lq + 4 * r;
-          GLb[(size_t)i * Mp + j] = (j <= i) ? gl[q][r] : 0.0;
+          pv[r] = (j < i) ? gl[q][r] : (j == i ? 0.5 * gl[q][r] : 0.0);
         }
+        store_tile(pv, nullptr, Pm, Mp, 16 * ti, 16 * tj, tile);
       }
     }
 #endif
     __syncthreads();
     stamp(8);
 
-    // ---- tail: G_Kzz = LI^T Phi(L^T G_L) LI through global memory, three TN products associated as LI^T (Pm LI):
-    // W = Pm LI is lower (M^3 / 3), S = LI^T W costs 2 M^3 / 3 (fit_body of the staged kernel has the derivation)
+    // ---- tail: G_Kzz = LI^T Pm LI through global memory, Pm = Phi(L^T G_L) from the register tiles above; two TN
+    // products, associated as LI^T (Pm LI): W = Pm LI is lower (M^3 / 3), S = LI^T W costs 2 M^3 / 3
     auto tail = [&](auto tu_tag) {
       constexpr int TU = decltype(tu_tag)::value;
       constexpr int TS = 16 * TU;
       const int mt = Mp / TS;
       gd* PmT = Pm;   // Pm^T: the upper and diagonal tiles are written, W reads exactly those
       gd* Wm = T1T;   // W: the lower and diagonal tiles are written, S reads exactly those
-      gemm_tn<TU, false, 4>(mt, mt, true, f.mat[B_L], GLb, Mp, nullptr,
-                         [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                         [=](int i0, int j0, const d4& v) {
-                           const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
-                           d4 pv;
-#pragma unroll
-                           for (int r = 0; r < 4; ++r) {
-                             const int i = i0 + g4 + 4 * r, j = j0 + c;
-                             pv[r] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
-                           }
-                           store_tile(pv, nullptr, PmT, Mp, i0, j0, tile);
-                         });
-      __syncthreads();
       gemm_tn<TU, false, 4>(mt, mt, true, PmT, f.mat[B_LI], Mp, nullptr,
                          [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; },
                          [=](int i0, int j0, const d4& v) {

@@ -1280,6 +1280,9 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
   gf* BMf = (gf*)BM;
   gf* BMTf = (gf*)BMT;
   gf* GAf = (gf*)GA;
+  gd* GAT = f.mat[B_GLS];  // G_A^T: the G_LS slot is otherwise unused here (G_LS never leaves the registers)
+  gf* GATf = (gf*)GAT;
+  gd* PmT = BM;            // Phi(L^T G_L)^T: B is dead once G_A is formed
   const int ct = cl_tid(), CT = cl_threads();
   double last_loss = 0.0;
 
@@ -1414,12 +1417,14 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                               const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                               const int n = n0 + lr;
                               const float gvn = (float)gv[n], gmn = (float)gmu[n];
+                              f4 ga;
 #pragma unroll
                               for (int r = 0; r < 4; ++r) {
                                 const int i = i0 + 4 * lq + r;  // float32 C layout
                                 const float a = Af[(size_t)i * Mp + n];
-                                GAf[(size_t)i * Mp + n] = 2.0f * gvn * v[r] + (float)vm[i] * gmn - 2.0f * a * gvn;
+                                ga[r] = 2.0f * gvn * v[r] + (float)vm[i] * gmn - 2.0f * a * gvn;
                               }
+                              store_tile_f32(ga, GAf, GATf, Mp, i0, n0);
                             });
       cbar();
       stamp(10);
@@ -1451,23 +1456,23 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       // G_KX = LI^T G_A in float64 (the float32 G_A enters through .double())
       gemm_tn<TU, false, gd, gf, ORD_ROWMAJOR, true>(mt, mt, false, f.mat[B_LI], GAf, Mp, nullptr,
                                 [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                                [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
-      cbar();
-      stamp(11);
-      // G_L = -tril(G_KX A^T) in float64 -> the whole B slot (the float32 B in its first half is dead)
-      gd* GLm = BM;
-      gemm_tn<TU, false, gd, gf, ORD_ROWMAJOR, true>(mt, mt, true, GKXT, ATf, Mp, nullptr,
+                                [=](int i, int n, const d4& v) { store_tile(v, GKX, (gd*)nullptr, Mp, i, n); });
+      // Pm = Phi(L^T G_L) = Phi(-G_A A^T) in float64 (see the float64 branch), transposed -> the whole B slot (the
+      // float32 B in its first half is dead)
+      gemm_tn<TU, false, gf, gf, ORD_ROWMAJOR, true>(mt, mt, true, GATf, ATf, Mp, nullptr,
                                 [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                                 [=](int i0, int j0, const d4& v) {
                                   const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+                                  d4 pv;
 #pragma unroll
                                   for (int r = 0; r < 4; ++r) {
                                     const int i = i0 + lq + 4 * r, j = j0 + lr;
-                                    GLm[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
+                                    pv[r] = (j < i) ? -v[r] : (j == i ? -0.5 * v[r] : 0.0);
                                   }
+                                  store_tile(pv, (gd*)nullptr, PmT, Mp, i0, j0);
                                 });
       cbar();
-      stamp(12);
+      stamp(11);
     } else {
     col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
     gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC, true>(mt, mt, false, LST, BM, Mp, nullptr,
@@ -1476,12 +1481,14 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                         const int n = n0 + lr;
                         const double gvn = gv[n], gmn = gmu[n];
+                        d4 ga;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                           const int i = i0 + lq + 4 * r;
                           const double a = A[(size_t)i * Mp + n];
-                          GA[(size_t)i * Mp + n] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
+                          ga[r] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
                         }
+                        store_tile(ga, GA, GAT, Mp, i0, n0);
                       });
     cbar();
     stamp(10);
@@ -1514,43 +1521,28 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
     // G_KX = LI^T G_A
     gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
-                      [=](int i, int n, const d4& v) { store_tile(v, GKX, GKXT, Mp, i, n); });
-    cbar();
-    stamp(11);
-    // G_L = -tril(G_KX A^T) -> BM buffer
-    gd* GLd = BM;
-    gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, GKXT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
-                      [=](int i0, int j0, const d4& v) {
-                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                          const int i = i0 + lq + 4 * r, j = j0 + lr;
-                          GLd[(size_t)i * Mp + j] = (j <= i) ? -v[r] : 0.0;
-                        }
-                      });
-    cbar();
-    stamp(12);
-    }
-    gd* GL = BM;
-    // G_Kzz (unsymmetrised) = L^-T Pm L^-1, Pm = Phi(tril(L^T G_L)), associated as L^-T (Pm L^-1): W = Pm L^-1 is a
-    // product of two lower-triangular matrices (M^3 / 3, lower itself), S = L^-T W costs 2 M^3 / 3 -- 1.0 M^3 where
-    // (L^-T Pm) L^-1 spends 2/3 + 1 (svgp_fit.hip has the same order).
-    // Pm^T -> GA buffer (the P operand of W: Pm^T[k][i] = Pm[i][k])
-    gd* PmT = GA;
-    gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, f.mat[B_L], GL, Mp, nullptr,
-                      [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },
+                      [=](int i, int n, const d4& v) { store_tile(v, GKX, (gd*)nullptr, Mp, i, n); });
+    // The Cholesky backward pass needs Pm = Phi(L^T G_L) with G_L = -tril(L^-T G_A A^T).  Row i of L^T X only reads
+    // rows k >= i of X, so the lower triangle of L^T tril(X) is the lower triangle of L^T X = -G_A A^T:
+    //   Pm = Phi(-G_A A^T)   -- no G_L, no product with L^T, and two cluster barriers fewer per step (rounds 1-2 formed
+    // G_L = -tril(G_KX A^T) and L^T G_L in phases of their own).  Stored transposed (the P operand of W) -> B buffer.
+    gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, GAT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
                       [=](int i0, int j0, const d4& v) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                         d4 pv;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                           const int i = i0 + lq + 4 * r, j = j0 + lr;
-                          pv[r] = (j < i) ? v[r] : (j == i ? 0.5 * v[r] : 0.0);
+                          pv[r] = (j < i) ? -v[r] : (j == i ? -0.5 * v[r] : 0.0);
                         }
                         store_tile(pv, (gd*)nullptr, PmT, Mp, i0, j0);
                       });
     cbar();
-    stamp(13);
+    stamp(11);
+    }
+    // G_Kzz (unsymmetrised) = L^-T Pm L^-1, associated as L^-T (Pm L^-1): W = Pm L^-1 is a product of two
+    // lower-triangular matrices (M^3 / 3, lower itself), S = L^-T W costs 2 M^3 / 3 -- 1.0 M^3 where (L^-T Pm) L^-1
+    // spends 2/3 + 1 (svgp_fit.hip has the same order).
     // W = Pm L^-1 (lower tiles only; zeros above the diagonal inside them) -> BMT buffer.  S reads W[k][j] for
     // k >= max(i0, j0) only, i.e. lower tiles: what the upper tiles of the buffer hold does not matter.
     // (j0 <= k < i0 + tile: Pm^T[k][i] = 0 for k > i, L^-1[k][j] = 0 for k < j)
