@@ -58,6 +58,7 @@ constexpr int kRedSlots = 8;            // values reduced across row groups per 
 #define GAPRO_WAVES_PER_SIMD 4           // 2 workgroups of 8 waves per CU -> 128 VGPRs per lane
 #endif
 constexpr int kWavesPerSimd = GAPRO_WAVES_PER_SIMD;
+constexpr int kKminMaxMp = 256;         // largest M_p with the copy-free product forms (fit_body's KMIN)
 #ifndef GAPRO_GEMM_RING
 #define GAPRO_GEMM_RING 2
 #endif
@@ -247,7 +248,20 @@ enum { ORD_ROWMAJOR = 0,   // equal ranges, or ranges shrinking with the tile ro
 // with the tile order; 256 concurrent fits stream ~100 MB per Adam step each at M = 384, together the ~6.3 TB/s the
 // HBM delivers), so the bytes per block are what a product costs.  The extents are then given in 32 x 32 units and an
 // odd count leaves a last row / column of 32 x 32 tiles, dealt after the full ones.
-template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, bool TRIM = false, typename KRange, typename Epi>
+// PK / QK (round 3): the operand is stored with the contraction index along its ROWS' contiguous direction -- P[i][k]
+// instead of P[k][i], Q[j][k] instead of Q[k][j] -- so that products of the forms X Y^T and X Y run on the matrices as
+// they are and nobody has to write (and read back) a transposed copy: A^T, B^T, G_A^T, Pm^T each cost a full matrix
+// of HBM writes per Adam step plus a pass through the waves' LDS transpose tiles.  A lane fetches two consecutive k of
+// its row with one 16-byte load (64 contiguous bytes per row and instruction); with any operand in this form the k of
+// MFMA step e = 0, 1 of a block of 8 is k0 + 2 (lane >> 4) + e for BOTH operands (a k-major operand then reads rows
+// k0 + 2 lq and k0 + 2 lq + 1) -- a fixed permutation of the contraction order inside a block, so these products do not
+// have the bits of the k-major form, but every product has ONE form in all kernels' variants that must agree.
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) d2 lds_d2;
+typedef __attribute__((address_space(1))) d2 g_d2;
+
+template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, bool TRIM = false, int PK = 0, int QK = 0,
+          typename KRange, typename Epi>
 __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
@@ -271,7 +285,8 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
   // time).
   auto tile = [&](auto tv_tag, int i0, int j0) {
     constexpr int TV = decltype(tv_tag)::value;
-    constexpr int KSV = TV >= 4 ? 1 : KS, KB = 4 * KSV;
+    constexpr bool MINOR = PK || QK;
+    constexpr int KSV = MINOR ? 2 : (TV >= 4 ? 1 : KS), KB = 4 * KSV;
     int klo, khi;
     kr(i0, j0, &klo, &khi);
     klo = uni(klo);
@@ -285,20 +300,49 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
     for (int u = 0; u < TV; ++u)
 #pragma unroll
       for (int v = 0; v < TV; ++v) acc[u][v] = (d4){0.0, 0.0, 0.0, 0.0};
-    const gd* pbase = P + (size_t)lq * ld + i0 + lr;
-    const gd* qbase = Q + (size_t)lq * ld + j0 + lr;
+    const gd* pbase = PK ? P + (size_t)(i0 + lr) * ld + 2 * lq : P + (size_t)(MINOR ? 2 * lq : lq) * ld + i0 + lr;
+    const gd* qbase = QK ? Q + (size_t)(j0 + lr) * ld + 2 * lq : Q + (size_t)(MINOR ? 2 * lq : lq) * ld + j0 + lr;
     double a0[KSV][TV], b0[KSV][TV], a1[KSV][TV], b1[KSV][TV];
     double s0[KSV], s1[KSV];
     auto load_block = [&](int k, double (&a)[KSV][TV], double (&b)[KSV][TV], double (&sc)[KSV]) {
+      if constexpr (MINOR) {
 #pragma unroll
-      for (int s = 0; s < KSV; ++s) {
-        const gd* pr = pbase + (size_t)(k + 4 * s) * ld;
-        const gd* qr = qbase + (size_t)(k + 4 * s) * ld;
+        for (int u = 0; u < TV; ++u) {
+          if constexpr (PK) {
+            const d2 t = *(const g_d2*)(pbase + (size_t)(16 * u) * ld + k);
+            a[0][u] = t[0];
+            a[1][u] = t[1];
+          } else {
+            a[0][u] = pbase[(size_t)k * ld + 16 * u];
+            a[1][u] = pbase[(size_t)(k + 1) * ld + 16 * u];
+          }
+        }
 #pragma unroll
-        for (int u = 0; u < TV; ++u) a[s][u] = pr[16 * u];
+        for (int v = 0; v < TV; ++v) {
+          if constexpr (QK) {
+            const d2 t = *(const g_d2*)(qbase + (size_t)(16 * v) * ld + k);
+            b[0][v] = t[0];
+            b[1][v] = t[1];
+          } else {
+            b[0][v] = qbase[(size_t)k * ld + 16 * v];
+            b[1][v] = qbase[(size_t)(k + 1) * ld + 16 * v];
+          }
+        }
+        if (SCALE) {
+          sc[0] = qscale[k + 2 * lq];
+          sc[1] = qscale[k + 2 * lq + 1];
+        }
+      } else {
 #pragma unroll
-        for (int v = 0; v < TV; ++v) b[s][v] = qr[16 * v];
-        if (SCALE) sc[s] = qscale[k + 4 * s + lq];
+        for (int s = 0; s < KSV; ++s) {
+          const gd* pr = pbase + (size_t)(k + 4 * s) * ld;
+          const gd* qr = qbase + (size_t)(k + 4 * s) * ld;
+#pragma unroll
+          for (int u = 0; u < TV; ++u) a[s][u] = pr[16 * u];
+#pragma unroll
+          for (int v = 0; v < TV; ++v) b[s][v] = qr[16 * v];
+          if (SCALE) sc[s] = qscale[k + 4 * s + lq];
+        }
       }
     };
     auto mma_block = [&](double (&a)[KSV][TV], double (&b)[KSV][TV], double (&sc)[KSV]) {
@@ -400,10 +444,6 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 // LDS image of a chunk: row k at k * 128 doubles, and inside a row the element i at i ^ (16 (k & 1)): the two k rows
 // a 32-lane group of a fragment read touches land in different halves of the 256-byte bank row (conflict-free
 // ds_read_b64) without padding.
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) d2 lds_d2;
-typedef __attribute__((address_space(1))) d2 g_d2;
-
 template <bool SCALE, bool TRIM, int PF, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_wg(int rows16, int cols16, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
@@ -1411,11 +1451,13 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
 
 // one product of the staged kernel: workgroup-tiled through LDS (WG; extents and ranges per 16 x 16 block) or one
 // tile per wave from global memory (gemm_tn)
-template <int WG, int TU, bool SCALE, int ORD, typename KRange, typename Epi>
+// (PK / QK: operands with the contraction index along their rows, see gemm_tn; lower-triangular outputs only -- the
+// workgroup-tiled form takes k-major operands)
+template <int WG, int TU, bool SCALE, int ORD, int PK = 0, int QK = 0, typename KRange, typename Epi>
 __device__ inline void product(int mo, int no, bool lower, const gd* __restrict__ P, const gd* __restrict__ Q, int ld,
                                const gd* __restrict__ qs, KRange kr, Epi epi, ldsd* ring) {
   if constexpr (WG == 0) {
-    gemm_tn<TU, SCALE, 2, ORD, true>(mo, no, lower, P, Q, ld, qs, kr, epi);
+    gemm_tn<TU, SCALE, 2, ORD, true, PK, QK>(mo, no, lower, P, Q, ld, qs, kr, epi);
   } else {
     // Workgroup-tiled products take the part of the output that whole 128 x 128 tiles cover; what is left at the
     // matrix edge (an L of up to 96 rows / columns, M_p a multiple of 32) goes to the per-wave products as 32 x 32
@@ -1425,15 +1467,16 @@ __device__ inline void product(int mo, int no, bool lower, const gd* __restrict_
     // a multiple of 32 here)
     const int rows = (16 * mo + 31) / 32 * 32, cols = (16 * no + 31) / 32 * 32;
     const int R = rows / kWgTile * kWgTile, Cc = cols / kWgTile * kWgTile;
-    if (R > 0 && Cc > 0 && !lower) {
-      gemm_wg<SCALE, true, WG>(R / 16, Cc / 16, false, P, Q, ld, qs, kr, epi, ring);
+    constexpr bool kMajor = !(PK || QK);  // the workgroup-tiled form takes k-major operands only
+    if constexpr (kMajor) {
+      if (R > 0 && Cc > 0 && !lower) gemm_wg<SCALE, true, WG>(R / 16, Cc / 16, false, P, Q, ld, qs, kr, epi, ring);
     }
     auto strip_t = [&](auto tu_tag, int r0, int c0, int nr, int nc, bool low) {
       constexpr int TUS = decltype(tu_tag)::value;  // 2: 32 x 32 wave tiles, 4: 64 x 64 (extents still in 32-units)
       if (nr <= 0 || nc <= 0) return;
       // (row-major tile order: the shell order of some products enumerates SQUARE tile grids only)
-      gemm_tn<TUS, SCALE, 2, ORD_ROWMAJOR, true>(
-          nr / 32, nc / 32, low, P + r0, Q + c0, ld, qs,
+      gemm_tn<TUS, SCALE, 2, ORD_ROWMAJOR, true, PK, QK>(
+          nr / 32, nc / 32, low, PK ? P + (size_t)r0 * ld : P + r0, QK ? Q + (size_t)c0 * ld : Q + c0, ld, qs,
           [=](int i0, int j0, int* lo, int* hi) {
             int l0, h0, l1, h1;  // a wave tile's range: the hull of its 16 x 16 blocks' (kr is monotone; gemm_tn trims hi)
             kr(r0 + i0, c0 + j0, &l0, &h0);
@@ -1460,15 +1503,23 @@ __device__ inline void product(int mo, int no, bool lower, const gd* __restrict_
       strip(0, 0, rows, cols, true);
       return;
     }
-    {
+    if constexpr (kMajor) {
       strip(R, 0, rows - R, cols, false);   // bottom strip, full width
       strip(0, Cc, R, cols - Cc, false);    // right strip above it
+    } else {
+      strip(0, 0, rows, cols, false);
     }
   }
 }
 
 // WG: 0 = one tile per wave (gemm_tn), 2 / 4 = workgroup-tiled products with that many register stages (gemm_wg)
-template <int TU, int DMAX, int DC, int WG = 0>
+// KMIN: the products that contract over the columns of A, B, G_A and Pm read those matrices as they are (gemm_tn's PK /
+// QK forms) and no transposed copy of them is written -- the build for M_p <= 256, where two workgroups share a CU and a
+// launch of such fits sits on the HBM roof: 160: +4 .. 8 %, 256: +5 .. 7 % fits/s.  Those loads touch 16 half cache
+// lines per instruction where the k-major form touches 4 whole ones, and the lower-triangular products are 25 .. 30 %
+// slower with them; with one workgroup per CU (M_p >= 288) that costs what the copies cost (320: -1 %, 384: -3 %,
+// 448: +2 %), so the larger fits keep the copies.
+template <int TU, int DMAX, int DC, int WG = 0, bool KMIN = false>
 __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* scratch, const gapro_fit_desc& desc, float* __restrict__ o_probs, float* __restrict__ o_probs_new,
                          unsigned char* __restrict__ o_labels, float* __restrict__ o_mu, float* __restrict__ o_var,
                          double* loss_out) {
@@ -1485,12 +1536,12 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   gd* MLS = f.mat[B_MLS];
   gd* VLS = f.mat[B_VLS];
   gd* A = f.mat[B_A];
-  gd* AT = f.mat[B_AT];
+  gd* AT = KMIN ? nullptr : f.mat[B_AT];
   gd* BM = f.mat[B_BM];
-  gd* BMT = f.mat[B_BMT];
+  gd* BMT = f.mat[B_BMT];  // !KMIN only
   gd* GA = f.mat[B_GA];
   gd* GKXT = f.mat[B_GKXT];
-  gd* GAT = GKXT;  // G_A^T lives in the G_KX^T slot until G_KX is formed
+  gd* GAT = KMIN ? nullptr : GKXT;  // !KMIN: G_A^T lives in the G_KX^T slot until G_KX is formed
   gd* vm = f.vec[V_M];
   gd* gmu = f.vec[V_GMU];
   gd* gv = f.vec[V_GV];
@@ -1545,14 +1596,16 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   gd* gpart_m = f.mat[B_GA];
   gd* gpart_a = gpart_m + (size_t)(Mp / 16) * Mp;
   gd* gpart_b = gpart_a + (size_t)(Mp / 16) * Mp;
-  // A = LI * KX (+ AT) and BMT = A^T LS (+ BM) over ncols columns; then mu (without c) and var
+  // A = LI * KX and B = LS^T A over ncols columns (row-major only: the products that contract over the columns of A
+  // and B read them with the contraction index along the rows, gemm_tn's PK / QK forms); then mu (without c) and var
   auto forward_products = [&](int ncols, double s_, double jitter_) {
     const int nt = (ncols + TSB - 1) / TSB;
     // A[i][n] = sum_k U[k][i] KX[k][n],  U[k][i] = LI[i][k] = 0 for k > i
     product<WG, TU, false, ORD_ROWS_DESC>(mt, nt, false, f.mat[B_U], f.mat[B_KX], Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
                        [=](int i, int n, const d4& v) {
-                         store_tile(v, A, AT, Mp, i, n, tile);
+                         if constexpr (KMIN) store_tile(v, A, nullptr, Mp, i, n, tile);
+                         else store_tile(v, A, AT, Mp, i, n, tile);
                          {
                            const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                            double pm = 0.0, pa = 0.0;
@@ -1577,6 +1630,26 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                          }
                        }, ring);
     __syncthreads();
+    if constexpr (KMIN) {
+    // B[j][n] = sum_i LS[i][j] A[i][n],  LS[i][j] = 0 for i < j
+    product<WG, TU, false, ORD_ROWMAJOR>(mt, nt, false, LS, A, Mp, nullptr,
+                       [=](int j0, int, int* lo, int* hi) { *lo = j0; *hi = Mp; },
+                       [=](int j, int n, const d4& v) {
+                         store_tile(v, BM, nullptr, Mp, j, n, tile);
+                         {
+                           const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+                           double pb = 0.0;
+#pragma unroll
+                           for (int r = 0; r < 4; ++r) pb += v[r] * v[r];
+                           pb += __shfl_xor(pb, 16, 64);
+                           pb += __shfl_xor(pb, 32, 64);
+                           if (lq == 0) {
+                             if (fuse) part_b[(j >> 4) * Mp + n + lr] = pb;
+                             else gpart_b[(size_t)(j >> 4) * Mp + n + lr] = pb;
+                           }
+                         }
+                       }, ring);
+    } else {
     // BMT[n][j] = sum_i A[i][n] LS[i][j],  LS[i][j] = 0 for i < j
     product<WG, TU, false, ORD_COLMAJOR>(nt, mt, false, A, LS, Mp, nullptr,
                        [=](int, int j0, int* lo, int* hi) { *lo = j0; *hi = Mp; },
@@ -1598,6 +1671,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            }
                          }
                        }, ring);
+    }
     __syncthreads();
     for (int n = threadIdx.x; n < nt * TSB; n += NT) {
       double sm = 0.0, sa = 0.0, sb = 0.0;
@@ -1669,6 +1743,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            const int i = i0 + lq + 4 * r;
                            const double a = A[(size_t)i * Mp + n];
                            ga[r] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
+                           if constexpr (KMIN) GA[(size_t)i * Mp + n] = ga[r];
                            double pg = a * gmn;
                            pg += __shfl_xor(pg, 1, 64);
                            pg += __shfl_xor(pg, 2, 64);
@@ -1679,7 +1754,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                              else gpart_g[(size_t)(n0 >> 4) * Mp + i] = pg;
                            }
                          }
-                         store_tile(ga, GA, GAT, Mp, i0, n0, tile);
+                         if constexpr (!KMIN) store_tile(ga, GA, GAT, Mp, i0, n0, tile);
                        }, ring);
     __syncthreads();
     for (int i = threadIdx.x; i < Mp; i += NT) {
@@ -1694,8 +1769,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(7);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL', Adam on LS fused in the epilogue
-    product<WG, TU, true, ORD_ROWMAJOR>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
-                      [=](int i0, int j0, const d4& v) {
+    auto gls_epi = [=](int i0, int j0, const d4& v) {
                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                         const int j = j0 + lr;
                         d4 newv;
@@ -1717,16 +1791,34 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                           newv[r] = lnew;
                         }
                         store_tile(newv, nullptr, LST, Mp, i0, j0, tile);  // LST[j][i]; zeros above the diagonal
-                      }, ring);
+                      };
+    auto gls_range = [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; };
+    if constexpr (KMIN)  // A and B as they are: both with the contraction index n along their rows
+      product<WG, TU, true, ORD_ROWMAJOR, 1, 1>(mt, mt, true, A, BM, Mp, gv, gls_range, gls_epi, ring);
+    else
+      product<WG, TU, true, ORD_ROWMAJOR>(mt, mt, true, AT, BMT, Mp, gv, gls_range, gls_epi, ring);
     __syncthreads();
     stamp(8);
     // The Cholesky backward pass needs Pm = Phi(L^T G_L) with G_L = -tril(L^-T G_A A^T) = -tril(G_KX A^T).  Row i of
     // L^T X only reads rows k >= i of X, so the lower triangle of L^T tril(X) is the lower triangle of L^T X, and with
     // X = -L^-T G_A A^T:   Pm = Phi(-G_A A^T)   -- no G_L, no product with L^T (rounds 1-2 and the first half of round 3
     // formed G_L and L^T G_L: 1.33 M^3 where this is 1.0 M^3, one phase and one matrix write more).
-    // Pm^T -> BM buffer (B is dead after G_A; P operand of W: Pm^T[k][i] = Pm[i][k], non-zero for k <= i)
-    gd* PmT = BM;
-    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, GAT, AT, Mp, nullptr, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
+    // -> B buffer (dead after G_LS).  KMIN: Pm as it is, from G_A and A as they are (contraction index n along their
+    // rows); otherwise Pm^T (the k-major P operand of W: Pm^T[k][i] = Pm[i][k], non-zero for k <= i) from G_A^T and A^T
+    gd* Pm = BM;
+    auto pm_range = [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; };
+    if constexpr (KMIN) {
+      product<WG, TU, false, ORD_ROWMAJOR, 1, 1>(mt, mt, true, GA, A, Mp, nullptr, pm_range,
+                       [=](int i0, int j0, const d4& v) {
+                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+                         for (int r = 0; r < 4; ++r) {
+                           const int i = i0 + lq + 4 * r, j = j0 + lr;
+                           Pm[(size_t)i * Mp + j] = (j < i) ? -v[r] : (j == i ? -0.5 * v[r] : 0.0);
+                         }
+                       }, ring);
+    } else {
+      product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, GAT, AT, Mp, nullptr, pm_range,
                        [=](int i0, int j0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                          d4 pv;
@@ -1735,11 +1827,12 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            const int i = i0 + lq + 4 * r, j = j0 + lr;
                            pv[r] = (j < i) ? -v[r] : (j == i ? -0.5 * v[r] : 0.0);
                          }
-                         store_tile(pv, nullptr, PmT, Mp, i0, j0, tile);
+                         store_tile(pv, nullptr, Pm, Mp, i0, j0, tile);
                        }, ring);
+    }
     __syncthreads();
     stamp(9);
-    // G_KX^T = G_A^T LI (only the transposed form is used: kernel gradients) -> over G_A^T; formed as the product whose
+    // G_KX^T = G_A^T LI (only the transposed form is used: kernel gradients); formed as the product whose
     // output IS the transposed matrix, so that the epilogue is plain row stores   (Q = LI[k][i], non-zero for k >= i)
     product<WG, TU, false, ORD_COLMAJOR>(mt, mt, false, GA, f.mat[B_LI], Mp, nullptr,
                        [=](int, int i0, int* lo, int* hi) { *lo = i0; *hi = Mp; },
@@ -1753,16 +1846,19 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     // W = Pm L^-1 (lower) -> the G_LS slot, which nothing else writes in this kernel: its upper blocks ARE zero, as the
     // hulls of S's ranges assume   (j0 <= k < i0 + tile: Pm^T[k][i] = 0 for k > i, L^-1[k][j] = 0 for k < j)
     gd* Wm = f.mat[B_GLS];
-    product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, PmT, f.mat[B_LI], Mp, nullptr,
-                       [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; },
-                       [=](int i0, int j0, const d4& v) {
+    auto w_epi = [=](int i0, int j0, const d4& v) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
 #pragma unroll
                          for (int r = 0; r < 4; ++r) {
                            const int i = i0 + lq + 4 * r, j = j0 + lr;
                            Wm[(size_t)i * Mp + j] = (j <= i) ? v[r] : 0.0;
                          }
-                       }, ring);
+                       };
+    auto w_range = [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; };
+    if constexpr (KMIN)
+      product<WG, TU, false, ORD_ROWMAJOR, 1, 0>(mt, mt, true, Pm, f.mat[B_LI], Mp, nullptr, w_range, w_epi, ring);
+    else
+      product<WG, TU, false, ORD_ROWMAJOR>(mt, mt, true, Pm, f.mat[B_LI], Mp, nullptr, w_range, w_epi, ring);
     __syncthreads();
     stamp(12);
     // S = L^-T W -> G in the BM buffer, G^T in the A buffer   (k >= max(i0, j0))
@@ -1937,7 +2033,10 @@ __device__ inline void fit_epilogue(const gapro_fit_desc& desc, const gapro_fit_
 
 // WPS = waves per SIMD the register budget is sized for: kWavesPerSimd (two workgroups per CU) for a full
 // launch, 2 (one workgroup per CU, 256 VGPRs, no spills in the body) when the launch has fewer fits than CUs
-template <int WPS>
+// KMIN: the copy-free product forms (fit_body), for fits up to M_p = kKminMaxMp -- a function of M_p alone, so that a fit
+// has the same bits in every build; the launcher (gapro_svgp_fit_batch) sends a fit to the instantiation of its M_p.
+// One form per kernel: with both bodies in one kernel either loses ~2 % (registers, code size).
+template <int WPS, bool KMIN>
 __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const float* __restrict__ feats_spp,
                                                  const int* __restrict__ idx, const gapro_fit_desc* __restrict__ descs,
                                                  const double* __restrict__ init_mean, gapro_fit_options opt,
@@ -1957,6 +2056,8 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   double* loss_slot = &o_loss[desc.slot];
   // the reference's two feature widths (xyz+rgb = 6, deep features = 32) get a compile-time D: the distance
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
+#define GAPRO_FIT_KM(TUV, DM, DCV, WGV)                                                                       \
+  fit_body<TUV, DM, DCV, WGV, KMIN>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot)
 #define GAPRO_FIT_BODY(DM, DCV)                                                                              \
   do {                                                                                                       \
     if (Mp > kFuseMaxMp && Mp % 32 == 0 && !(opt.reserved & 131072) &&                                       \
@@ -1965,18 +2066,20 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
          cover the matrix: M_p = 256, 384 (+6 % / +4 % fits/s, a quarter less traffic; neutral to -7 % at     \
          the other sizes: DESIGN 6.0).  Bit 13: every M_p > 128 that is a multiple of 32 (bit 14: not in the  \
          one-per-CU build); bit 17: nowhere */                                                                \
-      fit_body<1, DM, DCV, (WPS == 2 ? 4 : 2)>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
-    else if (WPS == 2 && DM == 6 && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096))                     \
-      fit_body<(WPS == 2 && DM == 6) ? 4 : 2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
-    else if (Mp >= 128 && Mp % 32 == 0)                                                                      \
-      fit_body<2, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
+      GAPRO_FIT_KM(1, DM, DCV, (WPS == 2 ? 4 : 2));                                                            \
+    else if (WPS == 2 && DM == 6 && !KMIN && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096)) {         \
+      if constexpr (WPS == 2 && DM == 6 && !KMIN)                                                            \
+        fit_body<4, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
+    } else if (Mp >= 128 && Mp % 32 == 0)                                                                    \
+      GAPRO_FIT_KM(2, DM, DCV, 0);                                                                             \
     else                                                                                                     \
-      fit_body<1, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
+      GAPRO_FIT_KM(1, DM, DCV, 0);                                                                             \
   } while (0)
   if (D == 6) GAPRO_FIT_BODY(6, 6);
   else if (D == 32) GAPRO_FIT_BODY(32, 32);
   else GAPRO_FIT_BODY(32, 0);
 #undef GAPRO_FIT_BODY
+#undef GAPRO_FIT_KM
   fit_epilogue(desc, opt, o_status, o_loss);
 }
 
@@ -2976,13 +3079,20 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   std::stable_sort(clus.begin(), clus.end(), by_cost);
   // the staged fits whose LDS fits a CU twice and the larger ones are two launches (see below)
   const long long kTwice = 72 * 1024;
-  size_t nbig = 0;  // sorted by M, the LDS need grows with M
-  long long lds_big = 0, lds_rest = 0;
+  size_t nbig = 0, nkmaj = 0;  // sorted by M, the LDS need grows with M: [0, nkmaj) M_p > kKminMaxMp, [0, nbig) "big"
+  long long lds_big = 0, lds_rest = 0, lds_kmaj = 0;
   for (const gapro_fit_desc& d : staged) {
     const long long b = staged_lds_bytes(d.m1 + d.m2, feat_dim);
-    if (b > kTwice && !(route_flags & 128)) {
+    // (the product forms of a fit are a function of its M_p, k_svgp_fit's KMIN: fits beyond kKminMaxMp are a launch of
+    // their own -- with D = 6 exactly the fits that need more than kTwice)
+    const bool kmaj = gapro_pad_m(d.m1 + d.m2) > kKminMaxMp;
+    if (kmaj) {
+      ++nkmaj;
+      lds_kmaj = std::max(lds_kmaj, b);
+    }
+    if (kmaj || (b > kTwice && !(route_flags & 128))) {
       ++nbig;
-      lds_big = std::max(lds_big, b);
+      if (!kmaj) lds_big = std::max(lds_big, b);
     } else {
       lds_rest = std::max(lds_rest, b);
     }
@@ -3083,9 +3193,9 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     // staged fits go out as two launches side by side: those whose LDS fits a CU twice in the `<4>` build (128 VGPRs,
     // two workgroups per CU: 17 % more fits/s at M <= 256 than one per CU), the larger ones in the `<2>` build (the
     // whole register file, no spills).  Either part with fewer fits than CUs takes `<2>` as well.
-    auto launch = [&](hipStream_t st, size_t first, size_t count, long long lds) -> int {
+    auto launch = [&](hipStream_t st, size_t first, size_t count, long long lds, bool kmaj) -> int {
       const bool one_per_cu = (int)count <= ctx->n_cu || lds > kTwice || (route_flags & 64);
-      auto kern = one_per_cu ? k_svgp_fit<2> : k_svgp_fit<kWavesPerSimd>;
+      auto kern = kmaj ? k_svgp_fit<2, false> : one_per_cu ? k_svgp_fit<2, true> : k_svgp_fit<kWavesPerSimd, true>;
       if (lds > 48 * 1024)
         GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kern, dim3((int)count), dim3(NT), (size_t)lds, st, (int)count, (int)feat_dim, d_feats_spp, d_idx,
@@ -3093,13 +3203,17 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                          d_mu, d_var, d_fit_status, d_fit_loss);
       return GAPRO_OK;
     };
-    if (nbig > 0) {
-      const int rc = launch(s_staged, 0, nbig, lds_big);
+    if (nkmaj > 0) {
+      const int rc = launch(s_staged, 0, nkmaj, lds_kmaj, true);
+      if (rc != GAPRO_OK) return rc;
+    }
+    if (nbig > nkmaj) {  // M_p <= kKminMaxMp with an LDS need beyond kTwice (wide features): behind the former
+      const int rc = launch(s_staged, nkmaj, nbig - nkmaj, lds_big, false);
       if (rc != GAPRO_OK) return rc;
     }
     if (nbig < staged.size()) {
       hipStream_t st = nbig > 0 ? s_staged2 : s_staged;
-      const int rc = launch(st, nbig, staged.size() - nbig, lds_rest);
+      const int rc = launch(st, nbig, staged.size() - nbig, lds_rest, false);
       if (rc != GAPRO_OK) return rc;
       if (st != s_staged) {  // everything staged is finished once s_staged has passed this point
         GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[4], st));

@@ -185,18 +185,18 @@ def main():
             ws = res["workspace"].cpu().numpy()
             prof = np.stack([ws[i * total + scal + 24: i * total + scal + 52] for i in range(min(n, 64))]).mean(0)
             names = ["chol:update", "chol:rest", "inv", "kx", "A+BMT+meanvar", "chol:diag", "quad/kl", "Gm+GA",
-                     "GLS+adam", "GKX", "GL", "Pm", "T1", "G", "kgrads+adamZ", "-", "adam", "predict", "chol:panel",
+                     "GLS+adam", "Pm(-GA A^T)", "GKX", "-", "W", "S", "kgrads+adamZ", "-", "adam", "predict", "chol:panel",
                      "misc"]
             route = _lib.load().gapro_fit_route(m, args.d)
             if not args.force_staged and route in (0, 3):
                 names = ["chol:update", "chol:rest", "inv", "s:fill", "s:A", "chol:diag", "post-strips", "s:B",
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
-                         "s:GKX", "adam", "predict", "s:GLacc+store", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
+                         "s:GKX+PmAcc", "adam", "predict", "s:GKXTstore", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
                          "(diag:stores", "x25", "x26", "x27"]
             from gapro_amd import _lib as _l
             if (route == 4 or args.cluster_all) and not args.no_cluster:
                 names = ["kzz", "chol:diag(leader)", "chol:panel", "chol:trailing", "inverse", "kx", "fwd:colpart",
-                         "-", "chol:flag", "quad+kl", "Gm+GA", "GLS+adamLS+GKX", "GL", "Pm", "T1", "G", "kgrads(fused)", "-",
+                         "-", "chol:flag", "quad+kl", "Gm+GA", "GLS+adamLS+GKX+Pm", "-", "-", "W", "S", "kgrads(fused)", "-",
                          "adam", "predict", "fwd:A", "fwd:B", "-", "-", "-", "-", "-", "-"]
             prof = prof[:25]  # slots 25 .. 27: start / end / CU of the workgroup (tools/fit_timeline.py)
             tot = prof[:22].sum()
