@@ -53,13 +53,16 @@ int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, co
                              unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss);
 
 // Padded size of a fit's M x M matrices: MFMA tiles are 16 wide, so M is rounded up to a multiple of 16 (everything
-// scales with M_p^3: rounding M = 80 to 96 instead of 80 costs 1.7x the work).  The products use 32 x 32 wave tiles
-// from M_p = 128 on where M_p is a multiple of 32, 16 x 16 ones otherwise; beyond 176 the larger tiles win back more
-// than the padding costs (measured), so M is rounded to a multiple of 32 there.
+// scales with M_p^2 M: rounding M = 80 to 96 instead of 80 costs 1.4x the work).  The staged kernel's 32 x 32 wave tiles
+// take a last row / column of 16 x 16 tiles where M_p is an odd multiple of 16 (round 3; rounds 1-2 rounded to 32
+// beyond 176: 8 % more work on average at M = 200).  From 352 on its 64 x 64 tiles need multiples of 32, and so does
+// the cluster kernel (M_p >= 512).
+// (M_p = 240 is skipped: 256 runs the workgroup-tiled products, and M = 230 is 5 % faster padded to 256 than to 240)
+constexpr int kPad16MaxMp = 336;
 inline __host__ __device__ int gapro_pad_m(int m) {
   if (m < 1) m = 1;
   const int p16 = (m + 15) / 16 * 16;
-  return p16 <= 176 ? p16 : (m + 31) / 32 * 32;
+  return p16 <= kPad16MaxMp && p16 != 240 ? p16 : (m + 31) / 32 * 32;
 }
 
 inline int gapro_fail(gapro_ctx* ctx, int code, const char* fmt, ...) {

@@ -381,12 +381,14 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 #pragma unroll
       for (int v = 0; v < TV; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
   };
-  // full tiles: fo x fn of TU x TU blocks; TU = 4 takes its extents in 32 x 32 units and may leave a last row / column
-  constexpr int TE = TU >= 4 ? 2 : TU;  // blocks per side of an edge tile
-  const int fo = TU >= 4 ? mo_tiles / 2 : mo_tiles, fn = TU >= 4 ? no_tiles / 2 : no_tiles;
-  const int odd_i = TU >= 4 ? (mo_tiles & 1) : 0, odd_j = (TU >= 4 && !lower_only) ? (no_tiles & 1) : 0;
+  // full tiles: fo x fn of TU x TU blocks.  TU >= 2 takes its extents in HALF tiles (TU = 2: 16 x 16, TU = 4: 32 x 32)
+  // and an odd count leaves a last row / column of half-size tiles: M_p need not be a multiple of the tile (round 3:
+  // M_p in steps of 16 up to 336, see gapro_pad_m)
+  constexpr int TE = TU >= 2 ? TU / 2 : TU;  // blocks per side of an edge tile
+  const int fo = TU >= 2 ? mo_tiles / 2 : mo_tiles, fn = TU >= 2 ? no_tiles / 2 : no_tiles;
+  const int odd_i = TU >= 2 ? (mo_tiles & 1) : 0, odd_j = (TU >= 2 && !lower_only) ? (no_tiles & 1) : 0;
   const int nfull = lower_only ? fo * (fo + 1) / 2 : fo * fn;
-  const int nrow = odd_i ? (lower_only ? mo_tiles : no_tiles) : 0;  // edge row: tiles (mo_tiles - 1, 0 ..) in 32-units
+  const int nrow = odd_i ? (lower_only ? mo_tiles : no_tiles) : 0;  // edge row: tiles (mo_tiles - 1, 0 ..) in half tiles
   const int ncol = odd_j ? mo_tiles - odd_i : 0;                    // edge column: tiles (0 .., no_tiles - 1) above it
   const int ntiles = nfull + nrow + ncol;
   const int rounds = (ntiles + NW - 1) / NW;
@@ -394,10 +396,10 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
   for (int q = 0; q < rounds; ++q) {
     const int t = q * NW + ((q & 1) ? NW - 1 - wave : wave);
     if (t >= ntiles) continue;
-    if (t >= nfull) {  // 32 x 32 edge tiles (TU = 4 only), a quarter of a full tile's work each
+    if (t >= nfull) {  // half-size edge tiles, a quarter of a full tile's work each
       const int e = t - nfull;
-      const int i32 = e < nrow ? mo_tiles - 1 : e - nrow, j32 = e < nrow ? e : no_tiles - 1;
-      tile(std::integral_constant<int, TE>{}, 32 * i32, 32 * j32);
+      const int ih = e < nrow ? mo_tiles - 1 : e - nrow, jh = e < nrow ? e : no_tiles - 1;
+      tile(std::integral_constant<int, TE>{}, 16 * TE * ih, 16 * TE * jh);
       continue;
     }
     int ti, tj;
@@ -1472,11 +1474,11 @@ __device__ inline void product(int mo, int no, bool lower, const gd* __restrict_
       if (R > 0 && Cc > 0 && !lower) gemm_wg<SCALE, true, WG>(R / 16, Cc / 16, false, P, Q, ld, qs, kr, epi, ring);
     }
     auto strip_t = [&](auto tu_tag, int r0, int c0, int nr, int nc, bool low) {
-      constexpr int TUS = decltype(tu_tag)::value;  // 2: 32 x 32 wave tiles, 4: 64 x 64 (extents still in 32-units)
+      constexpr int TUS = decltype(tu_tag)::value;  // 2: 32 x 32 wave tiles, 4: 64 x 64 (extents in half tiles)
       if (nr <= 0 || nc <= 0) return;
       // (row-major tile order: the shell order of some products enumerates SQUARE tile grids only)
       gemm_tn<TUS, SCALE, 2, ORD_ROWMAJOR, true, PK, QK>(
-          nr / 32, nc / 32, low, PK ? P + (size_t)r0 * ld : P + r0, QK ? Q + (size_t)c0 * ld : Q + c0, ld, qs,
+          nr / (8 * TUS), nc / (8 * TUS), low, PK ? P + (size_t)r0 * ld : P + r0, QK ? Q + (size_t)c0 * ld : Q + c0, ld, qs,
           [=](int i0, int j0, int* lo, int* hi) {
             int l0, h0, l1, h1;  // a wave tile's range: the hull of its 16 x 16 blocks' (kr is monotone; gemm_tn trims hi)
             kr(r0 + i0, c0 + j0, &l0, &h0);
@@ -1527,7 +1529,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   Shared& sh = g_sh;
   const int M = f.M, Mp = f.Mp, D = DC ? DC : f.D, T = f.T;
   constexpr int TS = 16 * TU;
-  constexpr int TSB = TU >= 4 ? 32 : TS;  // unit of gemm_tn's extents (TU = 4: 32 x 32, see there)
+  constexpr int TSB = TU >= 2 ? 8 * TU : TS;  // unit of gemm_tn's extents (TU >= 2: half tiles, see there)
   const int mt = Mp / TSB;
   const double Nd = (double)M;  // num_data = train_y.numel() (gaussian_process_utils.py:414)
   const double jitter = opt.jitter;
@@ -2070,7 +2072,7 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
     else if (WPS == 2 && DM == 6 && !KMIN && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096)) {         \
       if constexpr (WPS == 2 && DM == 6 && !KMIN)                                                            \
         fit_body<4, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
-    } else if (Mp >= 128 && Mp % 32 == 0)                                                                    \
+    } else if (Mp >= 128)                                                                                    \
       GAPRO_FIT_KM(2, DM, DCV, 0);                                                                             \
     else                                                                                                     \
       GAPRO_FIT_KM(1, DM, DCV, 0);                                                                             \
@@ -2738,11 +2740,11 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
     auto tail = [&](auto tu_tag) {
       constexpr int TU = decltype(tu_tag)::value;
       constexpr int TS = 16 * TU;
-      const int mt = Mp / TS;
+      const int mt = Mp / 16;  // gemm_tn's extents: 16 x 16 tiles (TU = 1) or half tiles (TU = 2)
       gd* PmT = Pm;   // Pm^T: the upper and diagonal tiles are written, W reads exactly those
       gd* Wm = T1T;   // W: the lower and diagonal tiles are written, S reads exactly those
       gemm_tn<TU, false, 4>(mt, mt, true, PmT, f.mat[B_LI], Mp, nullptr,
-                         [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS; },
+                         [=](int i0, int j0, int* lo, int* hi) { *lo = j0; *hi = i0 + TS < Mp ? i0 + TS : Mp; },
                          [=](int i0, int j0, const d4& v) {
                            const int ln = threadIdx.x & 63, c = ln & 15, g4 = ln >> 4;
 #pragma unroll
@@ -2757,7 +2759,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
                          [=](int i, int j, const d4& v) { store_tile(v, Gb, GTb, Mp, i, j, tile); });
       __syncthreads();
     };
-    if (Mp >= 64 && Mp % 32 == 0)
+    if (Mp >= 64)
       tail(std::integral_constant<int, 2>());
     else
       tail(std::integral_constant<int, 1>());
@@ -2907,7 +2909,7 @@ __global__ __launch_bounds__(NT, 2) void k_product_bench(int Mp, int reps, int s
     for (int r = 0; r < 4; ++r) Cm[(size_t)(i0 + lq + 4 * r) * Mp + j0 + lr] = v[r];
   };
   for (int r = 0; r < reps; ++r) {
-    if (ENGINE == 0) gemm_tn<2, false, 2, ORD_ROWS_DESC, true>(Mp / 32, Mp / 32, shp == 2 || shp == 5, P, Q, Mp, nullptr, kr, epi);
+    if (ENGINE == 0) gemm_tn<2, false, 2, ORD_ROWS_DESC, true>(Mp / 16, Mp / 16, shp == 2 || shp == 5, P, Q, Mp, nullptr, kr, epi);
     else if (ENGINE == 1) gemm_tn<4, false, 2, ORD_ROWS_DESC, true>(Mp / 32, Mp / 32, shp == 2 || shp == 5, P, Q, Mp, nullptr, kr, epi);
     else if (ENGINE == 2) product<4, 1, false, ORD_ROWS_DESC>(Mp / 16, Mp / 16, shp == 2 || shp == 5, P, Q, Mp, nullptr, kr, epi, scratch);
     else return;  // (engine 3 was a two-team form of engine 2: no faster, taken out again -- DESIGN 6.0)
