@@ -233,6 +233,7 @@ class Pipeline:
         self.strict = True
         self.last_stats = {}
         self.trace = None  # set to a list to collect (time, batch id, stage) host timestamps
+        self.workspace_headroom = 1.3  # growth factor of the fit workspaces over the need that triggers it
         # optional HIP-event timing of the fit launches (bench.py): list of (start_event, end_event, flops)
         self.profile_fit = False
         self.fit_events = []
@@ -467,7 +468,13 @@ class Pipeline:
         self._ws.setdefault(slot, None)
         cur = self._ws[slot]
         if cur is None or cur.numel() < n_doubles:
-            size = int(n_doubles * 1.05) + 1024
+            # 30 % headroom: the need of a batch of 256 scenes varies by ~10 %, and growing means a hipMalloc of
+            # 10 .. 20 GB per slot plus its fill behind the running fit kernels -- 2 s on a freshly booted box, inside
+            # whatever step first exceeds the old size (bench.py's sporadic 980 ms steps against 760 ms launches)
+            size = int(n_doubles * self.workspace_headroom) + 1024
+            if self.trace is not None:
+                import time as _time
+                self.trace.append((_time.perf_counter(), 0, "workspace grows to %.1f GB per slot" % (size * 8 / 1e9)))
             for k in list(self._ws):
                 if self._ws[k] is None or self._ws[k].numel() < size:
                     self._ws[k] = None  # release before growing
