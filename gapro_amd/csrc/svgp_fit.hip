@@ -58,6 +58,13 @@ constexpr int kRedSlots = 8;            // values reduced across row groups per 
 #define GAPRO_WAVES_PER_SIMD 4           // 2 workgroups of 8 waves per CU -> 128 VGPRs per lane
 #endif
 constexpr int kWavesPerSimd = GAPRO_WAVES_PER_SIMD;
+#ifndef GAPRO_TU4_MIN
+#define GAPRO_TU4_MIN 320
+#endif
+// 64 x 64 wave tiles from this M_p on (one-per-CU build, D = 6; multiples of 32).  Round 3, 512 fits: M_p = 320 +2.4 %,
+// 288 -2.2 % against 32 x 32 tiles; with the copy-free forms, one per CU, M_p = 192 / 224: -15 % (and one per CU with
+// 32 x 32 tiles is 7 .. 10 % behind two per CU there).
+constexpr int kTu4MinMp = GAPRO_TU4_MIN;
 constexpr int kKminMaxMp = 256;         // largest M_p with the copy-free product forms (fit_body's KMIN)
 #ifndef GAPRO_GEMM_RING
 #define GAPRO_GEMM_RING 2
@@ -2074,7 +2081,7 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
          the other sizes: DESIGN 6.0).  Bit 13: every M_p > 128 that is a multiple of 32 (bit 14: not in the  \
          one-per-CU build); bit 17: nowhere */                                                                \
       GAPRO_FIT_KM(1, DM, DCV, (WPS == 2 ? 4 : 2));                                                            \
-    else if (WPS == 2 && DM == 6 && !KMIN && Mp >= 352 && Mp % 32 == 0 && !(opt.reserved & 4096)) {         \
+    else if (WPS == 2 && DM == 6 && !KMIN && Mp >= kTu4MinMp && Mp % 32 == 0 && !(opt.reserved & 4096)) {   \
       if constexpr (WPS == 2 && DM == 6 && !KMIN)                                                            \
         fit_body<4, DM, DCV>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot); \
     } else if (Mp >= 128)                                                                                    \
