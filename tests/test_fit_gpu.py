@@ -168,6 +168,48 @@ def test_fit_ill_conditioned_problems_stay_finite():
         assert ((probs >= 0) & (probs <= 1)).all() and (probs_new >= 0.5).all()
 
 
+@pytest.mark.parametrize("m1,m2,t", [(70, 74, 20), (80, 88, 33), (100, 100, 40), (130, 135, 25), (148, 152, 30),
+                                     (165, 165, 17)])
+def test_fit_matches_oracle_where_m_p_is_an_odd_multiple_of_16(m1, m2, t):
+    """Round 3: M_p goes in steps of 16 up to 336 (gapro_pad_m) and the staged kernel's 32 x 32 wave tiles take a last
+    row / column of 16 x 16 tiles there (gemm_tn's half-tile extents): M_p = 144, 176, 208 with the copy-free product
+    forms, 272, 304, 336 with the k-major ones; 50 Adam steps against the float64 oracle."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    lay = (C.c_int64 * 8)()
+    _lib.load().gapro_fit_workspace_layout(m1 + m2, t, 6, C.cast(lay, C.c_void_p))
+    mp = (m1 + m2 + 15) // 16 * 16
+    assert mp % 32 == 16 and int(lay[0]) == mp, (mp, list(lay))  # the layout's padded size is the odd multiple
+    feats, b1, b2, it = make_gp_problem(300 + m1, m1, m2, t, 6)
+    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=50)[0]
+    _compare(out, _oracle(feats, b1, b2, it, 50))
+
+
+def test_two_per_cu_build_has_the_bits_of_the_one_per_cu_build():
+    """The staged kernel has one instantiation per register budget and product form (k_svgp_fit<WPS, KMIN>); a launch
+    with more fits than CUs runs its M_p <= 256 fits two per CU in the 128-VGPR build, a smaller one in the 256-VGPR
+    build.  The product forms are a function of M_p alone, so the same fit has the same bits in both -- M_p = 160
+    (whole 32 x 32 tiles), 208 (edge tiles), 256 (workgroup-tiled products)."""
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    feats_list, probs = [], []
+    base = 0
+    for i, (m1, m2, t) in enumerate([(75, 80, 9), (100, 104, 12), (125, 128, 7)]):
+        f, b1, b2, it = make_gp_problem(500 + i, m1, m2, t, 6)
+        feats_list.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(feats_list)
+    singles = [fit_gp_spp_batch(feats, [p], training_iter=8)[0] for p in probs]
+    many = fit_gp_spp_batch(feats, probs * 100, training_iter=8)  # 300 fits on 256 CUs: the two-per-CU launch
+    for k in (0, 1, 2, 150, 151, 152, 297, 298, 299):
+        for a, b in zip(many[k], singles[k % 3]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_fit_batch_equals_single_and_is_deterministic():
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
     from gapro_amd.synth import make_gp_problem
