@@ -24,7 +24,7 @@ constexpr int kClusterMinMp = 64;                // smallest padded M the cluste
 constexpr int kClusterDefaultMinMp = 512;        // default routing threshold (gapro_cluster_min_mp)
 // workgroups a fit of padded size Mp is spread over: the work grows with Mp^3 while a launch's other fits finish in
 // a fraction of a second, so the largest fits get the most CUs (powers of two; one CU up to Mp = 384)
-inline int cluster_g(int Mp, double unit = 384.0, bool pow2 = true) {
+inline __host__ __device__ int cluster_g(int Mp, double unit = 384.0, bool pow2 = true) {
   const double work = (double)Mp * Mp * Mp / (unit * unit * unit);
   int g = 1;
   if (pow2) {
@@ -40,10 +40,13 @@ constexpr int kClusterMaxMp = 5120;
 inline __host__ __device__ bool cluster_capable(int Mp) {
   return Mp >= kClusterMinMp && Mp % 32 == 0 && Mp <= kClusterMaxMp;
 }
-// a plane of the ordered two-stage column sums: sized for the largest cluster, so that the layout does not depend on
-// the cluster size policy
+// a plane of the ordered two-stage column sums: sized for the largest cluster ANY policy can give a fit of this size
+// (gapro_cluster_size: the work unit is tunable down to kClusterMinUnit), so that the layout does not depend on the
+// policy -- and not for 32 workgroups whatever the size: M_p = 64 .. 128 fits, thousands per batch and never on the
+// cluster kernel by default, carried 400 KB of scratch each
+constexpr double kClusterMinUnit = 64.0;
 inline __host__ __device__ long long cluster_plane_doubles(int Mp) {
-  const long long t = (long long)kClMaxG * kClThreads;
+  const long long t = (long long)cluster_g(Mp, kClusterMinUnit, true) * kClThreads;
   return Mp > t ? Mp : t;
 }
 inline __host__ __device__ long long cluster_part_doubles(int Mp) {

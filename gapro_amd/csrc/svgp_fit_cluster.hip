@@ -1824,7 +1824,7 @@ int gapro_cluster_size(int Mp, bool all) {
     const char* e = getenv("GAPRO_CLUSTER_UNIT");
     const char* r = getenv("GAPRO_CLUSTER_ROUND");
     if (r) pow2 = strcmp(r, "ceil") != 0;
-    unit = e && atof(e) >= 64.0 ? atof(e) : 384.0;
+    unit = e && atof(e) >= kClusterMinUnit ? atof(e) : 384.0;  // (the scratch planes are sized for kClusterMinUnit)
   }
   return cluster_g(Mp, unit, pow2 != 0);
 }
