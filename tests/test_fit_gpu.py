@@ -357,6 +357,29 @@ def test_small_fit_kernel_and_strip_kernel_agree():
             np.testing.assert_allclose(np.asarray(x, np.float64), np.asarray(y, np.float64), rtol=0, atol=2e-6)
 
 
+def test_three_staged_launches_of_one_batch_match_the_oracle():
+    """D = 16: one batch whose staged fits fall into all three launches of gapro_svgp_fit_batch -- M_p = 304 (k-major
+    product forms, k_svgp_fit<2, false>), M_p = 256 (copy-free forms, but 2 x 16 x 256 staged coordinates push the LDS
+    need beyond what fits a CU twice: k_svgp_fit<2, true> behind the former) and M_p = 144 (the rest) -- each against
+    the float64 oracle, 50 Adam steps."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    feats_list, probs, raw = [], [], []
+    base = 0
+    for i, (m1, m2, t) in enumerate([(150, 152, 20), (125, 128, 33), (70, 72, 9)]):
+        assert _lib.load().gapro_fit_route(m1 + m2, 16) == 1
+        f, b1, b2, it = make_gp_problem(700 + i, m1, m2, t, 16, std=0.5)
+        feats_list.append(f)
+        raw.append((f, b1, b2, it))
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    outs = fit_gp_spp_batch(np.concatenate(feats_list), probs, training_iter=50)
+    for out, (f, b1, b2, it) in zip(outs, raw):
+        _compare(out, _oracle(f, b1, b2, it, 50))
+
+
 @pytest.mark.parametrize("m1,m2,t,route", [(20, 28, 12, 3), (40, 50, 33, 0), (90, 100, 40, 1), (120, 136, 25, 4),
                                            (120, 136, 25, 2), (250, 262, 30, 4)])
 def test_fit_matches_oracle_with_deep_features_on_every_route(m1, m2, t, route):
