@@ -234,6 +234,8 @@ class Pipeline:
         self.last_stats = {}
         self.trace = None  # set to a list to collect (time, batch id, stage) host timestamps
         self.workspace_headroom = 1.3  # growth factor of the fit workspaces over the need that triggers it
+        self.serialize_fits = not os.environ.get("GAPRO_OVERLAP_FITS")  # fit launches never overlap (see fit_launch)
+        self._last_fit_done = None
         # optional HIP-event timing of the fit launches (bench.py): list of (start_event, end_event, flops)
         self.profile_fit = False
         self.fit_events = []
@@ -765,6 +767,14 @@ class Pipeline:
             tm = C.c_void_p()
             ctx.check(lib.gapro_fit_timing_create(ctx.handle, C.byref(tm)))
             ctx.check(lib.gapro_fit_timing_arm(ctx.handle, tm))
+        # One fit launch at a time.  The software pipeline launches fit(i) when the partition kernels of batch i+1 have
+        # completed, and those normally complete when fit(i-1) drains -- but now and then they slip in earlier, fit(i)
+        # is enqueued with most of fit(i-1) still to run, and the members of its cluster fits become resident one by
+        # one as CUs free up, spinning at their first barrier for hundreds of ms on CUs that fit(i-1) could use
+        # (bench.py --steps 20: cluster kernels of 1.2 .. 1.5 s beside the usual 0.23 s, launches 12 % longer).
+        prev = self._last_fit_done if self.serialize_fits else None
+        if prev is not None:
+            torch.cuda.current_stream(devc).wait_event(prev)
         ctx.check(lib.gapro_svgp_fit_batch(
             ctx.handle, _stream_handle(devc), n_fits, D, _ptr(feats_spp), _ptr(d_idx), C.cast(descs, C.c_void_p),
             _ptr(d_descs), _ptr(d_init),
@@ -802,6 +812,7 @@ class Pipeline:
         h_stat[:n_fits * 12].copy_(stat, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(devc))
+        self._last_fit_done = done
         keep = (d_descs, d_idx, d_init, ws, out, stat, feats_spp)  # alive until the launch has finished
         return dict(done=done, h_out=h_out, h_stat=h_stat, no=no, n_fits=n_fits, ws_bytes=ws_bytes, keep=keep,
                     ws=ws if keep_debug else None, descs=descs if keep_debug else None)
