@@ -689,12 +689,12 @@ __device__ inline void store_tile(const d4& v, gd* __restrict__ Cm, gd* __restri
 // One wave: lane r (mod 16) holds row r in registers; column pivots and multipliers travel by
 // v_readlane broadcasts, so the 16 dependent elimination steps never wait on LDS.  The inverse is a
 // forward substitution, one column per lane, reading L_kk as LDS broadcasts.  Results: L_kk and
-// Dinv = L_kk^-1 in g_sh.dblk / g_sh.dinv, and in global memory (L, L^T diagonal blocks, Dinv, Dinv^T).
+// Dinv = L_kk^-1 in g_sh.dblk / g_sh.dinv, and in global memory (L^T diagonal block, Dinv, Dinv^T).  (Round 3: L itself
+// is no longer written by these kernels -- since Pm = Phi(-G_A A^T) nothing reads it; everything works from L^T.)
 __device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp;
   kb = uni(kb);
-  gd* L = f.mat[B_L];
   gd* LT = f.mat[B_LT];
   const int lane = threadIdx.x & 63, r = lane & 15;
 #ifdef GAPRO_PROFILE
@@ -761,7 +761,6 @@ __device__ __noinline__ void diag_factor_invert(ldsd* panel, int kb) {
   for (int e = 0; e < 4; ++e) {
     const int idx = lane + 64 * e;
     const int rr = idx >> 4, cc = idx & 15;
-    L[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = g_sh.dblk[rr * 17 + cc];
     LT[(size_t)(16 * kb + rr) * Mp + 16 * kb + cc] = g_sh.dblk[cc * 17 + rr];
     f.dinv[(size_t)kb * 256 + idx] = g_sh.dinv[rr * 17 + cc];
     f.dinvT[(size_t)kb * 256 + idx] = g_sh.dinv[cc * 17 + rr];
@@ -819,14 +818,13 @@ __device__ inline void chol_update_tile(d4& acc, const gd* pa, const gd* pb, int
 //       points straight into the MFMA accumulator, the update reads L^T (TN form); S goes to an LDS panel
 //   (2) wave 0 factors the 16x16 diagonal block held one row per lane in registers (cross-lane
 //       broadcasts, no LDS round trips) and inverts it (column per lane)
-//   (3) panel below = S * Dinv^T, computed in LDS, then written once to L (rows) and L^T (rows)
+//   (3) panel below = S * Dinv^T, computed in LDS, then written once to L^T (rows)
 // The padded tail (index >= M) is an identity block.  Strict upper triangle of L stays zero.
 template <int DC>
 __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double s, double inv_l2, double jitter) {
   const Fit& f = g_sh.f;
   Shared& sh = g_sh;
   const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D, nb = Mp / 16;
-  gd* L = f.mat[B_L];
   gd* LT = f.mat[B_LT];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
@@ -873,10 +871,6 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
       pb[i * 17 + c] = acc;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L rows: 16 contiguous columns
-      const int i = idx >> 4, c = idx & 15;
-      L[(size_t)(16 * (kb + 1) + i) * Mp + 16 * kb + c] = pb[i * 17 + c];
-    }
     if (rows_below > 0)
       for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L^T rows: contiguous in i
         const int c = idx / rows_below, i = idx - c * rows_below;
@@ -902,7 +896,6 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
   const Fit& f = g_sh.f;
   Shared& sh = g_sh;
   const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D, nb = Mp / 16;
-  gd* L = f.mat[B_L];
   gd* LT = f.mat[B_LT];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
@@ -972,10 +965,6 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
       for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * st], lb[4 * st], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
-    }
-    for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L rows: 16 contiguous columns
-      const int i = idx >> 4, c = idx & 15;
-      L[(size_t)(16 * (kb + 1) + i) * Mp + 16 * kb + c] = pb[i * 17 + c];
     }
     if (rows_below > 0)
       for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L^T rows: contiguous in i

@@ -396,7 +396,9 @@ int gapro_fit_timing_offsets(gapro_ctx* ctx, gapro_fit_timing* ref, gapro_fit_ti
 /* Offsets (doubles, relative to a fit's ws_offset) of the fit's workspace regions, so tests can
  * inspect trained parameters: out8 = {Mp, matrices, vectors, X/Z block, test points, Dinv blocks,
  * scalars, total}.  Matrices are Mp x Mp row-major in the order LS, LS^T, Adam m/v of LS, G_LS, L,
- * L^T, L^-1, L^-T, KX, A, A^T, B, B^T, G_A, G_KX, G_KX^T; scalars: c, rho_s, rho_l, ... , loss. */
+ * L^T, L^-1, L^-T, KX, A, A^T, B, B^T, G_A, G_KX, G_KX^T; scalars: c, rho_s, rho_l, ... , loss.
+ * Which of the intermediate slots a fit fills depends on its kernel (the single-workgroup MFMA kernels keep L^T but
+ * not L, and up to M_p = 256 no A^T / B^T): trained parameters -- L_S, m (vector 1), Z, the scalars -- always. */
 int gapro_fit_workspace_layout(int32_t m, int32_t t, int32_t feat_dim, int64_t* out8);
 /* C[16x16] = P^T Q for row-major P, Q with 16 columns and K rows (K % 4 == 0): checks the
  * v_mfma_f64_16x16x4_f64 lane maps the fit kernel relies on. */
