@@ -113,6 +113,7 @@ SIGNATURES = {
                                        C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_fit_workspace_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P]),
     "gapro_fit_route": (C.c_int, [C.c_int32, C.c_int32]),
+    "gapro_fit_padded_m": (C.c_int, [C.c_int32, C.c_int32]),
     "gapro_fit_timing_create": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
     "gapro_fit_timing_destroy": (None, [_P]),
     "gapro_fit_timing_arm": (C.c_int, [_P, _P]),

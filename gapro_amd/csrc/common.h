@@ -58,11 +58,29 @@ int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, co
 // beyond 176: 8 % more work on average at M = 200).  From 352 on its 64 x 64 tiles need multiples of 32, and so does
 // the cluster kernel (M_p >= 512).
 // (M_p = 240 is skipped: 256 runs the workgroup-tiled products, and M = 230 is 5 % faster padded to 256 than to 240)
+// Round 4: the padded size is a function of (M, D).  An odd multiple of 16 beyond the strip kernels'
+// range is only handed out where the LDS-staged kernel takes the fit (its half-tile edges are the reason the step of 16
+// exists); a fit whose points do not fit beside the Cholesky panel (deep features: D = 32 beyond M_p = 208) runs on the
+// cluster kernel, which needs multiples of 32, and keeps round 2's padding.  Before, M = 257 .. 336 at D = 32 padded
+// to 272 / 304 / 336 fell through to the generic kernel.
 constexpr int kPad16MaxMp = 336;
-inline __host__ __device__ int gapro_pad_m(int m) {
+constexpr int kPad16AlwaysMp = 128;           // up to here every multiple of 16 runs on a strip / staged / generic route
+constexpr long long kStagedMaxDynLds = 150 * 1024;  // dynamic LDS budget of the staged kernel (svgp_fit.hip kMaxDynLds)
+// dynamic LDS bytes of the LDS-staged kernel (512 threads) for a PADDED size beyond kFuseMaxMp = 128:
+// Zt | Xt | max(reduction slots, Cholesky block column, operand ring); svgp_fit.hip checks this against its own
+// staged_lds_bytes
+inline __host__ __device__ long long gapro_staged_lds_bytes_mp(int Mp, int d) {
+  const long long red = 8 * 512, panel = (long long)Mp * 17 + 64 * 17, ring = 2 * 2 * 8 * (128 + 16);
+  long long s = red > panel ? red : panel;
+  s = s > ring ? s : ring;
+  return 8LL * (2LL * d * Mp + s);
+}
+inline __host__ __device__ int gapro_pad_m(int m, int d) {
   if (m < 1) m = 1;
-  const int p16 = (m + 15) / 16 * 16;
-  return p16 <= kPad16MaxMp && p16 != 240 ? p16 : (m + 31) / 32 * 32;
+  const int p16 = (m + 15) / 16 * 16, p32 = (m + 31) / 32 * 32;
+  if (p16 == p32 || p16 <= kPad16AlwaysMp) return p16;
+  if (p16 > kPad16MaxMp || p16 == 240) return p32;
+  return (d <= 32 && gapro_staged_lds_bytes_mp(p16, d) <= kStagedMaxDynLds) ? p16 : p32;
 }
 
 inline int gapro_fail(gapro_ctx* ctx, int code, const char* fmt, ...) {

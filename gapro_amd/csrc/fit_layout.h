@@ -63,7 +63,7 @@ struct Layout {
 };
 inline __host__ __device__ Layout make_layout(int m, int t, int d) {
   Layout L;
-  L.Mp = gapro_pad_m(m);
+  L.Mp = gapro_pad_m(m, d);
   L.Tp = round_up(t > 0 ? t : 1, 32);
   L.D = d;
   L.mat = 0;

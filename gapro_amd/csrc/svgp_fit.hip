@@ -114,11 +114,12 @@ inline __host__ __device__ int scratch_doubles(int Mp) {
   return m > c ? m : c;
 }
 inline __host__ __device__ long long staged_lds_bytes(int m, int d) {
-  const int Mp = gapro_pad_m(m);
+  const int Mp = gapro_pad_m(m, d);
   return 8LL * (2LL * d * Mp + scratch_doubles(Mp));
 }
+// (gapro_pad_m decides from gapro_staged_lds_bytes_mp, common.h: the two must agree beyond kFuseMaxMp)
 inline __host__ __device__ bool staged_ok(int m, int d) {
-  return gapro_pad_m(m) <= kMaxMpLds && d <= 32 && staged_lds_bytes(m, d) <= kMaxDynLds;
+  return gapro_pad_m(m, d) <= kMaxMpLds && d <= 32 && staged_lds_bytes(m, d) <= kMaxDynLds;
 }
 
 
@@ -2051,7 +2052,7 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   const int fit = blockIdx.x;
   if (fit >= n_fits) return;
   const gapro_fit_desc desc = descs[fit];
-  const int Mp = gapro_pad_m(desc.m1 + desc.m2);
+  const int Mp = gapro_pad_m(desc.m1 + desc.m2, D);
   ldsd* Zt = (ldsd*)dyn_lds;
   ldsd* Pt = Zt + D * Mp;
   ldsd* scratch = Pt + D * Mp;
@@ -2111,11 +2112,11 @@ inline __host__ __device__ int strip_region_doubles(int Mp) {
   return m > c ? m : c;
 }
 inline __host__ __device__ long long strip_lds_bytes(int m, int d) {
-  const int Mp = gapro_pad_m(m);
+  const int Mp = gapro_pad_m(m, d);
   return 8LL * (2LL * d * Mp + strip_region_doubles(Mp) + 3 * NT + Mp + 4 * SW + 32);
 }
 inline __host__ __device__ bool strip_ok(int m, int d) {
-  return gapro_pad_m(m) <= kStripMaxMp && d <= 32 && strip_lds_bytes(m, d) <= kMaxDynLds;
+  return gapro_pad_m(m, d) <= kStripMaxMp && d <= 32 && strip_lds_bytes(m, d) <= kMaxDynLds;
 }
 
 enum { K_LE = 0, K_GE = 1 };
@@ -2869,7 +2870,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, con
   const int fit = blockIdx.x;
   if (fit >= n_fits) return;
   const gapro_fit_desc desc = descs[fit];
-  const int Mp = gapro_pad_m(desc.m1 + desc.m2);
+  const int Mp = gapro_pad_m(desc.m1 + desc.m2, D);
   ldsd* Zt = (ldsd*)dyn_lds;
   ldsd* Pt = Zt + D * Mp;
   ldsd* region = Pt + D * Mp;
@@ -2989,15 +2990,15 @@ __global__ void k_stream_calib(long long n, const double* __restrict__ src, doub
 constexpr int kSmallFitMp = 64;
 static int fit_route(int m, int feat_dim, int flags) {
   // large fits: spread over several CUs (svgp_fit_cluster.hip); debug bit 3 keeps them on one workgroup
-  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m), (flags & 16) != 0) > 0) return 4;
+  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m, feat_dim), (flags & 16) != 0) > 0) return 4;
   if (!(flags & 1) && strip_ok(m, feat_dim)) {
-    const bool small = gapro_pad_m(m) <= kSmallFitMp && 2 * gapro_fit_strip_small_lds_bytes(m, feat_dim) + 16384 <= 160 * 1024;
+    const bool small = gapro_pad_m(m, feat_dim) <= kSmallFitMp && 2 * gapro_fit_strip_small_lds_bytes(m, feat_dim) + 16384 <= 160 * 1024;
     return (small && !(flags & 4)) ? 3 : 0;
   }
   if (staged_ok(m, feat_dim)) return 1;
   // neither LDS-resident kernel takes it (deep features: Z and X of M_p > 192 points at D = 32 do not fit beside the
   // Cholesky block column): the cluster kernel keeps the points in global memory and runs such a fit on one workgroup
-  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m), true) > 0) return 4;
+  if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m, feat_dim), true) > 0) return 4;
   return 2;
 }
 
@@ -3088,7 +3089,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     const long long b = staged_lds_bytes(d.m1 + d.m2, feat_dim);
     // (the product forms of a fit are a function of its M_p, k_svgp_fit's KMIN: fits beyond kKminMaxMp are a launch of
     // their own -- with D = 6 exactly the fits that need more than kTwice)
-    const bool kmaj = gapro_pad_m(d.m1 + d.m2) > kKminMaxMp;
+    const bool kmaj = gapro_pad_m(d.m1 + d.m2, feat_dim) > kKminMaxMp;
     if (kmaj) {
       ++nkmaj;
       lds_kmaj = std::max(lds_kmaj, b);
@@ -3165,7 +3166,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     std::vector<int> fi(clus.size()), fmp(clus.size()), fg(clus.size());
     for (size_t k = 0; k < clus.size(); ++k) {
       fi[k] = (int)(clus_base + k);
-      fmp[k] = gapro_pad_m(clus[k].m1 + clus[k].m2);
+      fmp[k] = gapro_pad_m(clus[k].m1 + clus[k].m2, feat_dim);
       fg[k] = gapro_cluster_size(fmp[k], true);
     }
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[6], s_clus));
@@ -3268,6 +3269,8 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
 }
 
 int gapro_fit_route(int32_t m, int32_t feat_dim) { return fit_route(m, feat_dim, 0); }
+
+int gapro_fit_padded_m(int32_t m, int32_t feat_dim) { return gapro_pad_m(m, feat_dim); }
 
 int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
   if (!ctx || !out) return GAPRO_ERR_BAD_ARG;

@@ -816,7 +816,9 @@ __global__ __launch_bounds__(NT) void k_svgp_fit_large(int n_fits, int D, const 
 #endif
   }
   __syncthreads();
-  if (Mp >= 128)
+  // 32 x 32 wave tiles need M_p to be a multiple of 32: fit_body<2> counts tiles as M_p / 32 and would leave the last 16
+  // rows / columns of an odd multiple of 16 uncomputed (D > 32 reaches this kernel with M_p = 144, 176, ...)
+  if (Mp >= 128 && Mp % 32 == 0)
     fit_body<2>(f, opt, sh, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);
   else
     fit_body<1>(f, opt, sh, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, &o_loss[desc.slot]);

@@ -789,8 +789,7 @@ class Pipeline:
             r = np.array([route[int(v)] for v in m])
             if flags & 16:
                 for v in np.unique(m):
-                    mp = (int(v) + 15) // 16 * 16
-                    mp = mp if mp <= 336 and mp != 240 else (int(v) + 31) // 32 * 32  # gapro_pad_m (csrc/common.h)
+                    mp = int(lib.gapro_fit_padded_m(int(v), D))
                     if mp >= 64 and mp % 32 == 0 and D <= 32:
                         r[m == v] = 4
             if flags & 8:  # no cluster kernel: those fits run where they ran in round 1

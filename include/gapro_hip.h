@@ -372,6 +372,9 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t f
  * two fits per CU), 4 = the cluster kernel (M_p >= 512: one fit spread over 4..32 workgroups with cluster barriers;
  * also, on one workgroup, every fit that fits neither LDS kernel).  M_p = m padded to the MFMA tile. */
 int gapro_fit_route(int32_t m, int32_t feat_dim);
+/* Padded size M_p of a fit's M x M matrices (a multiple of 16; of 32 where the kernel that takes the fit needs it):
+ * a function of (M, D) only, never of the routing options.  The workspace layout is built on it. */
+int gapro_fit_padded_m(int32_t m, int32_t feat_dim);
 
 /* Optional device-side timing of one fit launch (bench.py's roofline figure).  gapro_svgp_fit_batch runs
  * its kernels on streams the context owns (cluster, staged, strip and small-fit strip kernel side by side), so

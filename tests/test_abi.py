@@ -56,3 +56,28 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_padding_and_route_agree_for_every_size_and_feature_width():
+    """the padded size must be one the kernel the fit is routed to can run.  Odd multiples of 16
+    beyond the strip range exist only on the LDS-staged route; a fit the cluster kernel takes is padded to 32; the
+    generic kernel (D > 32) takes any multiple of 16 (its 32 x 32 tiles only at multiples of 32)."""
+    lib = _lib.load()
+    for d in (6, 16, 32, 40):
+        for m in range(2, 1200):
+            mp, r = lib.gapro_fit_padded_m(m, d), lib.gapro_fit_route(m, d)
+            assert mp >= m and mp % 16 == 0 and mp - m < 32
+            if r == 4:
+                assert mp % 32 == 0 and mp >= 64, (m, d, mp)
+            if r in (0, 3):
+                assert mp <= 128
+            if r == 2:
+                assert d > 32, (m, d, mp)  # nothing the reference's feature widths produce reaches the generic kernel
+            if d > 32:
+                assert r == 2
+    # deep features beyond the staged kernel's LDS: round 3 padded these to 272 / 304 / 336 and the generic kernel
+    # then skipped their last 16 rows
+    for m, mp in [(260, 288), (272, 288), (300, 320), (304, 320), (330, 352), (336, 352), (200, 208), (209, 224)]:
+        assert lib.gapro_fit_padded_m(m, 32) == mp, m
+        assert lib.gapro_fit_route(m, 32) == (1 if mp <= 208 else 4), m
+    assert [lib.gapro_fit_padded_m(m, 6) for m in (130, 200, 230, 260, 300, 330, 340)] == [144, 208, 256, 272, 304, 336, 352]

@@ -187,6 +187,27 @@ def test_fit_matches_oracle_where_m_p_is_an_odd_multiple_of_16(m1, m2, t):
     _compare(out, _oracle(feats, b1, b2, it, 50))
 
 
+@pytest.mark.parametrize("d", [32, 40])
+@pytest.mark.parametrize("m1,m2,t", [(130, 135, 21), (150, 150, 30), (160, 170, 12)])
+def test_wide_features_where_round_3_padded_to_an_odd_multiple_of_16(m1, m2, t, d):
+    """M = 265 / 300 / 330.  At D = 32 these fit neither LDS kernel, are padded to a multiple of 32
+    (gapro_pad_m is a function of (M, D)) and run on the cluster kernel; at D = 40 they run on the generic kernel, padded
+    to 32 as well (and its 32 x 32 tiles are only used where M_p is a multiple of 32).  Round 3 sent both to the generic kernel with M_p = 272 /
+    304 / 336 and left the last 16 rows and columns of every product uncomputed."""
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    lib = _lib.load()
+    m = m1 + m2
+    assert lib.gapro_fit_route(m, d) == (4 if d == 32 else 2)
+    mp = lib.gapro_fit_padded_m(m, d)
+    assert mp % 32 == 0 and mp >= m
+    feats, b1, b2, it = make_gp_problem(900 + m1, m1, m2, t, d, std=0.3)
+    out = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=50)[0]
+    _compare(out, _oracle(feats, b1, b2, it, 50))
+
+
 def test_two_per_cu_build_has_the_bits_of_the_one_per_cu_build():
     """The staged kernel has one instantiation per register budget and product form (k_svgp_fit<WPS, KMIN>); a launch
     with more fits than CUs runs its M_p <= 256 fits two per CU in the 128-VGPR build, a smaller one in the 256-VGPR
