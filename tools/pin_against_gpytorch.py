@@ -15,9 +15,22 @@ switches of the oracle and of ``gapro_fit_options``:
 This script builds EXACTLY the objects the reference builds -- the classes below are written from the reference's
 call sites, the script imports gpytorch only, never the reference -- and runs the reference's 50 Adam steps on every
 KAT's inputs, with the one source of non-determinism removed (the variational mean is initialised to zero instead of
-gpytorch's unseeded 1e-3 * randn: SURVEY B.3 / U3), once in float64 (``torch.set_default_dtype(torch.float64)``) and
-once in the stock float32.  For every KAT it prints the largest relative difference of mu / sigma^2 / p against the
-``fresh`` and ``stale`` vectors and against a jitter-1e-3 oracle run, and ends with a one-line verdict for U1 and U2.
+gpytorch's unseeded 1e-3 * randn: SURVEY B.3 / U3):
+
+  * in float64 CONFIGURED AS THE FLOAT32 MODEL the reference runs.  gpytorch's numerical settings are dtype-dependent
+    (``variational_cholesky_jitter`` 1e-4 for float / 1e-6 for double, ``min_variance`` 1e-6 / 1e-10,
+    ``cholesky_jitter`` 1e-6 / 1e-8), so ``torch.set_default_dtype(torch.float64)`` alone evaluates a DIFFERENT model
+    than the reference's float32 one.  The float64 runs are therefore wrapped in
+    ``variational_cholesky_jitter(float_value=j, double_value=j)``, ``min_variance(float_value=1e-6,
+    double_value=1e-6)`` and ``cholesky_jitter(float_value=1e-6, double_value=1e-8)`` (``f32_model_settings`` below),
+    once per candidate j in {1e-4, 1e-3}, and each is compared with the oracle run at THE SAME jitter: the distance that
+    is printed is a measured one, not the nearer of two wrong answers;
+  * in the stock float32 with the installed defaults untouched (what the reference actually executes).
+
+The installed defaults per dtype are printed; U2 is read from them (the float32 value of
+``variational_cholesky_jitter``) and must be one of the two jitters whose float64 run came out pinned.  For every KAT
+the script prints the largest relative difference of mu / sigma^2 / p against the ``fresh`` and ``stale`` vectors, and
+it ends with a one-line verdict for U1 and U2.
 
     python tools/pin_against_gpytorch.py [--kats m50_d6,m100_d6] [--iters 50] [--json out.json]
     python tools/pin_against_gpytorch.py --self-check     # no gpytorch needed: the oracle plays gpytorch's part
@@ -27,6 +40,7 @@ then report 'fresh' and 'jitter 1e-4' with differences at float64 round-off); te
 Nothing here is part of the product, and nothing here runs on the GPU box.
 """
 import argparse
+import contextlib
 import glob
 import json
 import os
@@ -46,9 +60,11 @@ def load_kat(name):
     return z, X, y, z["feats"][z["it"]]
 
 
-def run_gpytorch(X, y, Xt, iters, dtype):
+def run_gpytorch(X, y, Xt, iters, dtype, jitter=1e-4):
     """The reference's fit_gp_spp on (train_x, train_y, intersect_feats), gaussian_process_utils.py:395-438, with the
-    initial variational mean forced to zero.  dtype: 'f64' or 'f32' (gpytorch's stock precision)."""
+    initial variational mean forced to zero.  dtype: 'f32' = gpytorch's stock precision with the installed defaults
+    untouched (`jitter` is ignored); 'f64' = float64 arithmetic on the float32-CONFIGURED model with variational jitter
+    `jitter` (f32_model_settings)."""
     import gpytorch
     import torch
     from gpytorch.mlls.variational_elbo import VariationalELBO
@@ -74,49 +90,96 @@ def run_gpytorch(X, y, Xt, iters, dtype):
     old = torch.get_default_dtype()
     torch.set_default_dtype(T)
     try:
-        train_x = torch.as_tensor(X, dtype=T)
-        train_y = torch.as_tensor(y, dtype=T)
-        test_x = torch.as_tensor(Xt, dtype=T)
-        model = GPClassificationModel(train_x)
-        likelihood = gpytorch.likelihoods.BernoulliLikelihood()
-        # U3: gpytorch adds mean_init_std * randn to the variational mean on the first forward
-        # (CholeskyVariationalDistribution.initialize_variational_distribution); switch it off
-        vd = model.variational_strategy._variational_distribution
-        if hasattr(vd, "mean_init_std"):
-            vd.mean_init_std = 0.0
-        model.train()
-        likelihood.train()
-        optimizer = torch.optim.Adam(model.parameters(), lr=0.1)
-        mll = VariationalELBO(likelihood, model, train_y.numel())
-        losses = []
-        for _ in range(iters):
-            output = model(train_x)
-            loss = -mll(output, train_y)
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
-            losses.append(float(loss))
-        model.eval()
-        likelihood.eval()
-        with torch.no_grad():
-            f_pred = model(test_x)
-            p = likelihood(f_pred).mean
-            out = (f_pred.mean.double().numpy(), f_pred.variance.double().numpy(), p.double().numpy())
-        info = dict(version=getattr(gpytorch, "__version__", "?"),
-                    jitter_setting=float(gpytorch.settings.variational_cholesky_jitter.value(T))
-                    if hasattr(gpytorch.settings, "variational_cholesky_jitter") else None, loss=losses)
+        with contextlib.ExitStack() as stack:
+            if dtype == "f64":  # the float32-configured model, evaluated in float64
+                for cm in f32_model_settings(gpytorch.settings, jitter):
+                    stack.enter_context(cm)
+            train_x = torch.as_tensor(X, dtype=T)
+            train_y = torch.as_tensor(y, dtype=T)
+            test_x = torch.as_tensor(Xt, dtype=T)
+            model = GPClassificationModel(train_x)
+            likelihood = gpytorch.likelihoods.BernoulliLikelihood()
+            # U3: gpytorch adds mean_init_std * randn to the variational mean on the first forward
+            # (CholeskyVariationalDistribution.initialize_variational_distribution); switch it off
+            vd = model.variational_strategy._variational_distribution
+            if hasattr(vd, "mean_init_std"):
+                vd.mean_init_std = 0.0
+            model.train()
+            likelihood.train()
+            optimizer = torch.optim.Adam(model.parameters(), lr=0.1)
+            mll = VariationalELBO(likelihood, model, train_y.numel())
+            losses = []
+            for _ in range(iters):
+                output = model(train_x)
+                loss = -mll(output, train_y)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                losses.append(float(loss))
+            model.eval()
+            likelihood.eval()
+            with torch.no_grad():
+                f_pred = model(test_x)
+                p = likelihood(f_pred).mean
+                out = (f_pred.mean.double().numpy(), f_pred.variance.double().numpy(), p.double().numpy())
+        info = dict(version=getattr(gpytorch, "__version__", "?"), defaults=installed_defaults(gpytorch.settings, torch),
+                    loss=losses)
         return out, info
     finally:
         torch.set_default_dtype(old)
 
 
-def run_stand_in(X, y, Xt, iters, dtype):
-    """--self-check: the oracle in gpytorch's seat (fresh Cholesky, jitter 1e-4)."""
+# The reference runs gpytorch in float32 (gen_ps.py:79-89 uploads float32 features, nothing sets a default dtype), so the
+# model it evaluates is the one gpytorch's FLOAT values configure.  These are the settings whose value depends on the
+# dtype and that the reference's path reaches (VariationalStrategy: variational_cholesky_jitter on K_ZZ;
+# MultivariateNormal.variance: min_variance clamp; psd_safe_cholesky: cholesky_jitter retries -- done in float64 by
+# gpytorch whatever the input dtype, hence double_value 1e-8 stays).
+F32_MODEL = {"min_variance": dict(float_value=1e-6, double_value=1e-6),
+             "cholesky_jitter": dict(float_value=1e-6, double_value=1e-8)}
+
+
+def f32_model_settings(settings, jitter):
+    """Context managers that make a float64 run evaluate the float32-configured model with variational jitter `jitter`
+    for BOTH dtypes.  `settings` is gpytorch.settings (tests/test_pin_script.py passes a recording fake).  A setting the
+    installed version lacks is reported, not ignored silently."""
+    cms = []
+    want = dict(F32_MODEL)
+    want["variational_cholesky_jitter"] = dict(float_value=float(jitter), double_value=float(jitter))
+    for name in ("variational_cholesky_jitter", "min_variance", "cholesky_jitter"):
+        cls = getattr(settings, name, None)
+        if cls is None:
+            print("NOTE  gpytorch.settings.%s does not exist in this version: its value cannot be forced" % name)
+            continue
+        cms.append(cls(**want[name]))
+    return cms
+
+
+def installed_defaults(settings, torch):
+    """{setting: {"float": v, "double": v}} of the installed gpytorch (None where the setting does not exist)."""
+    out = {}
+    for name in ("variational_cholesky_jitter", "min_variance", "cholesky_jitter"):
+        cls = getattr(settings, name, None)
+        if cls is None or not hasattr(cls, "value"):
+            out[name] = None
+            continue
+        try:
+            out[name] = {"float": float(cls.value(torch.float32)), "double": float(cls.value(torch.float64))}
+        except TypeError:  # very old versions: one value for every dtype
+            out[name] = {"float": float(cls.value()), "double": float(cls.value())}
+    return out
+
+
+def run_stand_in(X, y, Xt, iters, dtype, jitter=1e-4):
+    """--self-check: the oracle in gpytorch's seat (fresh Cholesky; the jitter it is asked for in 'f64', the stock 1e-4
+    in 'f32')."""
     from oracle import svgp_oracle as so
 
     out, st = so.svgp_fit_predict_autograd(np.asarray(X, np.float64), y, np.asarray(Xt, np.float64), iters,
-                                           "f64" if dtype == "f64" else "mixed", return_trace=True)
-    return out, dict(version="self-check (oracle/svgp_oracle.py)", jitter_setting=1e-4, loss=st["loss"])
+                                           "f64" if dtype == "f64" else "mixed", return_trace=True,
+                                           jitter=jitter if dtype == "f64" else 1e-4)
+    defaults = {"variational_cholesky_jitter": {"float": 1e-4, "double": 1e-6},
+                "min_variance": {"float": 1e-6, "double": 1e-10}, "cholesky_jitter": {"float": 1e-6, "double": 1e-8}}
+    return out, dict(version="self-check (oracle/svgp_oracle.py)", defaults=defaults, loss=st["loss"])
 
 
 def rel(a, b):
@@ -142,55 +205,81 @@ def main():
         except ImportError:
             print("gpytorch is not installed: install the version your GaPro checkout runs with, or use --self-check")
             return 2
-    report, votes_u1, votes_u2 = {}, [], []
+    report, votes_u1 = {}, []
+    JITTERS = (1e-4, 1e-3)
+    defaults = None
     for name in names:
         z, X, y, Xt = load_kat(name)
         if len(X) > args.max_m:
             continue
-        if args.iters != 50:  # the frozen vectors are 50-step results: other step counts compare with a fresh oracle run
-            (mu_f, var_f, p_f) = so.svgp_fit_predict_autograd(X.astype(np.float64), y, Xt.astype(np.float64), args.iters)
-            (mu_s, var_s, _) = so.svgp_fit_predict_autograd(X.astype(np.float64), y, Xt.astype(np.float64), args.iters,
-                                                            eval_chol="stale")
-        else:
-            mu_f, var_f, p_f, mu_s, var_s = z["mu"], z["var"], z["p"], z["mu_stale"], z["var_stale"]
-        (mu_j3, var_j3, _) = so.svgp_fit_predict_autograd(X.astype(np.float64), y, Xt.astype(np.float64), args.iters,
-                                                          jitter=1e-3)
-        row = {"M": int(len(X)), "D": int(X.shape[1])}
-        for dt in ("f64", "f32"):
-            (mu, var, p), info = runner(X, y, Xt, args.iters, dt)
-            row[dt] = {"var_vs_fresh": rel(var, var_f), "var_vs_stale": rel(var, var_s), "var_vs_jitter1e-3": rel(var, var_j3),
-                       "mu_vs_fresh": rel(mu, mu_f), "mu_vs_stale": rel(mu, mu_s), "p_vs_fresh": float(np.max(np.abs(p - p_f))),
-                       "loss_first": info["loss"][0] if info["loss"] else None,
-                       "loss_last": info["loss"][-1] if info["loss"] else None}
-            row["gpytorch"] = info["version"]
-            row["jitter_setting"] = info["jitter_setting"]
-        r = row["f64"]
+        X64, Xt64 = X.astype(np.float64), Xt.astype(np.float64)
+        # oracle targets: fresh / stale at the KATs' jitter 1e-4 (frozen for 50 steps), and fresh / stale at 1e-3
+        tgt = {}
+        for j in JITTERS:
+            if j == 1e-4 and args.iters == 50:
+                tgt[j] = dict(mu_f=z["mu"], var_f=z["var"], p_f=z["p"], mu_s=z["mu_stale"], var_s=z["var_stale"])
+            else:
+                mu_f, var_f, p_f = so.svgp_fit_predict_autograd(X64, y, Xt64, args.iters, jitter=j)
+                mu_s, var_s, _ = so.svgp_fit_predict_autograd(X64, y, Xt64, args.iters, jitter=j, eval_chol="stale")
+                tgt[j] = dict(mu_f=mu_f, var_f=var_f, p_f=p_f, mu_s=mu_s, var_s=var_s)
+        row = {"M": int(len(X)), "D": int(X.shape[1]), "f64": {}}
+        for j in JITTERS:  # float64 arithmetic, float32-configured model, jitter j for both dtypes
+            (mu, var, p), info = runner(X, y, Xt, args.iters, "f64", j)
+            t = tgt[j]
+            row["f64"]["%g" % j] = {"var_vs_fresh": rel(var, t["var_f"]), "var_vs_stale": rel(var, t["var_s"]),
+                                    "mu_vs_fresh": rel(mu, t["mu_f"]), "mu_vs_stale": rel(mu, t["mu_s"]),
+                                    "p_vs_fresh": float(np.max(np.abs(p - t["p_f"]))),
+                                    "var_vs_other_jitter": rel(var, tgt[JITTERS[1 - JITTERS.index(j)]]["var_f"]),
+                                    "loss_first": info["loss"][0] if info["loss"] else None,
+                                    "loss_last": info["loss"][-1] if info["loss"] else None}
+        (mu, var, p), info = runner(X, y, Xt, args.iters, "f32")  # the stock run: installed defaults, float32
+        defaults = info["defaults"]
+        jd = (defaults.get("variational_cholesky_jitter") or {}).get("float")
+        t = tgt[jd] if jd in tgt else tgt[1e-4]
+        row["f32"] = {"var_vs_fresh": rel(var, t["var_f"]), "mu_vs_fresh": rel(mu, t["mu_f"]),
+                      "p_vs_fresh": float(np.max(np.abs(p - t["p_f"]))), "compared_with_jitter": jd if jd in tgt else 1e-4}
+        row["gpytorch"] = info["version"]
+        row["defaults"] = defaults
+        best = {j: min(row["f64"]["%g" % j]["var_vs_fresh"], row["f64"]["%g" % j]["var_vs_stale"]) for j in JITTERS}
+        r = row["f64"]["%g" % 1e-4]
         votes_u1.append("fresh" if r["var_vs_fresh"] <= r["var_vs_stale"] else "stale")
-        votes_u2.append("1e-4" if r["var_vs_fresh"] <= r["var_vs_jitter1e-3"] else "1e-3")
+        row["pinned_at"] = best
         report[name] = row
-        print("%-10s M=%3d D=%2d  f64: var vs fresh %.2e / stale %.2e / jitter-1e-3 %.2e, mu vs fresh %.2e, p %.2e   "
-              "f32: var vs fresh %.2e, mu %.2e" % (name, row["M"], row["D"], r["var_vs_fresh"], r["var_vs_stale"],
-                                                   r["var_vs_jitter1e-3"], r["mu_vs_fresh"], r["p_vs_fresh"],
-                                                   row["f32"]["var_vs_fresh"], row["f32"]["mu_vs_fresh"]), flush=True)
+        print("%-10s M=%3d D=%2d  f64 j=1e-4: var vs fresh %.2e / stale %.2e (other jitter's target %.2e), mu %.2e, p %.2e   "
+              "f64 j=1e-3: var vs fresh %.2e / stale %.2e   f32 stock: var %.2e, mu %.2e"
+              % (name, row["M"], row["D"], r["var_vs_fresh"], r["var_vs_stale"], r["var_vs_other_jitter"],
+                 r["mu_vs_fresh"], r["p_vs_fresh"], row["f64"]["0.001"]["var_vs_fresh"], row["f64"]["0.001"]["var_vs_stale"],
+                 row["f32"]["var_vs_fresh"], row["f32"]["mu_vs_fresh"]), flush=True)
     if not report:
         print("no KAT selected")
         return 1
-    worst = max(min(r["f64"]["var_vs_fresh"], r["f64"]["var_vs_stale"]) for r in report.values())
+    print("installed defaults (float / double): " + "; ".join(
+        "%s = %s" % (k, "absent" if v is None else "%g / %g" % (v["float"], v["double"])) for k, v in defaults.items()))
     u1 = max(set(votes_u1), key=votes_u1.count)
-    u2 = max(set(votes_u2), key=votes_u2.count)
-    verdict = ("VERDICT  gpytorch %s: U1 eval Cholesky = %s (%d/%d KATs), U2 jitter = %s (%d/%d); float64 run within %.1e of "
-               "the matching KAT vectors -> %s" % (next(iter(report.values()))["gpytorch"], u1, votes_u1.count(u1),
-                                                    len(votes_u1), u2, votes_u2.count(u2), len(votes_u2), worst,
-                                                    "PINNED (target 1e-4)" if worst < 1e-4 else
-                                                    "NOT pinned: read the rows above"))
+    worst = {j: max(r["pinned_at"][j] for r in report.values()) for j in JITTERS}
+    jd = (defaults.get("variational_cholesky_jitter") or {}).get("float")
+    if jd in worst:
+        u2 = "%g" % jd  # what the reference's float32 run uses: read from the installed settings, not guessed
+    else:
+        u2 = "unknown (%s)" % ("setting absent" if jd is None else "installed float default %g is neither candidate" % jd)
+    pinned = all(w < 1e-4 for w in worst.values())
+    verdict = ("VERDICT  gpytorch %s: U1 eval Cholesky = %s (%d/%d KATs); U2 variational jitter of the float32 model = %s "
+               "(installed default); float64 runs of the float32-configured model within %.1e (jitter 1e-4) / %.1e "
+               "(jitter 1e-3) of the oracle at the same jitter -> %s"
+               % (next(iter(report.values()))["gpytorch"], u1, votes_u1.count(u1), len(votes_u1), u2, worst[1e-4],
+                  worst[1e-3], "PINNED (target 1e-4)" if pinned else "NOT pinned: read the rows above"))
     print(verdict)
     if u1 == "stale":
         print("         set gapro_fit_options.eval_stale_chol = 1 (Pipeline(eval_stale_chol=True)) to reproduce this gpytorch")
-    if u2 == "1e-3":
+    if u2 == "0.001":
         print("         set gapro_fit_options.jitter = 1e-3 to reproduce this gpytorch")
+    md = defaults.get("min_variance")
+    if md is not None and md["float"] != 1e-6:
+        print("         the installed min_variance(float) is %g: set gapro_fit_options.min_variance to it" % md["float"])
     if args.json:
         with open(args.json, "w") as f:
-            json.dump({"kats": report, "u1": u1, "u2": u2, "worst_var_rel": worst, "verdict": verdict}, f, indent=1)
+            json.dump({"kats": report, "u1": u1, "u2": u2, "worst_var_rel": worst[1e-4], "worst_var_rel_jitter1e-3": worst[1e-3],
+                       "installed_defaults": defaults, "verdict": verdict}, f, indent=1, default=float)
     return 0
 
 
