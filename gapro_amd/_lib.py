@@ -16,7 +16,10 @@ GAPRO_OK = 0
 GAPRO_ERR_NOT_FINITE = -4
 GAPRO_ERR_CHOLESKY = -5
 STATUS_NAMES = {0: "OK", -1: "BAD_ARG", -2: "OOM", -3: "HIP", -4: "NOT_FINITE", -5: "CHOLESKY", -6: "SPP_RANGE",
-                -7: "WORKSPACE", -8: "TIMEOUT"}
+                -7: "WORKSPACE", -8: "TIMEOUT", -9: "IO", -10: "UNSUPPORTED"}
+GAPRO_ERR_TIMEOUT = -8
+GAPRO_ERR_IO = -9
+GAPRO_ERR_UNSUPPORTED = -10
 
 
 class GaproError(RuntimeError):
@@ -52,6 +55,12 @@ class SceneTask(C.Structure):
                 ("point_count", C.c_void_p), ("feats_spp", C.c_void_p), ("occ_bits", C.c_void_p),
                 ("n_bbs", C.c_void_p), ("sem_spp", C.c_void_p), ("inst_spp", C.c_void_p), ("prob_spp", C.c_void_p),
                 ("sem", C.c_void_p), ("inst", C.c_void_p), ("prob", C.c_void_p)]
+
+
+class PthArray(C.Structure):
+    """gapro_pth_array: one NumPy array of a torch.save()d file."""
+    _fields_ = [("kind", C.c_int32), ("itemsize", C.c_int32), ("ndim", C.c_int32), ("encoded", C.c_int32),
+                ("shape", C.c_int64 * 4), ("nbytes", C.c_int64)]
 
 
 class InstanceHeader(C.Structure):
@@ -119,6 +128,14 @@ SIGNATURES = {
     "gapro_fit_timing_arm": (C.c_int, [_P, _P]),
     "gapro_fit_timing_read": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "gapro_fit_timing_offsets": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "gapro_pth_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "gapro_pth_count": (C.c_int, [_P]),
+    "gapro_pth_is_sequence": (C.c_int, [_P]),
+    "gapro_pth_info": (C.c_int, [_P, C.c_int32, C.POINTER(PthArray)]),
+    "gapro_pth_read": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
+    "gapro_pth_close": (None, [_P]),
+    "gapro_pth_write": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(PthArray), C.POINTER(_P), C.c_int32]),
+    "gapro_pth_last_error": (C.c_char_p, []),
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "gapro_debug_stream": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
     "gapro_debug_mfma_peak": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),

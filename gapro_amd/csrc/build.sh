@@ -5,7 +5,7 @@
 # stamps (libgapro_hip_prof.so: never used by the product or the tests).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-srcs=(ctx.hip partition.hip svgp_fit.hip svgp_fit_small.hip svgp_fit_large.hip svgp_fit_cluster.hip labels.hip consumer.hip debug_peak.hip schedule.cpp)
+srcs=(ctx.hip partition.hip svgp_fit.hip svgp_fit_small.hip svgp_fit_large.hip svgp_fit_cluster.hip labels.hip consumer.hip debug_peak.hip schedule.cpp pth_io.cc)
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed)
 
 build_lib() {  # $1 = object directory, $2 = output library, rest = extra flags
@@ -22,7 +22,11 @@ build_lib() {  # $1 = object directory, $2 = output library, rest = extra flags
     # svgp_fit_small.hip is svgp_fit.hip built a second time
     [[ "$s" == "svgp_fit_small.hip" ]] && { t=$(stat -c %Y "${here}/svgp_fit.hip"); (( t > so )) && so=$t; }
     if [[ ! -f "$o" ]] || (( $(stat -c %Y "$o") < so )) || (( $(stat -c %Y "$o") < newest_hdr )); then
-      hipcc "${flags[@]}" "$@" -c -o "$o" "${here}/${s}" &
+      if [[ "$s" == *.cc ]]; then  # host-only C++ (no HIP headers): the system compiler, no device pass
+        g++ -O3 -std=c++17 -fPIC -Wall -c -o "$o" "${here}/${s}" &
+      else
+        hipcc "${flags[@]}" "$@" -c -o "$o" "${here}/${s}" &
+      fi
       pids+=($!)
     fi
   done

@@ -30,13 +30,23 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
                            (np.memmap) and upload straight from the page cache -- no unpickling, no loader process,
                            no shared-memory copy.  A cache whose source files changed is rebuilt.  Unpickling the
                            ScanNet .pth tuples is what caps the loaders at ~350 scenes/s per host
-    --loader_threads T     threads that read scenes from disk a batch ahead and write the results (default 4)
-    --loader_procs P       read and write in P loader PROCESSES (default -1 = min(16, physical cores / (2 W)) per
-                           worker for W workers, at most cores/4; 0 = threads only).
-                           Unpickling a ScanNet .pth holds the GIL, so threads top out near one core; processes
-                           hand the arrays over in POSIX shared memory (through the pipe when /dev/shm is full)
-                           and the loader threads only upload from it.  The pool is started before the worker
-                           touches the GPU.
+    --loader_threads T     threads that read scenes from disk two batches ahead, upload them and write the results
+                           (default -1 = min(16, physical cores / (2 W)) per worker for W workers, at least 4).
+                           Round 4: the scene and label files go through the native reader / writer (gapro_pth_*:
+                           no unpickling, no pickling, GIL released), so plain threads of the worker process feed a
+                           GPU and NO loader process is started by default.
+    --loader_procs P       read and write in P loader PROCESSES instead (default -1 = none with the native reader; the
+                           round-1..3 pool of min(16, physical cores / (2 W)) processes when GAPRO_NATIVE_PTH=0:
+                           unpickling a ScanNet .pth holds the GIL, so threads top out near one core; processes hand
+                           the arrays over in POSIX shared memory).  The pool is started before the worker touches
+                           the GPU.
+
+Exit status: 0 = every scene of the list is written (or was already there); 3 = the run finished but at least one scene
+was skipped or failed (no instances, unreadable file, non-finite input, a GP fit that stayed non-positive-definite or
+timed out twice): their scan names are listed on stderr, every other scene is written, and a re-run retries only
+those; 1 = a worker process died (its claimed-but-unwritten scenes are picked up by a re-run: finished scenes are
+skipped by their output files).  With --eval_pslabel the run ends with the reference's `Mean instance iou of pseudo
+labels` line (gen_ps.py:133-135) over ALL scenes processed by this run, aggregated across --devices workers.
 
 Differences from the reference, on purpose: output files are written atomically (tmp + rename); a scene
 that fails to load is reported and skipped instead of killing the run; a scene without instances (the
@@ -58,6 +68,7 @@ from glob import glob
 import numpy as np
 import torch
 
+from . import pth_io
 from .dist_utils import ClaimQueue, pending_scenes, shard_scenes, shard_scenes_lpt
 from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device
 from .pipeline import Pipeline, make_job
@@ -68,8 +79,10 @@ def read_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
     """gen_ps.py:37-69, the disk / host half (thread-safe, no device work): load the scene, build the features
     from UN-aligned xyz, axis-align, read the wall quads."""
     scan_name = filename.split("/")[-1][:12]
-    xyz, rgb, semantic_label, instance_label = torch.load(filename, weights_only=False)
-    spp = torch.load(osp.join(data_root, "superpoints", scan_name + ".pth"), weights_only=False)
+    # pth_io.load: the native reader (gapro_pth_*: no unpickling, GIL released) where the file is a NumPy payload as
+    # prepare_data_inst.py:104 / prepare_superpoint.py:27 write it, torch.load for anything else
+    xyz, rgb, semantic_label, instance_label = pth_io.load(filename)
+    spp = pth_io.load(osp.join(data_root, "superpoints", scan_name + ".pth"))
     spp = spp.numpy() if isinstance(spp, torch.Tensor) else np.asarray(spp)
     if use_deepfeat:
         mask_feats = torch.load(osp.join(deepfeat_folder, scan_name + ".pth"), weights_only=False)
@@ -114,8 +127,17 @@ def save_scene(save_path, outs, spp_inv=None, broadcast_mu_var=False):
     if broadcast_mu_var:
         mu, var = mu[spp_inv.long()], var[spp_inv.long()]
     tup = (sem.int().cpu().numpy(), ins.int().cpu().numpy(), prob.cpu().numpy(), mu.cpu().numpy(), var.cpu().numpy())
+    write_label_file(save_path, tup)
+
+
+def write_label_file(save_path, tup):
+    """The 5-tuple of NumPy arrays as a torch.load()-able file (gen_ps.py:132), atomically: the native writer
+    (gapro_pth_write: no pickling under the GIL; names numpy.core.multiarray, which NumPy 1.x -- the reference's own
+    environment -- and 2.x both import), torch.save where it declines (an empty array)."""
+    if pth_io.native_enabled() and pth_io.save_arrays(save_path, tup, as_tuple=True):
+        return
     tmp = save_path + ".tmp.%d" % os.getpid()
-    torch.save(tup, tmp)
+    torch.save(tuple(tup), tmp)
     os.replace(tmp, save_path)
 
 
@@ -334,9 +356,7 @@ def _save_arrays(save_path, arrays, spp_inv=None):
     sem, ins, prob, mu, var = arrays
     if spp_inv is not None:
         mu, var = mu[spp_inv], var[spp_inv]
-    tmp = save_path + ".tmp.%d" % os.getpid()
-    torch.save((sem, ins, prob, mu, var), tmp)
-    os.replace(tmp, save_path)
+    write_label_file(save_path, (sem, ins, prob, mu, var))
 
 
 _T_IMPORT = time.time()
@@ -351,11 +371,17 @@ def run_worker(filenames, args, device_index):
 
     n_procs = int(getattr(args, "loader_procs", 0))
     n_workers = max(1, int(getattr(args, "n_workers", 1)))  # GPU workers sharing this host (--devices)
+    native = pth_io.native_enabled()
+    phys = max(1, (os.cpu_count() or 2) // 2)
+    n_threads = int(getattr(args, "loader_threads", -1))
+    if n_threads <= 0:  # auto: with the native reader the threads ARE the loaders
+        n_threads = min(16, max(4, phys // (2 * n_workers))) if native else 4
+    if n_procs < 0 and native:
+        n_procs = 0  # nothing left that holds the GIL for long: no loader process, no shared-memory hand-over
     if n_procs < 0:
         # auto: at most 16 per worker (more only adds start-up time: 16 -> 32 -> 64 loaders: 223 -> 200 -> 159 scenes/s),
         # and all workers' loaders together at most half the physical cores -- eight workers x 16 loaders on one host
         # oversubscribe it long before eight GPUs are fed
-        phys = max(1, (os.cpu_count() or 2) // 2)
         n_procs = min(16, max(2, phys // (2 * n_workers)), (os.cpu_count() or 1) // 4)
         if n_procs < 2:  # a small host: one loader process is no faster than the threads
             n_procs = 0
@@ -368,6 +394,8 @@ def run_worker(filenames, args, device_index):
     pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest of its batch is written
     dev = pipe.device
     done = failed = 0
+    failed_names = []  # scan names of every scene this worker could not write (exit status 3)
+    miou = {}          # --eval_pslabel: scan name -> per-instance IoUs (float32), gen_ps.py:116-124
     t0 = time.time()
     queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
 
@@ -385,7 +413,7 @@ def run_worker(filenames, args, device_index):
             pending = pending_scenes(filenames, args.save_folder)
             for i in range(0, len(pending), args.batch_scenes):
                 yield pending[i:i + args.batch_scenes]
-    pool = cf.ThreadPoolExecutor(max_workers=max(1, args.loader_threads))
+    pool = cf.ThreadPoolExecutor(max_workers=max(1, n_threads))
     meta = []  # per yielded batch: (scenes, jobs)
     read_args = (args.data_root, args.use_deepfeat, args.deepfeat_folder)
     raw_cache = getattr(args, "raw_cache", None)
@@ -441,6 +469,27 @@ def run_worker(filenames, args, device_index):
                 print("[gen_ps] raw cache not written for %s: %r" % (fn, e), file=sys.stderr)
         return sc
 
+    def read_upload(fn):
+        """Pool thread, no loader process: native read (GIL released while the payloads are transcoded), host
+        preprocessing in NumPy, upload through the thread's pinned stager, GT boxes on the device."""
+        sc = read_and_cache(fn)
+        with torch.cuda.stream(side_stream()):
+            dev_sc = dict(scan_name=sc["scan_name"])
+            for k in _SHM_KEYS:
+                if k not in _DEVICE_DTYPES:
+                    dev_sc[k] = sc[k]
+            dev_sc.update(stager().upload({k: sc[k] for k in _DEVICE_DTYPES}, _DEVICE_DTYPES))
+            return add_instance_info(dev_sc, dev)
+
+    def export_native(path, job, o, ready):
+        """Pool thread, no loader process: device -> host on the thread's stream, then the native writer."""
+        st = side_stream()
+        with torch.cuda.stream(st):
+            st.wait_event(ready)
+            arrays = (o[0].int().cpu().numpy(), o[1].int().cpu().numpy()) + tuple(t.cpu().numpy() for t in o[2:])
+            inv = job.spp_inv.cpu().numpy() if args.broadcast_mu_var else None
+        _save_arrays(path, arrays, inv)
+
     def submit(chunk):
         out, misses = [], []
         for fn in chunk:
@@ -454,7 +503,7 @@ def run_worker(filenames, args, device_index):
             reads = [(fn, procs.apply_async(_read_scene_shm, (fn,) + read_args + (raw_cache,))) for fn in misses]
             out += [(fn, pool.submit(upload, r), True) for fn, r in reads]
         else:
-            out += [(fn, pool.submit(read_and_cache, fn), False) for fn in misses]
+            out += [(fn, pool.submit(read_upload, fn), True) for fn in misses]
         order = {fn: i for i, fn in enumerate(chunk)}
         return sorted(out, key=lambda e: order[e[0]])
 
@@ -493,11 +542,13 @@ def run_worker(filenames, args, device_index):
                     if sc is None:
                         print("[gen_ps] %s: no instances, skipped" % fn, file=sys.stderr)
                         failed += 1
+                        failed_names.append(fn.split("/")[-1][:12])
                         continue
                     scenes.append(sc)
                 except Exception as e:  # noqa: BLE001 - one bad scene must not kill the run
                     print("[gen_ps] %s: load failed: %r" % (fn, e), file=sys.stderr)
                     failed += 1
+                    failed_names.append(fn.split("/")[-1][:12])
             if not scenes:
                 continue
             t = time.time()
@@ -525,6 +576,12 @@ def run_worker(filenames, args, device_index):
             yield outs
 
     host_only = bool(os.environ.get("GAPRO_DRIVER_HOST_ONLY"))
+    out_folder = args.save_folder
+    if host_only:  # a measurement mode must never leave files that look like pseudo-labels
+        out_folder = osp.normpath(args.save_folder) + ".HOST_ONLY_MEASUREMENT"
+        os.makedirs(out_folder, exist_ok=True)
+        print("[gen_ps] WARNING: GAPRO_DRIVER_HOST_ONLY is set: NO pseudo-labels are generated; the all-zero stand-in "
+              "outputs go to %s, never to --save_folder" % out_folder, file=sys.stderr)
     writes = []
     t_first = None
     for outs in (host_only_stream(batches()) if host_only else pipe.run_stream(batches())):
@@ -537,6 +594,7 @@ def run_worker(filenames, args, device_index):
             if o is None:  # Pipeline.strict = False: this scene could not be processed, the others could
                 print("[gen_ps] warning: %s skipped: %s" % (s["scan_name"], job.error), file=sys.stderr)
                 failed += 1
+                failed_names.append(s["scan_name"])
                 continue
             if args.eval_pslabel:
                 from .eval_ps_labels import get_miou_scene
@@ -547,18 +605,23 @@ def run_worker(filenames, args, device_index):
                 sem_gt[(sem_gt == -1) | (sem_gt == -2)] = 18
                 ious = get_miou_scene(sem_gt.long(), ins_gt.long(), o[0].long(), o[1].long())
                 print("miou", ious)
-            path = osp.join(args.save_folder, s["scan_name"] + ".pth")
+                miou[s["scan_name"]] = ious.float().cpu().numpy()  # :125 ious_arr.append(ious)
+            path = osp.join(out_folder, s["scan_name"] + ".pth")
             if procs is not None:
                 writes.append(pool.submit(export, path, job, o, ready))
-            else:  # device -> host here; the file write goes to the pool
-                host = tuple(t.cpu() for t in o)
-                inv = job.spp_inv.cpu() if args.broadcast_mu_var else None
-                writes.append(pool.submit(save_scene, path, host, inv, args.broadcast_mu_var))
+            else:  # device -> host and the file write on a pool thread (native writer: no GIL)
+                writes.append(pool.submit(export_native, path, job, o, ready))
             done += 1
         spent["export"] += time.time() - t_exp
     try:
         for w in writes:
-            w.result().get() if procs is not None else w.result()
+            try:
+                w.result().get() if procs is not None else w.result()
+            except Exception as e:  # noqa: BLE001 - a failed write loses that scene, not the run
+                print("[gen_ps] a label file could not be written: %r" % (e,), file=sys.stderr)
+                failed += 1
+                done -= 1
+                failed_names.append("<write failed: %r>" % (e,))
     finally:  # queued writes are flushed and the loader processes released whatever happened above
         pool.shutdown()
         if procs is not None:
@@ -571,11 +634,60 @@ def run_worker(filenames, args, device_index):
     # start-up is reported apart from the rate: at ~300 scenes/s a 1201-scene split is a few seconds of work, and the
     # spawned interpreters / library loads of a worker and its loaders take longer than that
     print("[gen_ps] device %d: start-up %.1f s (process start -> generator ready), first batch out after %.1f s more, "
-          "%d loader processes%s" % (device_index, t0 - _T_IMPORT, (t_first - t0) if t_first else 0.0, n_procs,
-                                     ", host-only measurement mode" if host_only else ""))
+          "%d loader threads, %d loader processes, %s file I/O%s"
+          % (device_index, t0 - _T_IMPORT, (t_first - t0) if t_first else 0.0, n_threads, n_procs,
+             "native (gapro_pth_*)" if native else "torch.load / torch.save",
+             ", host-only measurement mode" if host_only else ""))
     if os.environ.get("GAPRO_DRIVER_TIMES"):
         print("[gen_ps] main-thread seconds: " + ", ".join("%s %.2f" % kv for kv in spent.items()))
-    return done, failed
+    result = dict(done=done, failed=sorted(failed_names), miou={k: [float(x) for x in v] for k, v in miou.items()},
+                  seconds=dt, startup_seconds=t0 - _T_IMPORT, first_batch_seconds=(t_first - t0) if t_first else 0.0,
+                  timeout_retries=int(getattr(pipe, "timeout_retries", 0)))
+    job_dir = getattr(args, "job_dir", None)
+    if job_dir:  # several workers: the parent aggregates (mean IoU over all scenes, failed scans, exit status)
+        import json
+
+        tmp = osp.join(job_dir, "result.%d.json.tmp" % device_index_rank(args))
+        with open(tmp, "w") as fh:
+            json.dump(result, fh)
+        os.replace(tmp, tmp[:-4])
+    return result
+
+
+def device_index_rank(args):
+    return max(int(getattr(args, "worker_rank", -1)), 0)
+
+
+def mean_instance_iou(miou_by_scan):
+    """gen_ps.py:133-135: torch.mean over the per-instance IoUs of every scene, concatenated in the (sorted) scene
+    order the reference iterates in; float32 as there.  None when no scene was evaluated."""
+    arrs = [torch.as_tensor(np.asarray(miou_by_scan[k], dtype=np.float32)) for k in sorted(miou_by_scan)]
+    arrs = [a for a in arrs if a.numel()]
+    if not arrs:
+        return None
+    return torch.mean(torch.cat(arrs, dim=0)).item()
+
+
+def finish_run(args, results, crashed=()):
+    """End of a run (one worker or the parent of several): the reference's summary line, the list of scenes that were
+    not written, the exit status (0 / 3 / 1: see the module docstring)."""
+    miou, failed = {}, []
+    for r in results:
+        miou.update(r.get("miou", {}))
+        failed += list(r.get("failed", []))
+    if args.eval_pslabel:
+        m = mean_instance_iou(miou)
+        if m is not None:
+            print("Mean instance iou of pseudo labels", m)  # :135
+    if crashed:
+        print("[gen_ps] worker(s) %s died: the scenes they had claimed but not written are NOT done; run the same "
+              "command again -- finished scenes are skipped by their output files (a fresh claim directory is used per "
+              "run)" % ", ".join(str(c) for c in crashed), file=sys.stderr)
+    if failed:
+        print("[gen_ps] %d scene(s) skipped or failed, not written: %s" % (len(failed), " ".join(sorted(failed))),
+              file=sys.stderr)
+    print("Finish")
+    return 1 if crashed else (3 if failed else 0)
 
 
 def main(argv=None):
@@ -593,11 +705,12 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--broadcast_mu_var", action="store_true")
     parser.add_argument("--raw_cache", type=str, default=None)
-    parser.add_argument("--loader_threads", type=int, default=4)
+    parser.add_argument("--loader_threads", type=int, default=-1)
     parser.add_argument("--loader_procs", type=int, default=-1)
     parser.add_argument("--farm", type=str, default="queue", choices=["queue", "lpt", "roundrobin"])
     parser.add_argument("--worker_rank", type=int, default=-1, help=argparse.SUPPRESS)
     parser.add_argument("--claim_dir", type=str, default=None, help=argparse.SUPPRESS)
+    parser.add_argument("--job_dir", type=str, default=None, help=argparse.SUPPRESS)
     args = parser.parse_args(argv)
 
     os.makedirs(args.save_folder, exist_ok=True)
@@ -620,31 +733,41 @@ def main(argv=None):
             mine = shard_scenes(filenames, r, len(devices))
         else:  # "lpt", or "queue" without a claim directory (a worker started by hand)
             mine = shard_scenes_lpt(filenames, r, len(devices))
-        run_worker(mine, args, devices[r])
-    else:
-        import shutil
-        import subprocess
+        result = run_worker(mine, args, devices[r])
+        if args.worker_rank >= 0 and args.job_dir:  # a child of the farm: the parent prints the summary
+            return 3 if result["failed"] else 0
+        return finish_run(args, [result])
+    import json
+    import shutil
+    import subprocess
 
-        extra = []
-        claim_dir = None
-        if args.farm == "queue":  # a fresh claim directory per job; the OUTPUT files are what a restart skips
-            claim_dir = osp.join(args.save_folder, ".claims.%d.%d" % (os.getpid(), int(time.time())))
-            os.makedirs(claim_dir)
-            extra = ["--claim_dir", claim_dir]
-        procs = []
-        try:
-            for r in range(len(devices)):
-                cmd = [sys.executable, "-m", "gapro_amd.gen_ps"] + (argv if argv is not None else sys.argv[1:]) + \
-                      ["--worker_rank", str(r)] + extra
-                procs.append(subprocess.Popen(cmd))
-            rc = [p.wait() for p in procs]
-        finally:
-            if claim_dir is not None:
-                shutil.rmtree(claim_dir, ignore_errors=True)
-        if any(rc):
-            raise SystemExit("a worker failed: %r" % rc)
-    print("Finish")
+    # a fresh job directory per run: the workers' claim files (queue farm) and their result files (mean IoU, failed
+    # scans); the OUTPUT files are what a restart skips
+    job_dir = osp.join(args.save_folder, ".job.%d.%d" % (os.getpid(), int(time.time())))
+    os.makedirs(job_dir)
+    extra = ["--job_dir", job_dir]
+    if args.farm == "queue":
+        claim_dir = osp.join(job_dir, "claims")
+        os.makedirs(claim_dir)
+        extra += ["--claim_dir", claim_dir]
+    procs, results, crashed = [], [], []
+    try:
+        for r in range(len(devices)):
+            cmd = [sys.executable, "-m", "gapro_amd.gen_ps"] + (argv if argv is not None else sys.argv[1:]) + \
+                  ["--worker_rank", str(r)] + extra
+            procs.append(subprocess.Popen(cmd))
+        rc = [p.wait() for p in procs]
+        for r, code in enumerate(rc):
+            path = osp.join(job_dir, "result.%d.json" % r)
+            if code in (0, 3) and osp.exists(path):
+                with open(path) as fh:
+                    results.append(json.load(fh))
+            else:
+                crashed.append("%d (device %d, exit status %r)" % (r, devices[r], code))
+    finally:
+        shutil.rmtree(job_dir, ignore_errors=True)
+    return finish_run(args, results, crashed)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

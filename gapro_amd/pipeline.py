@@ -15,6 +15,7 @@ torch is used only to own device memory and streams; all arithmetic happens in l
 from __future__ import annotations
 
 import os
+import sys
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
@@ -222,8 +223,23 @@ class Pipeline:
         self.opt.precision = 1 if precision == "mixed" else 0
         if cluster_all:
             self.opt.reserved |= 16
-        # A/B runs only: further debug bits of gapro_fit_options.reserved (include/gapro_hip.h) from the environment
-        self.opt.reserved |= int(os.environ.get("GAPRO_FIT_FLAGS", "0"), 0)
+        # A/B runs and tests only: further debug bits of gapro_fit_options.reserved (include/gapro_hip.h) from the
+        # environment.  Never silent: a leaked variable changes the routing of every fit.
+        env_flags = os.environ.get("GAPRO_FIT_FLAGS", "").strip()
+        if env_flags:
+            try:
+                bits = int(env_flags, 0)
+            except ValueError:
+                raise ValueError("GAPRO_FIT_FLAGS=%r is not an integer (debug bits of gapro_fit_options.reserved)"
+                                 % env_flags) from None
+            if bits:
+                print("[gapro_amd] GAPRO_FIT_FLAGS=0x%x: debug routing bits are ORed into every fit launch of this "
+                      "process (measurement / test setting, not a product mode)" % bits, file=sys.stderr)
+            self.opt.reserved |= bits
+        # a fit that comes back GAPRO_ERR_TIMEOUT (a cluster member was not resident in time: transient, unlike a failed
+        # factorisation) is run once more on the single-workgroup route before its scene is given up
+        self.retry_timeouts = True
+        self.timeout_retries = 0  # fits that went through the retry, over the life of this object
         self.init_mean_std = float(init_mean_std)
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap
@@ -649,6 +665,9 @@ class Pipeline:
             self.last_stats = dict(n_fits=0, n_fit_out=0, fit=None)
             return [None for _ in state["all_jobs"]]
         res = self.fit_collect(state["pending"], raise_on_failure=False) if state["pending"] is not None else None
+        if res is not None:
+            res = self._retry_timeouts(res, state["feats_spp_all"], state["descs"], state["h_idx"], state["n_out"],
+                                       slot=state["slot"], scene_keys=[j.scene_key for j in jobs])
         _mark("D fit")
         if res is not None and (res["status"] != 0).any():
             # per-fit status -> per-scene failure: only the scenes that own a failed fit are lost
@@ -727,8 +746,48 @@ class Pipeline:
     def fit_descs(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
                   init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, raise_on_failure: bool = True):
         """Launch a batch of fits and wait for the results (numpy arrays)."""
-        return self.fit_collect(self.fit_launch(feats_spp, descs, n_fits, h_idx, n_out, init_mean, keep_debug),
-                                raise_on_failure)
+        res = self.fit_collect(self.fit_launch(feats_spp, descs, n_fits, h_idx, n_out, init_mean, keep_debug),
+                               raise_on_failure=False)
+        res = self._retry_timeouts(res, feats_spp, descs, h_idx, n_out, init_mean=init_mean)
+        if raise_on_failure and (res["status"] != 0).any():
+            bad = int(np.nonzero(res["status"])[0][0])
+            raise _lib.GaproError(int(res["status"][bad]), "fit %d of %d failed" % (bad, n_fits))
+        return res
+
+    def _retry_timeouts(self, res, feats_spp, descs, h_idx, n_out, init_mean=None, slot="s0", scene_keys=None):
+        """Fits whose status is GAPRO_ERR_TIMEOUT are launched once more with the cluster kernel switched off (debug
+        bit 3 of gapro_fit_options.reserved: the LDS-staged kernel up to M_p = 512, the generic kernel beyond -- one
+        workgroup each, no cross-workgroup barrier that could time out) and their outputs, status and loss replace the
+        first attempt's.  A timeout says that a member of the fit's cluster was not given a CU within
+        GAPRO_CLUSTER_BARRIER_TIMEOUT_MS; the arithmetic never ran to an end, so there is nothing deterministic about
+        the failure and the second attempt computes what the first one would have (the per-fit result does not
+        depend on the kernel beyond float64 round-off: tests/test_fit_gpu.py).  Same descriptors, same index array,
+        same output offsets; only the workspace is the retry's own."""
+        bad = np.nonzero(res["status"] == _lib.GAPRO_ERR_TIMEOUT)[0]
+        if not len(bad) or not self.retry_timeouts:
+            return res
+        sub = (FitDesc * len(bad))()
+        for k, i in enumerate(bad):
+            C.memmove(C.byref(sub, k * C.sizeof(FitDesc)), C.byref(descs, int(i) * C.sizeof(FitDesc)), C.sizeof(FitDesc))
+        print("[gapro_amd] %d GP fit(s) timed out at a cluster barrier; retrying them on one workgroup each"
+              % len(bad), file=sys.stderr)
+        old = self.opt.reserved
+        self.opt.reserved = (int(old) | 8) & ~32768
+        try:
+            r2 = self.fit_collect(self.fit_launch(feats_spp, sub, len(bad), h_idx, n_out, init_mean, slot=slot + "retry",
+                                                  scene_keys=scene_keys), raise_on_failure=False)
+        finally:
+            self.opt.reserved = old
+        for k, i in enumerate(bad):
+            d = descs[int(i)]
+            a, b = int(d.out_offset), int(d.out_offset) + int(d.t)
+            for key in ("probs", "probs_new", "mu", "var", "labels"):
+                res[key][a:b] = r2[key][a:b]
+            res["status"][i] = r2["status"][k]
+            res["loss"][i] = r2["loss"][k]
+        self.timeout_retries += len(bad)
+        res["retried"] = [int(i) for i in bad]
+        return res
 
     def fit_launch(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
                    init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, slot: str = "s0",

@@ -40,9 +40,12 @@ typedef enum {
   GAPRO_ERR_CHOLESKY = -5,     /* K_ZZ + jitter*I not positive definite */
   GAPRO_ERR_SPP_RANGE = -6,    /* superpoint id range exceeds the rank-table capacity */
   GAPRO_ERR_WORKSPACE = -7,    /* workspace too small */
-  GAPRO_ERR_TIMEOUT = -8       /* a fit spread over several workgroups gave up at a cluster barrier: a member was
+  GAPRO_ERR_TIMEOUT = -8,      /* a fit spread over several workgroups gave up at a cluster barrier: a member was
                                 * not resident within GAPRO_CLUSTER_BARRIER_TIMEOUT_MS (default 5000); per-fit
                                 * status like GAPRO_ERR_CHOLESKY, the launch's other fits are unaffected */
+  GAPRO_ERR_IO = -9,           /* gapro_pth_*: open / read / write failed, or a damaged file */
+  GAPRO_ERR_UNSUPPORTED = -10  /* gapro_pth_*: a well-formed file this reader does not handle (compressed member,
+                                * tensor storages, object / big-endian / Fortran arrays, ...): fall back to torch.load */
 } gapro_status;
 
 typedef struct gapro_ctx gapro_ctx;
@@ -392,6 +395,41 @@ int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5);
  * the tail of the previous one runs, and a start event fires when its stream reaches it, not when the kernel gets
  * CUs): bench.py counts the overlapped time once when it averages launch durations.  Blocks until t has finished. */
 int gapro_fit_timing_offsets(gapro_ctx* ctx, gapro_fit_timing* ref, gapro_fit_timing* t, float* out_ms2);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene / label files (host; no device, no ctx, no Python objects -- callable from any thread without the GIL).
+ * Replaces the `torch.load` of gen_ps.py:45-46 (scene tuple written by ISBNet/dataset/scannetv2/prepare_data_inst.py:104,
+ * superpoint ids written by prepare_superpoint.py:27) and the `torch.save` of gen_ps.py:132.
+ *
+ * A torch.save()d NumPy array / tuple of NumPy arrays is a stored zip whose data.pkl (pickle protocol 2) holds every
+ * array buffer as latin-1 text re-encoded as UTF-8; unpickling it costs ~25 ms of a core per ScanNet scene under the GIL.
+ * gapro_pth_open maps the file and walks the pickle; gapro_pth_read transcodes one array's payload back to bytes
+ * straight into the caller's buffer (e.g. pinned staging memory).  GAPRO_ERR_UNSUPPORTED = well-formed but not handled
+ * here: the caller falls back to torch.load.  Errors: gapro_pth_last_error() (thread-local text).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gapro_pth_file gapro_pth_file;
+typedef struct gapro_pth_array {
+  int32_t kind;      /* NumPy dtype kind character: 'f', 'i', 'u' or 'b' (bool) */
+  int32_t itemsize;  /* bytes per element: 1, 2, 4 or 8 (little-endian) */
+  int32_t ndim;      /* 0..4 */
+  int32_t encoded;   /* read: 1 = stored as UTF-8 text (protocol 2), 0 = raw bytes (protocol >= 3); ignored on write */
+  int64_t shape[4];  /* C order; entries beyond ndim are 1 */
+  int64_t nbytes;    /* prod(shape) * itemsize */
+} gapro_pth_array;
+int gapro_pth_open(const char* path, gapro_pth_file** out);
+/* number of arrays (1 for a bare array), and whether the top-level object is a tuple / list */
+int gapro_pth_count(const gapro_pth_file* f);
+int gapro_pth_is_sequence(const gapro_pth_file* f);
+int gapro_pth_info(const gapro_pth_file* f, int32_t index, gapro_pth_array* out);
+/* decode array `index` into h_dst; dst_bytes must equal its nbytes */
+int gapro_pth_read(const gapro_pth_file* f, int32_t index, void* h_dst, int64_t dst_bytes);
+void gapro_pth_close(gapro_pth_file* f);
+/* Write n_arrays host arrays as one torch.load()-able file (tuple when as_tuple, else the single bare array):
+ * stored zip, protocol-2 pickle naming numpy.core.multiarray (importable by NumPy 1.x and 2.x); written to a
+ * temporary name in the same directory and renamed (atomic). */
+int gapro_pth_write(const char* path, int32_t n_arrays, const gapro_pth_array* descs, const void* const* h_data,
+                    int32_t as_tuple);
+const char* gapro_pth_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
  * Debug / test entry points (not needed by a caller of the path).

@@ -170,8 +170,10 @@ def test_cli_loader_processes_write_the_same_files(tmp_path):
 @pytest.mark.gpu
 def test_cli_a_scene_with_a_nan_feature_is_skipped_and_the_rest_of_its_batch_is_written(tmp_path):
     """One bad scene must not kill the run (the reference would propagate the NaN into every kernel
-    matrix of the scene and gpytorch would raise): 4 scenes in ONE batch, the second has a NaN colour -> 3 files, exit
-    code 0, one warning, and the 3 files equal those of a run without the bad scene."""
+    matrix of the scene and gpytorch would raise): 4 scenes in ONE batch, the second has a NaN colour -> 3 files, one
+    warning, and the 3 files equal those of a run without the bad scene.  The exit status says so: 3 =
+    finished, but the scans listed on stderr were not written -- a training pipeline downstream must not find out by
+    missing labels; the clean run returns 0."""
     import subprocess
     import sys
 
@@ -187,7 +189,10 @@ def test_cli_a_scene_with_a_nan_feature_is_skipped_and_the_rest_of_its_batch_is_
     r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", a, "--data_root", root,
                         "--batch_scenes", "4", "--loader_procs", "2"], cwd=repo, capture_output=True, text=True,
                        timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 3, r.stderr[-2000:]
+    listed = [l for l in r.stderr.splitlines() if "skipped or failed, not written" in l]
+    assert len(listed) == 1 and listed[0].rstrip().endswith(bad.scan_name) and "1 scene(s)" in listed[0]
+    assert r.stdout.rstrip().endswith("Finish")
     assert sorted(os.listdir(a)) == sorted(s.scan_name + ".pth" for s in scenes if s is not bad)
     warn = [l for l in r.stderr.splitlines() if "warning" in l and bad.scan_name in l]
     assert len(warn) == 1 and "NOT_FINITE" in warn[0], r.stderr[-2000:]
@@ -204,6 +209,54 @@ def test_cli_a_scene_with_a_nan_feature_is_skipped_and_the_rest_of_its_batch_is_
         for u, v in zip(torch.load(os.path.join(a, s.scan_name + ".pth"), weights_only=False),
                         torch.load(os.path.join(b, s.scan_name + ".pth"), weights_only=False)):
             np.testing.assert_array_equal(u, v)
+
+
+@pytest.mark.gpu
+def test_cli_mean_instance_iou_is_aggregated_over_all_workers(tmp_path):
+    """gen_ps.py:116-124, 133-135: with --eval_pslabel the run ends with `Mean instance iou of pseudo labels` =
+    torch.mean over the per-instance IoUs of ALL scenes.  With `--devices 0,0` every worker evaluates its own scenes
+    and the parent aggregates their result files: the line must equal the mean of the per-scene values recomputed here
+    from the written label files, and the single-worker run's line, bit for bit (same float32 reduction over the
+    scenes in sorted order).  A worker that skipped a scene makes the farm return 3."""
+    import subprocess
+    import sys
+
+    from gapro_amd.eval_ps_labels import get_miou_scene
+
+    root, scenes = _dataset(tmp_path, 6)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    means = []
+    for k, extra in enumerate((["--devices", "0,0", "--farm", "lpt"], [])):
+        save = str(tmp_path / ("run%d" % k))
+        r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", root,
+                            "--batch_scenes", "2", "--eval_pslabel"] + extra, cwd=repo, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("Mean instance iou of pseudo labels")]
+        assert len(lines) == 1 and r.stdout.count("miou tensor") == len(scenes), r.stdout[-2000:]
+        means.append(float(lines[0].split()[-1]))
+        assert not [f for f in os.listdir(save) if f.startswith(".")]  # the job directory is gone
+    per_scene = []
+    for s in sorted(scenes, key=lambda s: s.scan_name):
+        sem, ins, _, _, _ = torch.load(os.path.join(tmp_path, "run0", s.scan_name + ".pth"), weights_only=False)
+        sem_gt = torch.from_numpy(s.sem).cuda().int()
+        ins_gt = torch.from_numpy(s.inst).cuda().int()
+        sem_gt[sem_gt != -100] -= 2
+        sem_gt[(sem_gt == -1) | (sem_gt == -2)] = 18
+        per_scene.append(get_miou_scene(sem_gt.long(), ins_gt.long(), torch.from_numpy(sem).cuda().long(),
+                                        torch.from_numpy(ins).cuda().long()).float().cpu())
+    want = torch.mean(torch.cat(per_scene)).item()
+    assert means[0] == means[1] == want, (means, want)
+    # one scene without any instance: skipped by its worker, listed by the parent, exit status 3
+    fn = os.path.join(root, "train", scenes[2].scan_name + "_inst_nostuff.pth")
+    xyz, rgb, sem, inst = torch.load(fn, weights_only=False)
+    torch.save((xyz, rgb, sem, np.full_like(inst, -100.0)), fn)
+    save = str(tmp_path / "run2")
+    r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", root,
+                        "--batch_scenes", "2", "--devices", "0,0"], cwd=repo, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 3, r.stderr[-2000:]
+    assert [l for l in r.stderr.splitlines() if "not written: " + scenes[2].scan_name in l]
+    assert len(os.listdir(save)) == len(scenes) - 1
 
 
 @pytest.mark.gpu

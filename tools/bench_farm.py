@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""The product path at farm scale: `gen_ps --devices d0,d1,..` over an on-disk dataset of ScanNet-layout files.
+
+    python tools/bench_farm.py --data_root <dir>/dataset/scannetv2 --devices 0[,1,..] [--passes 2] [--batch 32]
+
+What BASELINE.json's north_star names -- "full ScanNetV2-train pseudo-label generation at 8xMI355X" -- is this command:
+files in (`torch.save`d scene tuples + superpoint ids + alignment + plane quads), files out (5-tuples), one worker
+process per GPU sharing the scene list through the claim queue, no collective.  bench.py writes the dataset (its 1201
+log-normal-sized stream scenes, one file set per scene) while it generates the resident copies, and calls this tool
+after the timed region; the result is the `gen_ps_farm` key of the bench line (never `value`).
+
+Every pass writes into a fresh label folder.  Pass 1 reads the `.pth` files as the dataset writer left them (page cache
+warm: the files were just written; a cold first pass additionally pays the disk), pass 2 the same again; with
+--raw_cache a third pass maps the raw scene cache the second one wrote.  Rate = scenes / the slowest worker's own clock
+(generator ready -> last file written); start-up (interpreter, library load, loader pool) is reported apart, as is the
+wall clock of the whole command.  Prints one line starting with "JSON ".
+"""
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one_pass(data_root, save, devices, batch, raw_cache, extra):
+    cmd = [sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", data_root, "--batch_scenes",
+           str(batch), "--devices", devices, "--raw_cache", raw_cache or "none"] + extra
+    t = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    wall = time.time() - t
+    txt = r.stdout
+    done = [(int(a), int(b), float(c)) for a, b, c in
+            re.findall(r"(\d+) scenes written, (\d+) skipped/failed, ([\d.]+) s", txt)]
+    start = [float(a) for a in re.findall(r"start-up ([\d.]+) s", txt)]
+    first = [float(a) for a in re.findall(r"first batch out after ([\d.]+) s", txt)]
+    io = re.findall(r"(\d+) loader threads, (\d+) loader processes, ([^,\n]+) file I/O", txt)
+    n = sum(d for d, _, _ in done)
+    slow = max((t for _, _, t in done), default=0.0)
+    out = dict(exit_status=r.returncode, scenes=n, failed=sum(f for _, f, _ in done),
+               scenes_per_s=round(n / slow, 2) if slow > 0 else 0.0, slowest_worker_s=round(slow, 2),
+               wall_s=round(wall, 2), startup_s=round(max(start, default=0.0), 2),
+               first_batch_s=round(max(first, default=0.0), 2),
+               per_worker_scenes=[d for d, _, _ in done], per_worker_s=[t for _, _, t in done],
+               written_files=len([f for f in os.listdir(save) if f.endswith(".pth")]) if os.path.isdir(save) else 0)
+    if io:
+        out["loader_threads"], out["loader_processes"], out["file_io"] = int(io[0][0]), int(io[0][1]), io[0][2].strip()
+    if r.returncode not in (0, 3):
+        out["error"] = (r.stderr or txt)[-600:]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data_root", required=True)
+    ap.add_argument("--devices", default="0")
+    ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--raw_cache", action="store_true", help="a further pass over the raw scene cache (opt-in of gen_ps)")
+    ap.add_argument("--gen-ps-args", default="", help="extra arguments for gen_ps, space separated")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+    train = os.path.join(args.data_root, "train")
+    files = sorted(f for f in os.listdir(train) if f.endswith("_inst_nostuff.pth"))
+    sizes = [os.path.getsize(os.path.realpath(os.path.join(train, f))) for f in files]
+    distinct = len({os.path.realpath(os.path.join(train, f)) for f in files})
+    out_root = tempfile.mkdtemp(prefix="gapro_farm_")
+    extra = [a for a in args.gen_ps_args.split(" ") if a]
+    res = dict(workers=len(args.devices.split(",")), devices=args.devices, scene_files=len(files),
+               distinct_scene_files=distinct, scene_file_MB=dict(min=round(min(sizes) / 1e6, 1),
+                                                                 median=round(sorted(sizes)[len(sizes) // 2] / 1e6, 1),
+                                                                 max=round(max(sizes) / 1e6, 1),
+                                                                 total_GB=round(sum(sizes) / 1e9, 2)),
+               batch_scenes=args.batch, passes=[])
+    try:
+        cache = os.path.join(out_root, "rawcache")
+        for k in range(args.passes):
+            p = one_pass(args.data_root, os.path.join(out_root, "labels%d" % k), args.devices, args.batch,
+                         cache if (args.raw_cache and k == args.passes - 1) else None, extra)
+            p["source"] = ".pth files (pass %d%s)" % (k + 1, ": page cache as the dataset writer left it" if k == 0 else "")
+            res["passes"].append(p)
+            print("pass %d: %s" % (k + 1, json.dumps(p)), file=sys.stderr, flush=True)
+        if args.raw_cache:
+            p = one_pass(args.data_root, os.path.join(out_root, "labels_raw"), args.devices, args.batch, cache, extra)
+            p["source"] = "raw scene cache written by the previous pass (gen_ps --raw_cache)"
+            res["passes"].append(p)
+    finally:
+        if not args.keep:
+            shutil.rmtree(out_root, ignore_errors=True)
+    print("JSON " + json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
