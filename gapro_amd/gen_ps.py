@@ -216,13 +216,18 @@ def read_raw_cache(path, stamp):
         return None
 
 
+_BLAS_LIMIT = []
+
+
 def _loader_init():
-    """Loader process start-up: single-threaded BLAS / torch (the pool is the parallelism)."""
+    """Loader process / worker start-up: single-threaded BLAS / torch (the pool is the parallelism).  Not a nicety: the
+    axis alignment of read_scene is a [N, 4] x [4, 4] product, which an 8-thread OpenBLAS takes 66 ms for (fork-join
+    over a 1 ms job; worse with the 128+ threads of the GPU host) against 1.1 ms on one thread -- with the same bits."""
     torch.set_num_threads(1)
     try:
         from threadpoolctl import threadpool_limits
 
-        threadpool_limits(1)
+        _BLAS_LIMIT.append(threadpool_limits(1))  # kept alive: the limit is process-wide until this object is dropped
     except Exception:  # noqa: BLE001 - optional
         pass
 
@@ -362,6 +367,96 @@ def _save_arrays(save_path, arrays, spp_inv=None):
 _T_IMPORT = time.time()
 
 
+def _chunks(filenames, args, queue):
+    """Batches of scenes still to do (:39-41): from the shared queue, or this worker's static shard."""
+    if queue is not None:
+        while True:
+            got = queue.claim(args.batch_scenes)
+            if not got:
+                return
+            got = pending_scenes(got, args.save_folder)
+            if got:
+                yield got
+    else:
+        pending = pending_scenes(filenames, args.save_folder)
+        for i in range(0, len(pending), args.batch_scenes):
+            yield pending[i:i + args.batch_scenes]
+
+
+def run_worker_dry(filenames, args, rank):
+    """`--dry_run` (hidden; tools/host_ceiling.py, bench.py --dry-run, tests/test_dist_cpu.py): the HOST side of one
+    worker with no GPU in it -- the same scene list / claim queue / loader threads / native reader, the host
+    preprocessing of read_scene, one pass over the arrays in place of the copy into the pinned staging buffer, all-zero
+    stand-in outputs of the right shapes through the same writer, the same result file for the parent.  Measures what
+    the host of a W-GPU node can feed and drain, and lets the farm's control path run on a box without a GPU.  The
+    label files go to <save_folder>.DRY_RUN, never to --save_folder: nothing here is a pseudo-label."""
+    import concurrent.futures as cf
+
+    _loader_init()
+    out_folder = osp.normpath(args.save_folder) + ".DRY_RUN"
+    os.makedirs(out_folder, exist_ok=True)
+    print("[gen_ps] WARNING: --dry_run: NO pseudo-labels are generated; all-zero stand-in outputs go to %s"
+          % out_folder, file=sys.stderr)
+    n_workers = max(1, int(getattr(args, "n_workers", 1)))
+    phys = max(1, (os.cpu_count() or 2) // 2)
+    n_threads = int(getattr(args, "loader_threads", -1))
+    if n_threads <= 0:
+        n_threads = min(16, max(4, phys // (2 * n_workers)))
+    queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
+    pool = cf.ThreadPoolExecutor(max_workers=n_threads)
+    read_args = (args.data_root, args.use_deepfeat, args.deepfeat_folder)
+    t0 = time.time()
+    done, failed_names = 0, []
+
+    def one(fn):
+        sc = read_scene(fn, *read_args)
+        n = int(len(sc["spp"]))
+        for k in _DEVICE_DTYPES:  # the upload's pass over the arrays (host -> pinned staging buffer)
+            np.array(sc[k])
+        s = max(1, n // 50)
+        arrays = (np.zeros(n, np.int32), np.zeros(n, np.int32), np.ones(n, np.float32),
+                  np.full(s, -100.0, np.float32), np.full(s, -100.0, np.float32))
+        _save_arrays(osp.join(out_folder, sc["scan_name"] + ".pth"), arrays, None)
+        return sc["scan_name"]
+
+    ahead = []
+    chunks = _chunks(filenames, args, queue)
+    for _ in range(2):
+        c = next(chunks, None)
+        if c:
+            ahead.append([(fn, pool.submit(one, fn)) for fn in c])
+    while ahead:
+        futs = ahead.pop(0)
+        c = next(chunks, None)
+        if c:
+            ahead.append([(fn, pool.submit(one, fn)) for fn in c])
+        for fn, f in futs:
+            try:
+                f.result()
+                done += 1
+            except Exception as e:  # noqa: BLE001
+                print("[gen_ps] %s: failed: %r" % (fn, e), file=sys.stderr)
+                failed_names.append(fn.split("/")[-1][:12])
+    pool.shutdown()
+    dt = time.time() - t0
+    print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.2f s (%.2f scenes/s)"
+          % (rank, done, len(failed_names), dt, done / dt if dt > 0 else 0.0))
+    print("[gen_ps] device %d: start-up %.1f s (process start -> generator ready), first batch out after %.1f s more, "
+          "%d loader threads, %d loader processes, %s file I/O, dry run (no GPU)"
+          % (rank, t0 - _T_IMPORT, 0.0, n_threads, 0,
+             "native (gapro_pth_*)" if pth_io.native_enabled() else "torch.load / torch.save"))
+    result = dict(done=done, failed=sorted(failed_names), miou={}, seconds=dt, startup_seconds=t0 - _T_IMPORT,
+                  first_batch_seconds=0.0, timeout_retries=0, dry_run=True)
+    if getattr(args, "job_dir", None):
+        import json
+
+        tmp = osp.join(args.job_dir, "result.%d.json.tmp" % device_index_rank(args))
+        with open(tmp, "w") as fh:
+            json.dump(result, fh)
+        os.replace(tmp, tmp[:-4])
+    return result
+
+
 def run_worker(filenames, args, device_index):
     """One GPU: scenes are read from disk by a pool of loader threads or processes (two batches ahead), go
     through the software-pipelined generator batch by batch (Pipeline.run_stream), and are written by the
@@ -371,6 +466,7 @@ def run_worker(filenames, args, device_index):
 
     n_procs = int(getattr(args, "loader_procs", 0))
     n_workers = max(1, int(getattr(args, "n_workers", 1)))  # GPU workers sharing this host (--devices)
+    _loader_init()  # the loader threads of this process call BLAS concurrently: one thread each
     native = pth_io.native_enabled()
     phys = max(1, (os.cpu_count() or 2) // 2)
     n_threads = int(getattr(args, "loader_threads", -1))
@@ -400,19 +496,8 @@ def run_worker(filenames, args, device_index):
     queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
 
     def chunk_iter():
-        """Batches of scenes still to do (:39-41): from the shared queue, or this worker's static shard."""
-        if queue is not None:
-            while True:
-                got = queue.claim(args.batch_scenes)
-                if not got:
-                    return
-                got = pending_scenes(got, args.save_folder)
-                if got:
-                    yield got
-        else:
-            pending = pending_scenes(filenames, args.save_folder)
-            for i in range(0, len(pending), args.batch_scenes):
-                yield pending[i:i + args.batch_scenes]
+        return _chunks(filenames, args, queue)
+
     pool = cf.ThreadPoolExecutor(max_workers=max(1, n_threads))
     meta = []  # per yielded batch: (scenes, jobs)
     read_args = (args.data_root, args.use_deepfeat, args.deepfeat_folder)
@@ -628,7 +713,7 @@ def run_worker(filenames, args, device_index):
             procs.close()
             procs.join()
     dt = time.time() - t0
-    print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.1f s (%.2f scenes/s)%s"
+    print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.2f s (%.2f scenes/s)%s"
           % (device_index, done, failed, dt, done / dt if dt > 0 else 0.0,
              ", %d from the raw cache" % cache_hits[0] if raw_cache else ""))
     # start-up is reported apart from the rate: at ~300 scenes/s a 1201-scene split is a few seconds of work, and the
@@ -711,6 +796,7 @@ def main(argv=None):
     parser.add_argument("--worker_rank", type=int, default=-1, help=argparse.SUPPRESS)
     parser.add_argument("--claim_dir", type=str, default=None, help=argparse.SUPPRESS)
     parser.add_argument("--job_dir", type=str, default=None, help=argparse.SUPPRESS)
+    parser.add_argument("--dry_run", action="store_true", help=argparse.SUPPRESS)
     args = parser.parse_args(argv)
 
     os.makedirs(args.save_folder, exist_ok=True)
@@ -733,7 +819,7 @@ def main(argv=None):
             mine = shard_scenes(filenames, r, len(devices))
         else:  # "lpt", or "queue" without a claim directory (a worker started by hand)
             mine = shard_scenes_lpt(filenames, r, len(devices))
-        result = run_worker(mine, args, devices[r])
+        result = run_worker_dry(mine, args, r) if args.dry_run else run_worker(mine, args, devices[r])
         if args.worker_rank >= 0 and args.job_dir:  # a child of the farm: the parent prints the summary
             return 3 if result["failed"] else 0
         return finish_run(args, [result])

@@ -86,6 +86,16 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["steps"] == 3 and rec["value"] is None
     assert rec["ms_per_step"] >= 4.0  # rank 1 sleeps 4 ms per step, rank 0 only 2: the MAX must win
+    # with --gpus N the line carries `gen_ps_farm` -- N workers through `gen_ps --devices` over
+    # scene FILES (here: --dry_run workers, the host side only; on the GPU box the real ones), two passes, start-up apart
+    farm = rec["gen_ps_farm"]
+    assert farm["workers"] == 2 and farm["devices"] == "0,1" and farm["dry_run"] is True and farm["scene_files"] == 6
+    assert len(farm["passes"]) == 2
+    for p in farm["passes"]:
+        assert p["exit_status"] == 0 and p["scenes"] == 6 and p["written_files"] == 6 and p["failed"] == 0
+        assert len(p["per_worker_scenes"]) == 2 and sum(p["per_worker_scenes"]) == 6
+        assert p["file_io"].startswith("native") and p["loader_processes"] == 0
+        assert "startup_s" in p and "wall_s" in p and p["scenes_per_s"] > 0
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():

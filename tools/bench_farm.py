@@ -47,7 +47,8 @@ def one_pass(data_root, save, devices, batch, raw_cache, extra):
                wall_s=round(wall, 2), startup_s=round(max(start, default=0.0), 2),
                first_batch_s=round(max(first, default=0.0), 2),
                per_worker_scenes=[d for d, _, _ in done], per_worker_s=[t for _, _, t in done],
-               written_files=len([f for f in os.listdir(save) if f.endswith(".pth")]) if os.path.isdir(save) else 0)
+               written_files=sum(len([f for f in os.listdir(d) if f.endswith(".pth")])
+                                 for d in (save, save + ".DRY_RUN") if os.path.isdir(d)))
     if io:
         out["loader_threads"], out["loader_processes"], out["file_io"] = int(io[0][0]), int(io[0][1]), io[0][2].strip()
     if r.returncode not in (0, 3):
