@@ -136,6 +136,11 @@ SIGNATURES = {
     "gapro_pth_close": (None, [_P]),
     "gapro_pth_write": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(PthArray), C.POINTER(_P), C.c_int32]),
     "gapro_pth_last_error": (C.c_char_p, []),
+}
+
+# libgapro_hip_debug.so (include/gapro_hip_debug.h): measurement / self-test entry points, loaded on request only
+DEBUG_LIB_PATH = os.path.join(_HERE, "libgapro_hip_debug.so")
+DEBUG_SIGNATURES = {
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "gapro_debug_stream": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
     "gapro_debug_mfma_peak": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
@@ -147,6 +152,23 @@ SIGNATURES = {
 }
 
 _lib: Optional[C.CDLL] = None
+_dbg: Optional[C.CDLL] = None
+
+
+def load_debug() -> C.CDLL:
+    """Load libgapro_hip_debug.so (tools, bench.py's peak_measured, the MFMA lane-map test); the product never does."""
+    global _dbg
+    if _dbg is not None:
+        return _dbg
+    if not os.path.exists(DEBUG_LIB_PATH):
+        raise ImportError("libgapro_hip_debug.so not built: run gapro_amd/csrc/build.sh; expected at " + DEBUG_LIB_PATH)
+    lib = C.CDLL(DEBUG_LIB_PATH)
+    for name, (res, args) in DEBUG_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _dbg = lib
+    return lib
 
 
 def load() -> C.CDLL:
@@ -179,6 +201,11 @@ class Context:
             raise GaproError(rc, "gapro_ctx_create(device=%d): no usable HIP device" % device)
         self.handle = h
         self.device = int(device)
+
+    @property
+    def dbg(self) -> C.CDLL:
+        """The debug library's entry points (they take this context's handle)."""
+        return load_debug()
 
     @classmethod
     def get(cls, device: int = 0) -> "Context":

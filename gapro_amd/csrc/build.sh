@@ -5,12 +5,20 @@
 # stamps (libgapro_hip_prof.so: never used by the product or the tests).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-srcs=(ctx.hip partition.hip svgp_fit.hip svgp_fit_small.hip svgp_fit_large.hip svgp_fit_cluster.hip labels.hip consumer.hip debug_peak.hip schedule.cpp pth_io.cc)
+srcs=(ctx.hip partition.hip svgp_fit.hip svgp_fit_small.hip svgp_fit_large.hip svgp_fit_cluster.hip labels.hip consumer.hip schedule.cpp pth_io.cc)
+# libgapro_hip_debug.so: measurement / self-test entry points (include/gapro_hip_debug.h), never loaded by the product
+debug_srcs=(svgp_fit_debug.hip debug_peak.hip)
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed)
 
 build_lib() {  # $1 = object directory, $2 = output library, rest = extra flags
   local odir="$1" out="$2"; shift 2
   mkdir -p "${odir}"
+  # the -D flags are part of the build's identity: a variant rebuilt with other flags must not reuse objects
+  local flagstr="$*"
+  if [[ ! -f "${odir}/.flags" ]] || [[ "$(cat "${odir}/.flags")" != "${flagstr}" ]]; then
+    rm -f "${odir}"/*.o
+    printf '%s' "${flagstr}" > "${odir}/.flags"
+  fi
   local newest_hdr=0 h t
   for h in "${here}"/*.h "${here}/../../include"/*.h "${here}/build.sh"; do
     t=$(stat -c %Y "$h"); (( t > newest_hdr )) && newest_hdr=$t
@@ -19,8 +27,8 @@ build_lib() {  # $1 = object directory, $2 = output library, rest = extra flags
   for s in "${srcs[@]}"; do
     o="${odir}/${s%.*}.o"; objs+=("$o")
     so=$(stat -c %Y "${here}/${s}")
-    # svgp_fit_small.hip is svgp_fit.hip built a second time
-    [[ "$s" == "svgp_fit_small.hip" ]] && { t=$(stat -c %Y "${here}/svgp_fit.hip"); (( t > so )) && so=$t; }
+    # svgp_fit_small.hip / svgp_fit_debug.hip are svgp_fit.hip built again
+    [[ "$s" == "svgp_fit_small.hip" || "$s" == "svgp_fit_debug.hip" ]] && { t=$(stat -c %Y "${here}/svgp_fit.hip"); (( t > so )) && so=$t; }
     if [[ ! -f "$o" ]] || (( $(stat -c %Y "$o") < so )) || (( $(stat -c %Y "$o") < newest_hdr )); then
       if [[ "$s" == *.cc ]]; then  # host-only C++ (no HIP headers): the system compiler, no device pass
         g++ -O3 -std=c++17 -fPIC -Wall -c -o "$o" "${here}/${s}" &
@@ -38,6 +46,10 @@ build_lib() {  # $1 = object directory, $2 = output library, rest = extra flags
 }
 
 build_lib "${here}/build/rel" "${here}/../libgapro_hip.so"
+product_srcs=("${srcs[@]}")
+srcs=("${debug_srcs[@]}")
+build_lib "${here}/build/debug" "${here}/../libgapro_hip_debug.so"
+srcs=("${product_srcs[@]}")
 # experiments: GAPRO_VARIANT=name GAPRO_VARIANT_FLAGS="-DX ..." builds libgapro_hip_name.so (tools/bench_fit.py --lib)
 if [[ -n "${GAPRO_VARIANT:-}" ]]; then
   # shellcheck disable=SC2086

@@ -10,6 +10,10 @@
 
 constexpr unsigned kTaskRing = 1024;
 
+namespace gapro_mfma {
+typedef double d4 __attribute__((ext_vector_type(4)));  // one 16 x 16 MFMA accumulator block (C layout), per lane
+}
+
 struct gapro_ctx {
   int device = 0;
   int n_cu = 0;

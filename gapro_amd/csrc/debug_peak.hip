@@ -5,6 +5,7 @@
 // runs `waves_per_simd` waves per SIMD, each wave a loop of dependent-free v_mfma chains (8 independent
 // accumulators, no memory traffic inside the loop), timed with HIP events on the stream they run on.
 #include "common.h"
+#include "../../include/gapro_hip_debug.h"
 #include "mfma64.h"
 
 namespace {

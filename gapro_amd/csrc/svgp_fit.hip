@@ -1,33 +1,41 @@
-// Batched whitened-SVGP classifier fit for gfx950 (MI355X): one workgroup = one GP fit, the whole
-// Adam loop inside one launch.  LDS-staged kernel (M_p <= 512); svgp_fit_large.hip is the generic
-// fallback with the same arithmetic.
+// Batched whitened-SVGP classifier fit for gfx950 (MI355X): one workgroup = one GP fit, the whole Adam loop inside
+// one launch.  This file holds the single-workgroup MFMA kernels -- k_svgp_fit<WPS, KMIN> (LDS-staged, 128 < M_p <= 512),
+// k_svgp_fit_strip<D> (strip-streaming, M_p <= 128; built a second time with 256 threads per fit as svgp_fit_small.hip
+// for M_p <= 64) -- and the host entry gapro_svgp_fit_batch that routes every fit of a launch (strip / staged / cluster
+// / generic kernel).  svgp_fit_cluster.hip spreads one large fit over several workgroups; svgp_fit_large.hip is the
+// generic fallback (D > 32) with the same arithmetic.
 //
-// Replaces reference gapro/gaussian_process_utils.py:382-445 (fit_gp_spp) and the gpytorch objects
-// it builds (:11-25): CholeskyVariationalDistribution + whitened VariationalStrategy with learned
-// inducing locations, ConstantMean, ScaleKernel(RBFKernel), BernoulliLikelihood (20-point
-// Gauss-Hermite), VariationalELBO, Adam(lr=0.1) x training_iter, then prediction.  There is no
-// autograd on the device: the backward pass is the hand-derived one of SURVEY.md Appendix B.5,
-// restated and checked against torch autograd in oracle/svgp_oracle.py.
+// Replaces reference gapro/gaussian_process_utils.py:382-445 (fit_gp_spp) and the gpytorch objects it builds
+// (:11-25): CholeskyVariationalDistribution + whitened VariationalStrategy with learned inducing locations,
+// ConstantMean, ScaleKernel(RBFKernel), BernoulliLikelihood (20-point Gauss-Hermite), VariationalELBO,
+// Adam(lr=0.1) x training_iter (:416-423), then prediction (:426-438).  There is no autograd on the device: the
+// backward pass is the hand-derived one of SURVEY.md Appendix B.5, restated and checked against torch autograd in
+// oracle/svgp_oracle.py.
 //
-// Arithmetic: float64 throughout (DESIGN.md "Precision").  Every M x M x M contraction is a TN-form
-// MFMA product (v_mfma_f64_16x16x4_f64):  C[i][j] = sum_k P[k][i] * Q[k][j], both operands row-major
-// in k so that fragment loads are 128-byte row segments; a matrix needed in both orientations is
-// written in both by the producing epilogue (transposed copies go through an LDS tile so that the
-// global stores stay row-contiguous).
+// Arithmetic: float64 throughout (DESIGN.md "Precision").  Every M x M x M contraction is an MFMA product on
+// v_mfma_f64_16x16x4_f64.  The default form is TN, C[i][j] = sum_k P[k][i] Q[k][j], both operands row-major in k so
+// that fragment loads are 128-byte row segments; up to M_p = 256 (KMIN) the products that contract over the COLUMNS of
+// A, B, G_A, Pm read those matrices as they are (two consecutive k per 16-byte load), so that no transposed copy is
+// ever written.
 //
-// Per Adam step:
-//   forward : Kzz tiles are evaluated on the fly inside the blocked left-looking Cholesky (16-wide
-//             panels, MFMA updates, panel held in LDS, diagonal block factored in registers by one
-//             wave) -> L, L^T;  LI = L^-1 (one 16-wide block column per wave, blocks kept in registers)
-//             KX = k(Z, X);  A = LI KX;  B = LS^T A;  mu = A^T m + c;  var = s + eps + |B|^2 - |A|^2
+// Per Adam step (round 3's step: 7.67 M^3 executed; G_L is never formed):
+//   forward : K_ZZ tiles are evaluated on the fly inside the blocked left-looking Cholesky (16-wide block columns,
+//             MFMA updates reading L^T, block column in LDS, 16 x 16 diagonal block factored AND inverted in registers by
+//             one wave) -> L^T (the row-major factor L is not written: nothing reads it);  LI = L^-1 (one 16-wide block
+//             column per wave, blocks kept in registers) -> LI, LI^T;  KX = k(Z, X);  A = LI KX;  B = LS^T A;
+//             mu = A^T m + c;  var = s + eps + colsum(B^2) - colsum(A^2)  (column sums fused into the product epilogues)
 //             g_mu, g_v from the 20-point Gauss-Hermite rule of log Phi(y f)
-//   backward: G_m, G_c;  G_A = m g_mu^T + LS G_B - 2 A diag(g_v);  G_LS = tril(A G_B^T) + KL' with the
-//             Adam update of LS fused into the epilogue;  G_KX = LI^T G_A;  G_L = -tril(G_KX A^T);
-//             G_Kzz = LI^T Phi(L^T G_L) LI;  one fused pass turns G_Kzz, G_KX into G_s, G_l, G_Z
-//             (kernel values recomputed from the LDS copies of Z and X) and applies Adam to Z
-//   Adam    : torch.optim.Adam defaults (beta 0.9/0.999, eps 1e-8), lr 0.1
-// Inducing points Z and training points X live transposed in LDS ([d][i]) so that a thread that owns
-// column j reads its own point conflict-free and the row point as an LDS broadcast.
+//   backward: G_m, G_c;  G_A = m g_mu^T + LS (2 B g_v) - 2 A diag(g_v);  G_LS = tril(A (2 B g_v)^T) + KL' with the Adam
+//             update of LS fused into the epilogue;  G_KX^T = G_A^T LI (only the transposed G_KX is ever read);
+//             Pm = Phi(L^T G_L) = Phi(-G_A A^T)   (tril(L^T tril(X)) = tril(L^T X) and L^T LI^T = I);
+//             G_Kzz = LI^T (Pm LI): W = Pm LI is lower (M^3 / 3), S = LI^T W (2 M^3 / 3);  one fused pass turns G_Kzz and
+//             G_KX into G_s, G_l, G_Z (kernel values recomputed from the LDS copies of Z and X) and applies Adam to Z
+//   Adam    : torch.optim.Adam defaults (beta 0.9 / 0.999, eps 1e-8), lr 0.1 on {Z, m, tril(LS), c, rho_s, rho_l}
+// Inducing points Z and training points X live transposed in LDS ([d][i]) so that a thread that owns column j reads
+// its own point conflict-free and the row point as an LDS broadcast.
+//
+// Built a third time with GAPRO_DEBUG_TU (svgp_fit_debug.hip -> libgapro_hip_debug.so): only the debug entry points
+// of include/gapro_hip_debug.h (product-engine bench, MFMA lane-map self test, counter-calibration streams).
 #include <math.h>
 
 #include <algorithm>
@@ -36,7 +44,10 @@
 
 #include "common.h"
 #include "fit_layout.h"
+#ifdef GAPRO_DEBUG_TU
+#include "../../include/gapro_hip_debug.h"
 #include "mfma64.h"
+#endif
 
 void gapro_launch_fit_large(hipStream_t stream, int n_fits, int feat_dim, const float* d_feats_spp, const int* d_idx,
                             const gapro_fit_desc* d_descs, const double* d_init_mean, const gapro_fit_options& opt,
@@ -456,9 +467,9 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
 // with triangular operands every SIMD gets a long and a short contraction range.  A piece skips the chunks outside the
 // hull of its blocks' ranges (the extra rows inside the hull multiply structural zeros of a triangular operand: x + 0 y
 // = x, the bits stay).
-// LDS image of a chunk: row k at k * 128 doubles, and inside a row the element i at i ^ (16 (k & 1)): the two k rows
-// a 32-lane group of a fragment read touches land in different halves of the 256-byte bank row (conflict-free
-// ds_read_b64) without padding.
+// LDS image of a chunk: row k at k * kWgRow doubles with kWgRow = 128 + 16 (padded rows, no swizzle): the two k rows a
+// 32-lane group of a fragment read touches start 128 bytes apart modulo the 256-byte bank row, i.e. they land in
+// different halves of it (conflict-free ds_read_b64).
 template <bool SCALE, bool TRIM, int PF, typename KRange, typename Epi>
 __device__ __noinline__ void gemm_wg(int rows16, int cols16, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
@@ -2880,6 +2891,7 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, con
   fit_epilogue(desc, opt, o_status, o_loss);
 }
 
+#ifdef GAPRO_DEBUG_TU
 // ---- product engines side by side (debug entry, tools/product_bench.py) --------------------------------
 // Every workgroup owns three M_p x M_p matrices (P, Q, C) of a slab and computes C = P^T Q `reps` times with one of the
 // staged kernel's product engines, plain-store epilogue: engine 0 = gemm_tn with 32 x 32 wave tiles, 1 = 64 x 64 wave
@@ -2928,13 +2940,15 @@ __global__ void k_mfma_selftest(const double* __restrict__ P, const double* __re
   for (int k = 0; k < K; k += 4)
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(k + lq) * 16 + lr], Q[(k + lq) * 16 + lr], acc, 0, 0, 0);
   for (int r = 0; r < 4; ++r) C[(lq + 4 * r) * 16 + lr] = acc[r];
-  if (K < 0) {  // never taken: keeps the four-block form of mfma64.h (an experiment of round 3) compiling
+  if (K < 0) {  // never taken: keeps the four-block form of mfma64.h (an experiment of round 3) compiling (debug TU)
     d4 t = (d4){0.0, 0.0, 0.0, 0.0};
     gapro_mfma::mma16(P[lr], Q[lr], t);
     t = gapro_mfma::unrotate(t);
     C[lane] = t[0];
   }
 }
+
+#endif  // GAPRO_DEBUG_TU
 
 }  // namespace
 
@@ -2960,15 +2974,8 @@ extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_d
 }
 // LDS bytes of a small fit in THIS translation unit's layout (NT-dependent reduction scratch)
 extern "C" long long gapro_fit_strip_small_lds_bytes(int m, int feat_dim) { return strip_lds_bytes(m, feat_dim); }
-#else
-extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_dim, size_t lds_bytes,
-                                            const float* d_feats_spp, const int32_t* d_idx,
-                                            const gapro_fit_desc* d_descs, const double* d_init_mean,
-                                            const gapro_fit_options* opt, double* d_workspace, float* d_probs,
-                                            float* d_probs_new, uint8_t* d_labels, float* d_mu, float* d_var,
-                                            int32_t* d_fit_status, double* d_fit_loss);
-extern "C" long long gapro_fit_strip_small_lds_bytes(int m, int feat_dim);
-
+#elif defined(GAPRO_DEBUG_TU)
+// ---- debug translation unit (svgp_fit_debug.hip -> libgapro_hip_debug.so; include/gapro_hip_debug.h) ------------
 __global__ void k_stream_calib(long long n, const double* __restrict__ src, double* __restrict__ dst, int mode) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   double acc = 0.0;
@@ -2982,6 +2989,74 @@ __global__ void k_stream_calib(long long n, const double* __restrict__ src, doub
     if ((threadIdx.x & 63) == 0) atomicAdd(&dst[blockIdx.x], acc);
   }
 }
+
+extern "C" {
+
+// Debug: the staged kernel's product engines side by side (k_product_bench); d_slab: n_wg * 3 * mp * mp doubles,
+// filled by the caller.  Returns the launch's milliseconds (HIP events on `stream`, blocking) in *out_ms.
+int gapro_debug_product_bench(gapro_ctx* ctx, void* stream_, int32_t engine, int32_t shape, int32_t mp, int32_t reps,
+                              int32_t n_wg, double* d_slab, float* out_ms) {
+  if (!ctx || !d_slab || !out_ms || engine < 0 || engine > 2 || shape < 0 || shape > 5 || mp < 128 || mp % 32 ||
+      reps <= 0 || n_wg <= 0)
+    return GAPRO_ERR_BAD_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int lds = 8 * kWgRingDoubles + 1024;
+  hipEvent_t e0, e1;
+  GAPRO_HIP_CHECK(ctx, hipEventCreate(&e0));
+  GAPRO_HIP_CHECK(ctx, hipEventCreate(&e1));
+  auto launch = [&](int n) -> int {
+#define GAPRO_PB(E)                                                                                              \
+  do {                                                                                                           \
+    GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_product_bench<E>,                                    \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));                 \
+    hipLaunchKernelGGL(k_product_bench<E>, dim3(n_wg), dim3(NT), (size_t)lds, stream, (int)mp, n, (int)shape, d_slab); \
+  } while (0)
+    if (engine == 0) GAPRO_PB(0);
+    else if (engine == 1) GAPRO_PB(1);
+    else GAPRO_PB(2);
+#undef GAPRO_PB
+    return GAPRO_OK;
+  };
+  if (launch(1) != GAPRO_OK) return GAPRO_ERR_HIP;
+  GAPRO_HIP_CHECK(ctx, hipEventRecord(e0, stream));
+  if (launch(reps) != GAPRO_OK) return GAPRO_ERR_HIP;
+  GAPRO_HIP_CHECK(ctx, hipEventRecord(e1, stream));
+  GAPRO_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(out_ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+// Debug: C = P^T Q for 16-column operands with K rows (K % 4 == 0); checks the MFMA lane maps.
+int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream_, const double* d_P, const double* d_Q, double* d_C, int32_t K) {
+  if (!ctx || !d_P || !d_Q || !d_C || K <= 0 || (K & 3)) return GAPRO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream_, d_P, d_Q, d_C, (int)K);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+// Debug: streaming kernels with a known byte count in this library's own access pattern (one double per
+// lane, grid-stride), used to calibrate the FETCH_SIZE / WRITE_SIZE counters.  mode 0: read n doubles and
+// write one partial sum per workgroup; mode 1: copy n doubles.
+int gapro_debug_stream(gapro_ctx* ctx, void* stream_, int64_t n, const double* d_src, double* d_dst, int32_t mode) {
+  if (!ctx || !d_src || !d_dst || n <= 0 || mode < 0 || mode > 1) return GAPRO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_stream_calib, dim3(4096), dim3(256), 0, (hipStream_t)stream_, (long long)n, d_src, d_dst,
+                     (int)mode);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
+}  // extern "C"
+#else
+extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_dim, size_t lds_bytes,
+                                            const float* d_feats_spp, const int32_t* d_idx,
+                                            const gapro_fit_desc* d_descs, const double* d_init_mean,
+                                            const gapro_fit_options* opt, double* d_workspace, float* d_probs,
+                                            float* d_probs_new, uint8_t* d_labels, float* d_mu, float* d_var,
+                                            int32_t* d_fit_status, double* d_fit_loss);
+extern "C" long long gapro_fit_strip_small_lds_bytes(int m, int feat_dim);
 
 // 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel, 3 = strip-streaming kernel of the small-fit
 // translation unit (M_p <= 64: 256 threads per fit, two fits per CU), 4 = cluster kernel (one fit over several
@@ -3070,6 +3145,17 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       clus.push_back(d);
     } else {
       large.push_back(d);
+      // beyond the cluster kernel's cap (kClusterMaxMp: its merge inverse keeps one LDS record per pair of panels) a
+      // fit runs on ONE workgroup of the generic kernel: correct, but minutes per fit -- never silently
+      if (feat_dim <= 32 && gapro_pad_m(m, feat_dim) > gapro_fit::kClusterMaxMp) {
+        static bool warned = false;
+        if (!warned) {
+          warned = true;
+          fprintf(stderr, "libgapro_hip: a GP fit with M = %d inducing points exceeds the multi-workgroup kernel's cap "
+                          "(M_p <= %d): it runs on one workgroup of the generic kernel (minutes per fit)\n", m,
+                  gapro_fit::kClusterMaxMp);
+        }
+      }
     }
   }
   if ((size_t)need > workspace_bytes)
@@ -3351,62 +3437,6 @@ int gapro_fit_timing_offsets(gapro_ctx* ctx, gapro_fit_timing* ref, gapro_fit_ti
   }
   out_ms2[0] = lo;
   out_ms2[1] = hi;
-  return GAPRO_OK;
-}
-
-// Debug: the staged kernel's product engines side by side (k_product_bench); d_slab: n_wg * 3 * mp * mp doubles,
-// filled by the caller.  Returns the launch's milliseconds (HIP events on `stream`, blocking) in *out_ms.
-int gapro_debug_product_bench(gapro_ctx* ctx, void* stream_, int32_t engine, int32_t shape, int32_t mp, int32_t reps,
-                              int32_t n_wg, double* d_slab, float* out_ms) {
-  if (!ctx || !d_slab || !out_ms || engine < 0 || engine > 2 || shape < 0 || shape > 5 || mp < 128 || mp % 32 ||
-      reps <= 0 || n_wg <= 0)
-    return GAPRO_ERR_BAD_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  const int lds = 8 * kWgRingDoubles + 1024;
-  hipEvent_t e0, e1;
-  GAPRO_HIP_CHECK(ctx, hipEventCreate(&e0));
-  GAPRO_HIP_CHECK(ctx, hipEventCreate(&e1));
-  auto launch = [&](int n) -> int {
-#define GAPRO_PB(E)                                                                                              \
-  do {                                                                                                           \
-    GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_product_bench<E>,                                    \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds));                 \
-    hipLaunchKernelGGL(k_product_bench<E>, dim3(n_wg), dim3(NT), (size_t)lds, stream, (int)mp, n, (int)shape, d_slab); \
-  } while (0)
-    if (engine == 0) GAPRO_PB(0);
-    else if (engine == 1) GAPRO_PB(1);
-    else GAPRO_PB(2);
-#undef GAPRO_PB
-    return GAPRO_OK;
-  };
-  if (launch(1) != GAPRO_OK) return GAPRO_ERR_HIP;
-  GAPRO_HIP_CHECK(ctx, hipEventRecord(e0, stream));
-  if (launch(reps) != GAPRO_OK) return GAPRO_ERR_HIP;
-  GAPRO_HIP_CHECK(ctx, hipEventRecord(e1, stream));
-  GAPRO_HIP_CHECK(ctx, hipEventSynchronize(e1));
-  GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(out_ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  GAPRO_LAUNCH_CHECK(ctx);
-  return GAPRO_OK;
-}
-
-// Debug: C = P^T Q for 16-column operands with K rows (K % 4 == 0); checks the MFMA lane maps.
-int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream_, const double* d_P, const double* d_Q, double* d_C, int32_t K) {
-  if (!ctx || !d_P || !d_Q || !d_C || K <= 0 || (K & 3)) return GAPRO_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_mfma_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream_, d_P, d_Q, d_C, (int)K);
-  GAPRO_LAUNCH_CHECK(ctx);
-  return GAPRO_OK;
-}
-
-// Debug: streaming kernels with a known byte count in this library's own access pattern (one double per
-// lane, grid-stride), used to calibrate the FETCH_SIZE / WRITE_SIZE counters.  mode 0: read n doubles and
-// write one partial sum per workgroup; mode 1: copy n doubles.
-int gapro_debug_stream(gapro_ctx* ctx, void* stream_, int64_t n, const double* d_src, double* d_dst, int32_t mode) {
-  if (!ctx || !d_src || !d_dst || n <= 0 || mode < 0 || mode > 1) return GAPRO_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_stream_calib, dim3(4096), dim3(256), 0, (hipStream_t)stream_, (long long)n, d_src, d_dst,
-                     (int)mode);
-  GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
 }
 

@@ -8,8 +8,8 @@ from gapro_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "gapro_hip.h")).read()
+def _declared_symbols(header="gapro_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gapro_[a-z0-9_]+)\s*\(", text)))
 
@@ -22,6 +22,19 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), "missing export " + n
         assert n in _lib.SIGNATURES, "binding lacks " + n
     assert lib.gapro_version() == 200
+
+
+def test_debug_entry_points_live_in_their_own_library_and_header():
+    """VERDICT r03 (housekeeping): the measurement / self-test entry points are not part of the product library nor of
+    its public header; libgapro_hip_debug.so exports exactly what include/gapro_hip_debug.h declares."""
+    assert not [n for n in _declared_symbols() if n.startswith("gapro_debug_")]
+    lib = _lib.load()
+    names = _declared_symbols("gapro_hip_debug.h")
+    assert len(names) == 6 and all(n.startswith("gapro_debug_") for n in names), names
+    dbg = _lib.load_debug()
+    for n in names:
+        assert hasattr(dbg, n) and n in _lib.DEBUG_SIGNATURES and not hasattr(lib, n), n
+    assert not [n for n in _lib.SIGNATURES if n.startswith("gapro_debug_")]
 
 
 def test_struct_layouts_match_the_header():

@@ -22,7 +22,7 @@ def test_mfma_f64_lane_maps():
     Q = rng.integers(-4, 5, size=(K, 16)).astype(np.float64)  # asymmetric: catches a transposed C map
     dP, dQ = torch.from_numpy(P).cuda(), torch.from_numpy(Q).cuda()
     dC = torch.zeros((16, 16), dtype=torch.float64, device="cuda")
-    ctx.check(ctx.lib.gapro_debug_mfma_tn(ctx.handle, None, C.c_void_p(dP.data_ptr()), C.c_void_p(dQ.data_ptr()),
+    ctx.check(ctx.dbg.gapro_debug_mfma_tn(ctx.handle, None, C.c_void_p(dP.data_ptr()), C.c_void_p(dQ.data_ptr()),
                                            C.c_void_p(dC.data_ptr()), K))
     torch.cuda.synchronize()
     np.testing.assert_array_equal(dC.cpu().numpy(), P.T @ Q)

@@ -24,7 +24,7 @@ def measure(device=0, iters=20000):
         best = 0.0
         for wps in (1, 2, 4):
             tf = C.c_double()
-            ctx.check(ctx.lib.gapro_debug_mfma_peak(ctx.handle, None, kind, iters, wps, C.c_void_p(sink.data_ptr()),
+            ctx.check(ctx.dbg.gapro_debug_mfma_peak(ctx.handle, None, kind, iters, wps, C.c_void_p(sink.data_ptr()),
                                                     C.byref(tf)))
             out["%s_wps%d" % (name, wps)] = tf.value
             best = max(best, tf.value)
@@ -39,7 +39,7 @@ def measure(device=0, iters=20000):
                               ("f64_16x16x4_wg_tiled_loop", 16 | 7, 2), ("f64_4x4x4_4b_lds_loop", 0, 2)):
         tf = C.c_double()
         try:
-            ctx.check(ctx.lib.gapro_debug_wgloop(ctx.handle, None, 4000, mode, per_cu * n_cu, C.c_void_p(src.data_ptr()),
+            ctx.check(ctx.dbg.gapro_debug_wgloop(ctx.handle, None, 4000, mode, per_cu * n_cu, C.c_void_p(src.data_ptr()),
                                                  C.c_void_p(sink.data_ptr()), C.byref(tf)))
             out[key] = tf.value
         except Exception as e:  # noqa: BLE001 - diagnostic
@@ -61,7 +61,7 @@ def clocks(device=0, iters=20000):
     out = {}
     for frac in (8, 4, 2, 1):
         tf, mhz = C.c_double(), C.c_double()
-        ctx.check(ctx.lib.gapro_debug_mfma_clock(ctx.handle, None, iters, 4, 4 * n_cu // frac,
+        ctx.check(ctx.dbg.gapro_debug_mfma_clock(ctx.handle, None, iters, 4, 4 * n_cu // frac,
                                                  C.c_void_p(sink.data_ptr()), C.byref(tf), C.byref(mhz)))
         out["workgroups_%d" % (4 * n_cu // frac)] = {"tflops": round(tf.value, 2), "s_memtime_mhz": round(mhz.value, 1)}
     return out

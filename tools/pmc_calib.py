@@ -18,7 +18,7 @@ ctx = Context(0)
 src = torch.ones(n, dtype=torch.float64, device="cuda")
 dst = torch.zeros(n, dtype=torch.float64, device="cuda")
 for mode in (0, 1, 0, 1):
-    ctx.check(ctx.lib.gapro_debug_stream(ctx.handle, None, n, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+    ctx.check(ctx.dbg.gapro_debug_stream(ctx.handle, None, n, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
                                          mode))
 torch.cuda.synchronize()
 print("bytes_read_per_launch", 8 * n, "bytes_written_per_launch(mode1)", 8 * n)

@@ -9,5 +9,5 @@ sink = torch.zeros(8, dtype=torch.float64, device="cuda")
 for iters in (20000, 200000, 1000000, 3000000):
     for mode, nm in ((16 | 128, "sp lds+mfma random"), (16 | 7 | 128, "sp all random")):
         tf = C.c_double()
-        ctx.check(lib.gapro_debug_wgloop(ctx.handle, None, iters, mode, n_cu, C.c_void_p(src.data_ptr()), C.c_void_p(sink.data_ptr()), C.byref(tf)))
+        ctx.check(ctx.dbg.gapro_debug_wgloop(ctx.handle, None, iters, mode, n_cu, C.c_void_p(src.data_ptr()), C.c_void_p(sink.data_ptr()), C.byref(tf)))
         print("iters %8d (%.2f s) %-22s %6.2f TFLOP/s" % (iters, 2048.0*16*8*iters*n_cu/(tf.value*1e12), nm, tf.value), flush=True)

@@ -42,7 +42,7 @@ for mp in [int(x) for x in args.mp.split(",")]:
             row = []
             for eng in [int(x) for x in args.engines.split(',')]:
                 ms = C.c_float()
-                ctx.check(ctx.lib.gapro_debug_product_bench(ctx.handle, None, eng, shape, mp, args.reps, n_wg,
+                ctx.check(ctx.dbg.gapro_debug_product_bench(ctx.handle, None, eng, shape, mp, args.reps, n_wg,
                                                             C.c_void_p(slab.data_ptr()), C.byref(ms)))
                 us = 1e3 * ms.value / args.reps
                 tf = frac * 2.0 * mp ** 3 * n_wg * args.reps / (ms.value * 1e-3) / 1e12
@@ -53,7 +53,7 @@ for mp in [int(x) for x in args.mp.split(",")]:
                 for eng in [int(x) for x in args.engines.split(',')]:
                     slab.view(n_wg, 3, mp, mp)[:, 2].zero_()
                     ms = C.c_float()
-                    ctx.check(ctx.lib.gapro_debug_product_bench(ctx.handle, None, eng, shape, mp, 1, n_wg,
+                    ctx.check(ctx.dbg.gapro_debug_product_bench(ctx.handle, None, eng, shape, mp, 1, n_wg,
                                                                 C.c_void_p(slab.data_ptr()), C.byref(ms)))
                     c = slab.view(n_wg, 3, mp, mp)[0, 2].clone()
                     if shape in (2, 5):

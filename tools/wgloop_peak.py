@@ -24,12 +24,12 @@ extra = [(8 | 128, "16x16x4", "lds reads + mfma, RANDOM operands"), (16 | 128, "
 for per_cu in (1, 2):
     for m, f, nm in extra:
         tf = C.c_double()
-        ctx.check(lib.gapro_debug_wgloop(ctx.handle, None, 20000, m, per_cu * n_cu, C.c_void_p(src.data_ptr()),
+        ctx.check(ctx.dbg.gapro_debug_wgloop(ctx.handle, None, 20000, m, per_cu * n_cu, C.c_void_p(src.data_ptr()),
                                          C.c_void_p(sink.data_ptr()), C.byref(tf)))
         print("%d WG/CU  %-9s %-36s %6.2f TFLOP/s" % (per_cu, f, nm, tf.value))
     for form in (8, 16):
         for mode in (0, 1, 2, 3, 4, 7):
             tf = C.c_double()
-            ctx.check(lib.gapro_debug_wgloop(ctx.handle, None, 20000, mode | form, per_cu * n_cu,
+            ctx.check(ctx.dbg.gapro_debug_wgloop(ctx.handle, None, 20000, mode | form, per_cu * n_cu,
                                              C.c_void_p(src.data_ptr()), C.c_void_p(sink.data_ptr()), C.byref(tf)))
             print("%d WG/CU  %-9s %-36s %6.2f TFLOP/s" % (per_cu, {0: "4x4x4_4b", 8: "16x16x4", 16: "16x16x4 sp"}[form], names[mode], tf.value))
