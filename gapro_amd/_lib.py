@@ -136,6 +136,7 @@ SIGNATURES = {
     "gapro_pth_close": (None, [_P]),
     "gapro_pth_write": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(PthArray), C.POINTER(_P), C.c_int32]),
     "gapro_pth_last_error": (C.c_char_p, []),
+    "gapro_scene_default_feats": (C.c_int, [_P, _P, C.c_int64, _P]),
 }
 
 # libgapro_hip_debug.so (include/gapro_hip_debug.h): measurement / self-test entry points, loaded on request only

@@ -579,6 +579,7 @@ struct gapro_pth_file {
   int fd = -1;
   const unsigned char* map = nullptr;
   size_t size = 0;
+  bool owned = false;        // map is a malloc'd copy of the file (read), not a mapping
   bool is_sequence = false;  // tuple / list of arrays (false: one bare array)
   std::vector<Array> arrays;
   decode_fn decode = nullptr;
@@ -590,7 +591,8 @@ const char* gapro_pth_last_error(void) { return t_err.c_str(); }
 
 void gapro_pth_close(gapro_pth_file* f) {
   if (!f) return;
-  if (f->map) munmap((void*)f->map, f->size);
+  if (f->map && f->owned) free((void*)f->map);
+  else if (f->map) munmap((void*)f->map, f->size);
   if (f->fd >= 0) close(f->fd);
   delete f;
 }
@@ -606,13 +608,33 @@ int gapro_pth_open(const char* path, gapro_pth_file** out) {
   if (fstat(f->fd, &st) != 0 || st.st_size < 22)
     return fail(GAPRO_ERR_IO, std::string("gapro_pth_open: ") + path + ": not a zip archive (too short)");
   f->size = (size_t)st.st_size;
-  void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, f->fd, 0);
-  if (m == MAP_FAILED) {
-    f->map = nullptr;
-    return fail(GAPRO_ERR_IO, std::string("gapro_pth_open: mmap: ") + strerror(errno));
+  // The file is READ into a heap buffer by default, not mapped: mmap / munmap take the address-space lock of the whole
+  // process and every first touch of a mapped page is a fault under it -- with 8 .. 16 loader threads per worker
+  // process that is what the threads queue on (GAPRO_PTH_MAP=1 maps instead: one thread, or files beyond memory).
+  static const bool use_map = [] { const char* e = getenv("GAPRO_PTH_MAP"); return e && e[0] == '1'; }();
+  if (use_map) {
+    void* m = mmap(nullptr, f->size, PROT_READ, MAP_PRIVATE, f->fd, 0);
+    if (m == MAP_FAILED) {
+      f->map = nullptr;
+      return fail(GAPRO_ERR_IO, std::string("gapro_pth_open: mmap: ") + strerror(errno));
+    }
+    f->map = (const unsigned char*)m;
+    (void)madvise(m, f->size, MADV_SEQUENTIAL);
+  } else {
+    unsigned char* buf = (unsigned char*)malloc(f->size);
+    if (!buf) return fail(GAPRO_ERR_OOM, "gapro_pth_open: out of memory");
+    f->map = buf;
+    f->owned = true;
+    size_t got = 0;
+    while (got < f->size) {
+      const ssize_t r = pread(f->fd, buf + got, f->size - got, (off_t)got);
+      if (r < 0 && errno == EINTR) continue;
+      if (r <= 0) return fail(GAPRO_ERR_IO, std::string("gapro_pth_open: read: ") + (r < 0 ? strerror(errno) : "short file"));
+      got += (size_t)r;
+    }
+    close(f->fd);
+    f->fd = -1;
   }
-  f->map = (const unsigned char*)m;
-  (void)madvise(m, f->size, MADV_SEQUENTIAL);
   const unsigned char* z = f->map;
   const size_t n = f->size;
   // end of central directory: scan back over a possible archive comment
@@ -724,6 +746,22 @@ int gapro_pth_read(const gapro_pth_file* f, int32_t index, void* h_dst, int64_t 
   }
   const long long got = f->decode(a.payload, a.payload_len, (unsigned char*)h_dst, a.nbytes);
   if (got != a.nbytes) return fail(GAPRO_ERR_IO, "gapro_pth_read: malformed UTF-8 payload (or length mismatch)");
+  return GAPRO_OK;
+}
+
+// ---- default features (gen_ps.py:55) ---------------------------------------------------------------------------
+// feats = np.concatenate([xyz, rgb], -1) cast to float32 (gen_ps.py:55 builds the float64 concatenation, :84 uploads it
+// as a float tensor): one pass, each element rounded float64 -> float32 exactly as the cast does.
+int gapro_scene_default_feats(const double* h_xyz, const double* h_rgb, int64_t n_points, float* h_feats) {
+  if (n_points < 0 || (n_points > 0 && (!h_xyz || !h_rgb || !h_feats)))
+    return fail(GAPRO_ERR_BAD_ARG, "gapro_scene_default_feats: bad argument");
+  for (int64_t i = 0; i < n_points; ++i) {
+    float* o = h_feats + 6 * i;
+    const double* a = h_xyz + 3 * i;
+    const double* b = h_rgb + 3 * i;
+    o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)a[2];
+    o[3] = (float)b[0]; o[4] = (float)b[1]; o[5] = (float)b[2];
+  }
   return GAPRO_OK;
 }
 

@@ -1579,6 +1579,13 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
 #else
   auto stamp = [&](int) {};
 #endif
+  // between the products of the merged backward phase: nothing in the product build; the diagnostic build either keeps
+  // the per-product stamps (and with them the barriers: GAPRO_PROFILE_SPLIT) or charges the whole phase to slot 10
+#if defined(GAPRO_PROFILE) && defined(GAPRO_PROFILE_SPLIT)
+#define STAMP_MERGED(id) do { __syncthreads(); stamp(id); } while (0)
+#else
+#define STAMP_MERGED(id) do { } while (0)
+#endif
 
   auto refresh_hypers = [&]() {
     __syncthreads();
@@ -1812,15 +1819,21 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
       product<WG, TU, true, ORD_ROWMAJOR, 1, 1>(mt, mt, true, A, BM, Mp, gv, gls_range, gls_epi, ring);
     else
       product<WG, TU, true, ORD_ROWMAJOR>(mt, mt, true, AT, BMT, Mp, gv, gls_range, gls_epi, ring);
-    __syncthreads();
-    stamp(8);
+    // (round 4) no barrier here, nor after Pm: G_LS, Pm and G_KX^T all read A, B, G_A, LI as the G_A phase left them
+    // and write disjoint matrices (Pm now goes to the L slot, which no single-workgroup MFMA kernel writes since
+    // round 3, instead of the B buffer G_LS is still reading), so a wave that has finished its G_LS tiles goes straight
+    // on to its Pm and G_KX^T tiles.  Three barrier-separated phases whose tiles do not divide evenly among eight waves
+    // (36 lower 32 x 32 tiles at M_p = 256: 4.5 rounds, the slowest wave sets the pace of each) become ONE phase of
+    // 36 + 36 + 64 tiles, with the heavy Adam epilogue of G_LS under other waves' MFMAs.  Same tiles, same k order:
+    // the bits do not change.
+    STAMP_MERGED(8);
     // The Cholesky backward pass needs Pm = Phi(L^T G_L) with G_L = -tril(L^-T G_A A^T) = -tril(G_KX A^T).  Row i of
     // L^T X only reads rows k >= i of X, so the lower triangle of L^T tril(X) is the lower triangle of L^T X, and with
     // X = -L^-T G_A A^T:   Pm = Phi(-G_A A^T)   -- no G_L, no product with L^T (rounds 1-2 and the first half of round 3
     // formed G_L and L^T G_L: 1.33 M^3 where this is 1.0 M^3, one phase and one matrix write more).
     // -> B buffer (dead after G_LS).  KMIN: Pm as it is, from G_A and A as they are (contraction index n along their
     // rows); otherwise Pm^T (the k-major P operand of W: Pm^T[k][i] = Pm[i][k], non-zero for k <= i) from G_A^T and A^T
-    gd* Pm = BM;
+    gd* Pm = f.mat[B_L];
     auto pm_range = [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; };
     if constexpr (KMIN) {
       product<WG, TU, false, ORD_ROWMAJOR, 1, 1>(mt, mt, true, GA, A, Mp, nullptr, pm_range,
@@ -1845,8 +1858,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                          store_tile(pv, nullptr, Pm, Mp, i0, j0, tile);
                        }, ring);
     }
-    __syncthreads();
-    stamp(9);
+    STAMP_MERGED(9);
     // G_KX^T = G_A^T LI (only the transposed form is used: kernel gradients); formed as the product whose
     // output IS the transposed matrix, so that the epilogue is plain row stores   (Q = LI[k][i], non-zero for k >= i)
     product<WG, TU, false, ORD_COLMAJOR>(mt, mt, false, GA, f.mat[B_LI], Mp, nullptr,

@@ -18,7 +18,11 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
                            (largest file first) through O_EXCL claim files under <save_folder>/.claims.*, so a fast
                            GPU takes more; lpt: static longest-processing-time-first partition by file size;
                            roundrobin: rank r takes scenes r, r+world, .. of the sorted list
-    --batch_scenes B       scenes whose GP fits share one launch (default 32)
+    --batch_scenes B       scenes whose GP fits share one launch (default 256: a launch lasts at least as long as its
+                           largest fit -- a floor / wall pair of M ~ 1000 takes ~0.3 s on its 32 CUs -- so small batches
+                           of real scene mixes leave most of the chip idle: 32 scenes per launch ran at 90 scenes/s,
+                           256 at 330; with several workers the claim queue hands out shrinking shares of what is left,
+                           at most B at a time)
     --init_mean_std S      std of the random initial variational mean (gpytorch: 1e-3 unseeded;
                            default 0 = deterministic), --seed seeds it
     --broadcast_mu_var     write mu/var at point length (what the released data loaders index)
@@ -75,27 +79,76 @@ from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
 
 
-def read_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None):
+class SceneScratch:
+    """Grow-only host buffers of one loader thread.  A scene is ~30 MB of short-lived arrays; allocated afresh per
+    scene they are mmap'd, page-faulted and unmapped by glibc every time, which 8 .. 16 threads of one process
+    serialise on.  read_scene(..., scratch=...) decodes and preprocesses into these instead; the returned arrays are
+    views that stay valid until the same thread reads its next scene (the caller uploads / copies them first)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, shape, dtype):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        b = self.bufs.get(name)
+        if b is None or b.nbytes < n:
+            b = self.bufs[name] = np.empty(max(n * 5 // 4, 1 << 16), dtype=np.uint8)
+        return b[:n].view(dtype).reshape(shape)
+
+
+def _load_numpy_file(path, scratch, prefix):
+    """torch.load of a NumPy payload through the native reader, into the thread's scratch buffers when given."""
+    if pth_io.native_enabled():
+        got = pth_io.load_arrays(path, out=(lambda i, shape, dt: scratch.get("%s%d" % (prefix, i), shape, dt))
+                                 if scratch is not None else None)
+        if got is not None:
+            arrays, is_seq = got
+            return tuple(arrays) if is_seq else arrays[0]
+    return torch.load(path, weights_only=False)
+
+
+def read_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None, scratch=None):
     """gen_ps.py:37-69, the disk / host half (thread-safe, no device work): load the scene, build the features
-    from UN-aligned xyz, axis-align, read the wall quads."""
+    from UN-aligned xyz, axis-align, read the wall quads.  The scene and superpoint files go through the native reader
+    (gapro_pth_*: no unpickling, GIL released) where they are NumPy payloads as prepare_data_inst.py:104 /
+    prepare_superpoint.py:27 write them, through torch.load otherwise.  With `scratch` (a SceneScratch owned by the
+    calling thread) every large array lives in reused buffers."""
     scan_name = filename.split("/")[-1][:12]
-    # pth_io.load: the native reader (gapro_pth_*: no unpickling, GIL released) where the file is a NumPy payload as
-    # prepare_data_inst.py:104 / prepare_superpoint.py:27 write it, torch.load for anything else
-    xyz, rgb, semantic_label, instance_label = pth_io.load(filename)
-    spp = pth_io.load(osp.join(data_root, "superpoints", scan_name + ".pth"))
+    xyz, rgb, semantic_label, instance_label = _load_numpy_file(filename, scratch, "scene")
+    spp = _load_numpy_file(osp.join(data_root, "superpoints", scan_name + ".pth"), scratch, "spp")
     spp = spp.numpy() if isinstance(spp, torch.Tensor) else np.asarray(spp)
+    n = xyz.shape[0]
     if use_deepfeat:
         mask_feats = torch.load(osp.join(deepfeat_folder, scan_name + ".pth"), weights_only=False)
         mask_feats = mask_feats.numpy() if isinstance(mask_feats, torch.Tensor) else np.asarray(mask_feats)
+        mask_feats = np.asarray(mask_feats, dtype=np.float32)
+    elif scratch is not None and xyz.ndim == 2 and xyz.shape[1] == 3 and rgb.shape == xyz.shape:
+        # np.concatenate([xyz, rgb], -1).astype(float32) (:55, before the alignment) without the float64 intermediate:
+        # the same per-element rounding, written straight into the reused float32 buffer
+        mask_feats = scratch.get("feats", (n, 6), np.float32)
+        if (xyz.dtype == np.float64 and rgb.dtype == np.float64 and xyz.flags.c_contiguous and rgb.flags.c_contiguous):
+            from . import _lib
+
+            _lib.load().gapro_scene_default_feats(xyz.ctypes.data, rgb.ctypes.data, n, mask_feats.ctypes.data)
+        else:
+            mask_feats[:, 0:3] = xyz
+            mask_feats[:, 3:6] = rgb
     else:
-        mask_feats = np.concatenate([xyz, rgb], axis=-1)  # :55 (before the alignment)
+        mask_feats = np.asarray(np.concatenate([xyz, rgb], axis=-1), dtype=np.float32)  # :55
     A = read_axis_align_matrix(osp.join(data_root, "scans_transform", scan_name, scan_name + ".txt"))
-    pts = np.ones((xyz.shape[0], 4))
-    pts[:, 0:3] = xyz[:, 0:3]
-    xyz_al = np.dot(pts, A.transpose())[:, :3]  # :65-69
+    if scratch is not None:
+        pts = scratch.get("pts", (n, 4), np.float64)
+        pts[:, 3] = 1.0
+        pts[:, 0:3] = xyz[:, 0:3]
+        xyz_al = np.dot(pts, A.transpose(), out=scratch.get("aligned", (n, 4), np.float64))[:, :3]  # :65-69
+    else:
+        pts = np.ones((n, 4))
+        pts[:, 0:3] = xyz[:, 0:3]
+        xyz_al = np.dot(pts, A.transpose())[:, :3]  # :65-69
     wall_cls, wall_box, wall_volume = get_wall_boxes(scan_name, data_root=data_root)
-    return dict(scan_name=scan_name, coords_float=xyz_al, mask_feats=np.asarray(mask_feats, dtype=np.float32),
-                spp=spp.astype(np.int64),
+    return dict(scan_name=scan_name, coords_float=xyz_al, mask_feats=mask_feats,
+                spp=spp.astype(np.int64, copy=False),
                 wall_box=np.asarray(wall_box, dtype=np.float32) if len(wall_box) else [],
                 wall_box_volume=np.asarray(wall_volume, dtype=np.float32) if len(wall_box) else [],
                 semantic_label=semantic_label, instance_label=instance_label)
@@ -229,6 +282,19 @@ def _loader_init():
 
         _BLAS_LIMIT.append(threadpool_limits(1))  # kept alive: the limit is process-wide until this object is dropped
     except Exception:  # noqa: BLE001 - optional
+        pass
+    # A scene is ~30 MB of short-lived NumPy arrays (decoded tuple, features, aligned coordinates).  glibc serves those
+    # with mmap / munmap or trims the heap after every free: page faults and address-space locking that 8 .. 16 loader
+    # threads of one process serialise on (8 threads: 134 -> 205 scenes/s of host work with the heap kept).  Keep freed
+    # memory in the process: M_MMAP_THRESHOLD (-3) at its 32 MiB maximum, M_TRIM_THRESHOLD (-1) and M_TOP_PAD (-2) large.
+    try:
+        import ctypes
+
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 32 << 20)
+        libc.mallopt(-1, 0x7FFFFFFF)
+        libc.mallopt(-2, 256 << 20)
+    except Exception:  # noqa: BLE001 - not glibc
         pass
 
 
@@ -370,8 +436,9 @@ _T_IMPORT = time.time()
 def _chunks(filenames, args, queue):
     """Batches of scenes still to do (:39-41): from the shared queue, or this worker's static shard."""
     if queue is not None:
+        n_workers = max(1, int(getattr(args, "n_workers", 1)))
         while True:
-            got = queue.claim(args.batch_scenes)
+            got = queue.claim(queue.guided(args.batch_scenes, n_workers))
             if not got:
                 return
             got = pending_scenes(got, args.save_folder)
@@ -408,14 +475,27 @@ def run_worker_dry(filenames, args, rank):
     t0 = time.time()
     done, failed_names = 0, []
 
+    import threading
+
+    tls = threading.local()
+
     def one(fn):
-        sc = read_scene(fn, *read_args)
+        if not hasattr(tls, "scratch"):
+            tls.scratch = SceneScratch()
+        sc = read_scene(fn, *read_args, scratch=tls.scratch)
         n = int(len(sc["spp"]))
-        for k in _DEVICE_DTYPES:  # the upload's pass over the arrays (host -> pinned staging buffer)
-            np.array(sc[k])
+        for k in _DEVICE_DTYPES:  # the upload's pass over the arrays (host -> the thread's staging buffer)
+            a = np.asarray(sc[k])
+            np.copyto(tls.scratch.get("stage_" + k, a.shape, a.dtype), a)
         s = max(1, n // 50)
-        arrays = (np.zeros(n, np.int32), np.zeros(n, np.int32), np.ones(n, np.float32),
-                  np.full(s, -100.0, np.float32), np.full(s, -100.0, np.float32))
+        arrays = (tls.scratch.get("o0", (n,), np.int32), tls.scratch.get("o1", (n,), np.int32),
+                  tls.scratch.get("o2", (n,), np.float32), tls.scratch.get("o3", (s,), np.float32),
+                  tls.scratch.get("o4", (s,), np.float32))
+        arrays[0][:] = 0
+        arrays[1][:] = 0
+        arrays[2][:] = 1.0
+        arrays[3][:] = -100.0
+        arrays[4][:] = -100.0
         _save_arrays(osp.join(out_folder, sc["scan_name"] + ".pth"), arrays, None)
         return sc["scan_name"]
 
@@ -545,8 +625,13 @@ def run_worker(filenames, args, device_index):
             dev_sc.update(stager().upload({k: sc[k] for k in _SHM_KEYS if k in _DEVICE_DTYPES}, _DEVICE_DTYPES))
             return add_instance_info(dev_sc, dev)
 
+    def scratch():
+        if not hasattr(tls, "scratch"):
+            tls.scratch = SceneScratch()
+        return tls.scratch
+
     def read_and_cache(fn):
-        sc = read_scene(fn, *read_args)
+        sc = read_scene(fn, *read_args, scratch=scratch())  # consumed (uploaded) by this thread before its next read
         if raw_cache:
             try:
                 write_raw_cache(raw_cache_path(raw_cache, fn), sc, _source_stamp(fn, *read_args))
@@ -785,7 +870,7 @@ def main(argv=None):
     parser.add_argument("--data_root", type=str, default="dataset/scannetv2")
     parser.add_argument("--split", type=str, default="train", choices=["train", "val"])
     parser.add_argument("--devices", type=str, default="0")
-    parser.add_argument("--batch_scenes", type=int, default=32)
+    parser.add_argument("--batch_scenes", type=int, default=256)
     parser.add_argument("--init_mean_std", type=float, default=0.0)
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--broadcast_mu_var", action="store_true")

@@ -434,6 +434,9 @@ void gapro_pth_close(gapro_pth_file* f);
 int gapro_pth_write(const char* path, int32_t n_arrays, const gapro_pth_array* descs, const void* const* h_data,
                     int32_t as_tuple);
 const char* gapro_pth_last_error(void);
+/* The reference's default features (gen_ps.py:55: np.concatenate([xyz, rgb], -1) of the UN-aligned coordinates, uploaded
+ * as float32 at :84): h_feats[n][6] = float32 of [xyz | rgb], one pass on the host. */
+int gapro_scene_default_feats(const double* h_xyz, const double* h_rgb, int64_t n_points, float* h_feats);
 
 /* ------------------------------------------------------------------------------------------
  * Inspection (tests): where a fit's trained parameters live in its workspace.  The measurement / self-test entry points

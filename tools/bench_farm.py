@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--data_root", required=True)
     ap.add_argument("--devices", default="0")
     ap.add_argument("--passes", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--raw_cache", action="store_true", help="a further pass over the raw scene cache (opt-in of gen_ps)")
     ap.add_argument("--gen-ps-args", default="", help="extra arguments for gen_ps, space separated")
     ap.add_argument("--keep", action="store_true")
