@@ -988,6 +988,113 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
   }
 }
 
+// ---- the look-ahead with the next column's partial sums in REGISTERS (staged kernel, round 4) --------------------
+// The LDS look-ahead above needs two panels (87 KB at M_p = 256), which the staged kernel does not have beside Z, X
+// and its two-workgroups-per-CU budget of 72 KB.  Here the tiles of column kb + 1 that a wave builds while wave 0
+// factors the diagonal block of column kb stay in that wave's registers (at most TMAX accumulators of 8 VGPRs: block
+// rows kb + w, kb + w + 7, ... for wave w >= 1), take column kb's rank-16 contribution from the scaled panel, and are
+// written to the ONE panel once every reader of column kb is done with it.  Same MFMAs in the same order per
+// accumulator: bit-identical to cholesky_fused.  Four barriers per block column, as there.
+template <int DC, int TMAX>
+__device__ __noinline__ void cholesky_fused_lookahead_reg(const ldsd* Zt, ldsd* panel, double s, double inv_l2,
+                                                          double jitter) {
+  const Fit& f = g_sh.f;
+  Shared& sh = g_sh;
+  const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D, nb = Mp / 16;
+  gd* LT = f.mat[B_LT];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lr = lane & 15, lq = lane >> 4;
+  // block (ib, kb) of Kzz + jitter I minus the contributions of the block columns < qb
+  auto build = [&](int ib, int kb, int qb) -> d4 {
+    d4 acc;
+    const int col = 16 * kb + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * ib + lq + 4 * r;
+      double v = 0.0;
+      if (row < M && col < M) {
+        v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+        if (row == col) v += jitter;
+      } else if (row == col) {
+        v = 1.0;
+      }
+      acc[r] = v;
+    }
+    const gd* pa = LT + (size_t)lq * Mp + 16 * ib + lr;
+    const gd* pb = LT + (size_t)lq * Mp + 16 * kb + lr;
+    chol_update_tile(acc, pa, pb, Mp, 16 * qb);
+    return acc;
+  };
+  for (int ib = wave; ib < nb; ib += NW) {
+    const d4 acc = build(ib, 0, 0);
+    ldsd* dst = panel + (16 * ib) * 17;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = acc[r];
+  }
+  __syncthreads();
+  d4 nx[TMAX];
+  for (int kb = 0; kb < nb; ++kb) {
+    // (2) diagonal block on wave 0 | column kb + 1 without the contribution of column kb on the other waves
+    if (wave == 0) {
+      diag_factor_invert(panel, kb);
+    } else {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        const int ib = kb + wave + t * (NW - 1);
+        if (ib < nb) nx[t] = build(ib, kb + 1, kb);
+      }
+    }
+    __syncthreads();
+    prof_stamp(5);
+    // (3) rows below the diagonal block, in LDS: P[i][c] <- sum_{q <= c} S[i][q] Dinv[c][q]
+    const int rows_below = Mp - 16 * (kb + 1);
+    ldsd* pb = panel + 16 * 17;
+    for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {
+      const int i = idx >> 4, c = idx & 15;
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc += (q <= c) ? pb[i * 17 + q] * sh.dinv[c * 17 + q] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();  // the 16 lanes of a row have all read S before any overwrites it
+      pb[i * 17 + c] = acc;
+    }
+    __syncthreads();
+    // column kb's contribution to this wave's tiles of column kb + 1, both operands from the scaled panel
+    if (wave != 0) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        const int ib = kb + wave + t * (NW - 1);
+        if (ib < nb) {
+          const ldsd* la = pb + (16 * (ib - kb - 1) + lr) * 17 + lq;
+          const ldsd* lb = pb + lr * 17 + lq;
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+            nx[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[4 * st], lb[4 * st], nx[t], 0, 0, 0);
+        }
+      }
+    }
+    if (rows_below > 0)
+      for (int idx = threadIdx.x; idx < rows_below * 16; idx += NT) {  // L^T rows: contiguous in i
+        const int c = idx / rows_below, i = idx - c * rows_below;
+        LT[(size_t)(16 * kb + c) * Mp + 16 * (kb + 1) + i] = pb[i * 17 + c];
+      }
+    __syncthreads();  // every reader of the scaled column kb is done: the panel takes column kb + 1
+    if (wave != 0) {
+#pragma unroll
+      for (int t = 0; t < TMAX; ++t) {
+        const int ib = kb + wave + t * (NW - 1);
+        if (ib < nb) {
+          ldsd* dst = panel + (16 * (ib - kb - 1)) * 17;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(lq + 4 * r) * 17 + lr] = nx[t][r];
+        }
+      }
+    }
+    __syncthreads();
+    prof_stamp(18);
+  }
+}
+
 // ---- gpytorch's psd_safe_cholesky around either factorisation -----------------------------------------------
 // VariationalStrategy._cholesky_factor calls psd_safe_cholesky(K_ZZ.double() + jitter I): when the factorisation meets
 // a non-positive pivot it is repeated on K + j I with j = psd_jitter * 10^i (settings.cholesky_jitter: 1e-8 for
@@ -995,12 +1102,16 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
 // GAPRO_ERR_CHOLESKY for this fit; the other fits of the launch are unaffected).  The extra jitter lives inside the
 // factorisation only: it is not added to the k_xx term of the predictive variance, as in gpytorch.  A function of its
 // own so that the retry state is not live across the step loop of the callers.
-template <int DC, bool LOOKAHEAD>
+// LOOKAHEAD: 0 = cholesky_fused, 1 = two LDS panels (strip kernels), 2 / 3 = the next column in registers, at most 3 / 5
+// tiles per wave (staged kernel: M_p <= 256 / <= 512)
+template <int DC, int LOOKAHEAD>
 __device__ __noinline__ void cholesky_psd_safe(const ldsd* Zt, ldsd* scratch, double s, double inv_l2, double jitter,
                                                int retries, double psd_jitter) {
   double extra = 0.0;
   for (int attempt = 0;; ++attempt) {
-    if (LOOKAHEAD) cholesky_fused_lookahead<DC>(Zt, scratch, s, inv_l2, jitter + extra);
+    if (LOOKAHEAD == 1) cholesky_fused_lookahead<DC>(Zt, scratch, s, inv_l2, jitter + extra);
+    else if (LOOKAHEAD == 2) cholesky_fused_lookahead_reg<DC, 3>(Zt, scratch, s, inv_l2, jitter + extra);
+    else if (LOOKAHEAD == 3) cholesky_fused_lookahead_reg<DC, 5>(Zt, scratch, s, inv_l2, jitter + extra);
     else cholesky_fused<DC>(Zt, scratch, s, inv_l2, jitter + extra);
     const int bad = g_sh.chol_bad;  // both factorisations end with a workgroup barrier
     if (!bad) return;               // the common case: one LDS read, no extra barrier
@@ -1583,8 +1694,13 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   // the per-product stamps (and with them the barriers: GAPRO_PROFILE_SPLIT) or charges the whole phase to slot 10
 #if defined(GAPRO_PROFILE) && defined(GAPRO_PROFILE_SPLIT)
 #define STAMP_MERGED(id) do { __syncthreads(); stamp(id); } while (0)
+#elif defined(GAPRO_NO_MERGED_BWD)  // A/B builds: the three products as three barrier-separated phases (round 3)
+#define STAMP_MERGED(id) do { __syncthreads(); } while (0)
 #else
-#define STAMP_MERGED(id) do { } while (0)
+  // merged only in the KMIN instantiations (M_p <= 256).  Beyond, G_A^T lives in the G_KX^T slot until G_KX^T is formed
+  // (GAT below), so Pm -- which reads it -- must be complete before G_KX^T starts; and with one workgroup per CU and
+  // 64 x 64 tiles the merge measured +-0 there anyway.
+#define STAMP_MERGED(id) do { if constexpr (!KMIN) __syncthreads(); } while (0)
 #endif
 
   auto refresh_hypers = [&]() {
@@ -1598,7 +1714,15 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   };
   auto factorize = [&]() {
     stamp(19);
-    cholesky_psd_safe<DC, false>(Zt, scratch, sh.s, sh.inv_l2, jitter, opt.psd_retries, opt.psd_jitter);
+#ifdef GAPRO_NO_CHOL_LOOKAHEAD
+    cholesky_psd_safe<DC, 0>(Zt, scratch, sh.s, sh.inv_l2, jitter, opt.psd_retries, opt.psd_jitter);
+#else
+    // The register look-ahead (next column's tiles built while wave 0 factors the diagonal block) beyond M_p = 256:
+    // one workgroup per CU there, nobody else fills the CU while seven waves wait for the diagonal block (512 fits:
+    // M = 320 -1.9 %, 384 -1.6 %, 448 -1.0 % in time, bit-identical).  Up to 256 two workgroups share a CU and hide
+    // each other's serial stretches: 160 +-0, 200 +1.3 %, 256 +1 % -- not used there.
+    cholesky_psd_safe<DC, KMIN ? 0 : 3>(Zt, scratch, sh.s, sh.inv_l2, jitter, opt.psd_retries, opt.psd_jitter);
+#endif
     stamp(1);
     if (Mp <= 128)
       tri_inverse<8>(scratch);
@@ -2501,7 +2625,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   };
   auto factorize = [&]() {
     stamp(19);
-    cholesky_psd_safe<DC, true>(Zt, scratch, sh.s, sh.inv_l2, jitter, opt.psd_retries, opt.psd_jitter);
+    cholesky_psd_safe<DC, 1>(Zt, scratch, sh.s, sh.inv_l2, jitter, opt.psd_retries, opt.psd_jitter);
     stamp(1);
     tri_inverse_strip(scratch);
     __syncthreads();

@@ -30,10 +30,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(workers, data, out_root, native=True, tag=""):
+def measure(workers, data, out_root, native=True, tag="", threads=-1):
     save = os.path.join(out_root, "w%d%s" % (workers, tag))
     cmd = [sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", data, "--batch_scenes", "32",
-           "--devices", ",".join(str(d) for d in range(workers)), "--raw_cache", "none", "--dry_run"]
+           "--devices", ",".join(str(d) for d in range(workers)), "--raw_cache", "none", "--dry_run", "--loader_threads", str(threads)]
     env = dict(os.environ, GAPRO_NATIVE_PTH="1" if native else "0")
     t = time.time()
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=env)
@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--unique", type=int, default=16)
     ap.add_argument("--gpu-rate", type=float, default=340.0, help="scenes/s one GPU takes (resident inputs)")
     ap.add_argument("--torch-io", action="store_true", help="also the round-1..3 I/O (GAPRO_NATIVE_PTH=0)")
+    ap.add_argument("--threads", type=int, default=-1, help="loader threads per worker (-1 = gen_ps's own choice)")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
     from gapro_amd.synth import make_scene, write_scannet_layout
@@ -86,7 +87,7 @@ def main():
         rows = []
         for w in [int(x) for x in args.workers.split(",") if x]:
             for native in ((True, False) if args.torch_io else (True,)):
-                r = measure(w, data, root, native, "" if native else "t")
+                r = measure(w, data, root, native, "" if native else "t", args.threads)
                 r["projected_farm_scenes_per_s"] = round(min(w * args.gpu_rate, r["scenes_per_s"]), 1)
                 rows.append(r)
                 print("workers %d x %s loader threads, %s: host delivers %7.1f scenes/s -> farm of %d GPUs: "
