@@ -59,7 +59,8 @@ def main():
     ap.add_argument("--workers", default="1,2,4,8")
     ap.add_argument("--scenes", type=int, default=1024)
     ap.add_argument("--points", type=int, default=150000)
-    ap.add_argument("--unique", type=int, default=16)
+    ap.add_argument("--unique", type=int, default=16, help="scenes generated")
+    ap.add_argument("--distinct", type=int, default=512, help="scenes with files of their own (copies of the generated ones)")
     ap.add_argument("--gpu-rate", type=float, default=340.0, help="scenes/s one GPU takes (resident inputs)")
     ap.add_argument("--torch-io", action="store_true", help="also the round-1..3 I/O (GAPRO_NATIVE_PTH=0)")
     ap.add_argument("--threads", type=int, default=-1, help="loader threads per worker (-1 = gen_ps's own choice)")
@@ -75,11 +76,18 @@ def main():
             sc = make_scene(seed=i % 8, n_points=args.points, n_objects=25, with_walls_json=False,
                             scan_name="scene%04d_00" % i)
             write_scannet_layout(sc, data)
+        # Further scenes are real COPIES (own inodes, own page-cache pages) up to --distinct, links beyond: with 16
+        # files behind 1024 names, 64 .. 128 reader threads take and drop references on the same few thousand page
+        # structs -- cache-line ping-pong across both sockets that a dataset of distinct files does not have (round 4:
+        # 4 workers x 16 threads read 985 scenes/s from 16 linked files)
+        link = os.symlink
         for i in range(uniq, args.scenes):
-            src, dst = "scene%04d_00" % (i % uniq), "scene%04d_00" % i
-            os.symlink(os.path.join(data, "train", src + "_inst_nostuff.pth"),
-                       os.path.join(data, "train", dst + "_inst_nostuff.pth"))
-            os.symlink(os.path.join(data, "superpoints", src + ".pth"), os.path.join(data, "superpoints", dst + ".pth"))
+            base = i % uniq if i < args.distinct else uniq + (i - uniq) % max(1, min(args.distinct, args.scenes) - uniq)
+            src, dst = "scene%04d_00" % base, "scene%04d_00" % i
+            make = shutil.copyfile if i < args.distinct else link
+            make(os.path.join(data, "train", src + "_inst_nostuff.pth"),
+                 os.path.join(data, "train", dst + "_inst_nostuff.pth"))
+            make(os.path.join(data, "superpoints", src + ".pth"), os.path.join(data, "superpoints", dst + ".pth"))
             os.makedirs(os.path.join(data, "scans_transform", dst))
             os.symlink(os.path.join(data, "scans_transform", src, src + ".txt"),
                        os.path.join(data, "scans_transform", dst, dst + ".txt"))
