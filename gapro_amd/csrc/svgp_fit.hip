@@ -280,6 +280,75 @@ enum { ORD_ROWMAJOR = 0,   // equal ranges, or ranges shrinking with the tile ro
 // MFMA step e = 0, 1 of a block of 8 is k0 + 2 (lane >> 4) + e for BOTH operands (a k-major operand then reads rows
 // k0 + 2 lq and k0 + 2 lq + 1) -- a fixed permutation of the contraction order inside a block, so these products do not
 // have the bits of the k-major form, but every product has ONE form in all kernels' variants that must agree.
+// ---- two-phase epilogues (round 4) --------------------------------------------------------------------------------
+// An epilogue that READS memory (G_A: A, m, g_mu, g_v; G_LS: L_S and its Adam moments) used to be called block by block
+// behind the k-loop: loads of block n + 1 were issued behind the stores of block n (the compiler cannot prove that GA
+// and A do not alias) and vmcnt counts loads and stores in issue order, so every 16 x 16 block of a tile paid one full
+// memory round trip -- the G_A and G_LS phases ran at 19 .. 42 % matrix-pipe busy where the plain-store G_KX^T product
+// runs at 41 .. 72 % (tools/phase_table.py).  A two-phase epilogue splits into load(i0, j0) -> Pre (loads only) and
+// store(i0, j0, block, pre): the product engines call load() for a group of up to four blocks back to back, then
+// store() for the group -- one round trip per group.  Same arithmetic per element: bit-identical.
+// GROUP = blocks whose loads are issued together: 4 with the whole register file (256 VGPRs: M = 320 -4.6 %, 384
+// -3.2 %, 448 -1.9 % in time with the register look-ahead Cholesky), 1 in the 128-VGPR two-per-CU build, where
+// the ~100 registers of four blocks' operands spill and the second workgroup hides the round trips anyway (group 4
+// there: M = 144 .. 200 +9 %, 256 +5 % in time).
+template <int GROUP, typename LoadF, typename StoreF>
+struct TwoPhaseEpi {
+  LoadF load;
+  StoreF store;
+  static constexpr bool two_phase = true;
+  static constexpr int group = GROUP;
+};
+template <int GROUP = 4, typename LoadF, typename StoreF>
+__device__ inline TwoPhaseEpi<GROUP, LoadF, StoreF> two_phase_epi(LoadF l, StoreF st) {
+  return TwoPhaseEpi<GROUP, LoadF, StoreF>{l, st};
+}
+template <typename T, typename = void>
+struct is_two_phase : std::false_type {};
+template <typename T>
+struct is_two_phase<T, std::void_t<decltype(T::two_phase)>> : std::true_type {};
+// an epilogue shifted by (r0, c0): what product<> hands to the per-wave strips of a workgroup-tiled product
+template <typename Epi>
+__device__ inline auto shifted_epi(Epi epi, int r0, int c0) {
+  if constexpr (is_two_phase<Epi>::value) {
+    return two_phase_epi<Epi::group>([=](int i, int j) { return epi.load(r0 + i, c0 + j); },
+                         [=](int i, int j, const gapro_mfma::d4& v, const auto& pre) { epi.store(r0 + i, c0 + j, v, pre); });
+  } else {
+    return [=](int i, int j, const gapro_mfma::d4& v) { epi(r0 + i, c0 + j, v); };
+  }
+}
+// run the epilogue over NB blocks; blk(b, &i, &j) gives block b's position (or i < 0: not part of the output),
+// acc(b) its accumulator
+template <int NB, typename Epi, typename BlkPos, typename AccOf>
+__device__ inline void run_epilogue(Epi& epi, BlkPos blk, AccOf acc) {
+  if constexpr (is_two_phase<Epi>::value) {
+    constexpr int G = NB < Epi::group ? NB : Epi::group;
+#pragma unroll
+    for (int g0 = 0; g0 < NB; g0 += G) {
+      decltype(epi.load(0, 0)) pv[G];
+#pragma unroll
+      for (int b = 0; b < G; ++b) {
+        int i, j;
+        blk(g0 + b, &i, &j);
+        if (i >= 0) pv[b] = epi.load(i, j);
+      }
+#pragma unroll
+      for (int b = 0; b < G; ++b) {
+        int i, j;
+        blk(g0 + b, &i, &j);
+        if (i >= 0) epi.store(i, j, acc(g0 + b), pv[b]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      int i, j;
+      blk(b, &i, &j);
+      if (i >= 0) epi(i, j, acc(b));
+    }
+  }
+}
+
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) d2 lds_d2;
 typedef __attribute__((address_space(1))) d2 g_d2;
@@ -400,10 +469,8 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
         mma_block(a0, b0, s0);
       }
     }
-#pragma unroll
-    for (int u = 0; u < TV; ++u)
-#pragma unroll
-      for (int v = 0; v < TV; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
+    run_epilogue<TV * TV>(epi, [&](int b, int* i, int* j) { *i = i0 + 16 * (b / TV); *j = j0 + 16 * (b % TV); },
+                          [&](int b) -> const d4& { return acc[b / TV][b % TV]; });
   };
   // full tiles: fo x fn of TU x TU blocks.  TU >= 2 takes its extents in HALF tiles (TU = 2: 16 x 16, TU = 4: 32 x 32)
   // and an odd count leaves a last row / column of half-size tiles: M_p need not be a multiple of the tile (round 3:
@@ -667,11 +734,13 @@ __device__ __noinline__ void gemm_wg(int rows16, int cols16, bool lower_only, co
       }
       // (no barrier here: what slower waves may still do with the ring is the read-ahead of a chunk that does not
       // exist, and the next tile's prologue has a barrier between its first LDS store and everything else)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (on_mask & (1u << (4 * u + v))) epi(I0 + 32 * wi + 16 * u, J0 + 64 * wj + 16 * v, acc[u][v]);
+      run_epilogue<8>(epi,
+                      [&](int b, int* i, int* j) {
+                        const bool on = (on_mask >> b) & 1u;
+                        *i = on ? I0 + 32 * wi + 16 * (b >> 2) : -1;
+                        *j = J0 + 64 * wj + 16 * (b & 3);
+                      },
+                      [&](int b) -> const d4& { return acc[b >> 2][b & 3]; });
     }
   }
 }
@@ -1220,7 +1289,29 @@ __device__ __noinline__ void tri_inverse(ldsd* tiles) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lr = lane & 15, lq = lane >> 4;
   ldsd* tile = tiles + wave * 16 * 17;
-  for (int k = wave; k < nb; k += NW) {
+  // Which wave takes which block column.  NBR > 0 (M_p <= 128): round-robin, at most one column per wave.  Long
+  // columns (NBR == 0, round 4): a column of n blocks is a serial chain of n (n - 1) / 2 block products, and dealt
+  // round-robin wave 0 got columns 0, 8, 16, ... -- 1.5x the mean work at M_p = 384, with the whole workgroup waiting
+  // for it at the barrier behind this phase.  Longest-processing-time-first instead: columns in ascending k (descending
+  // cost) each go to the wave with the least work so far (every wave computes the same table; the result of a column
+  // does not depend on who computes it: bit-identical).
+  unsigned long long mine = 0;  // bit k: this wave computes block column k (nb <= 32)
+  if (NBR == 0) {
+    int load[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) load[w] = 0;
+    for (int k = 0; k < nb; ++k) {
+      int best = 0;
+#pragma unroll
+      for (int w = 1; w < NW; ++w) best = load[w] < load[best] ? w : best;
+      const int n = nb - k;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) load[w] += (w == best) ? n * (n - 1) / 2 + 1 : 0;
+      if (best == wave) mine |= 1ull << k;
+    }
+  }
+  for (int k = NBR > 0 ? wave : 0; k < nb; k += NBR > 0 ? NW : 1) {
+    if (NBR == 0 && !((mine >> k) & 1ull)) continue;
     d4 blk[NBR > 0 ? NBR : 1];
     d4 dk;
 #pragma unroll
@@ -1253,21 +1344,19 @@ __device__ __noinline__ void tri_inverse(ldsd* tiles) {
       }
     } else {
       for (int i = k + 1; i < nb; ++i) {
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        // nacc = -sum_{j = k}^{i - 1} L_ij LI_jk through the Cholesky update's double-buffered block loop (round 4: the
+        // loop here issued the eight loads of a block and waited for them before its four MFMAs, one memory round trip
+        // per block of a chain of up to nb (nb - 1) / 2 blocks).  -(a) b accumulated is exactly -(a b accumulated), and
+        // (-Dinv) x = Dinv (-x): the same bits as before.
+        d4 nacc = (d4){0.0, 0.0, 0.0, 0.0};
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        for (int j = k; j < i; ++j) {
-#pragma unroll
-          for (int q = 0; q < 16; q += 4) {
-            const double a = LT[(size_t)(16 * j + q + lq) * Mp + 16 * i + lr];
-            const double b = LI[(size_t)(16 * j + q + lq) * Mp + 16 * k + lr];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-          }
-        }
+        chol_update_tile(nacc, LT + (size_t)(16 * k + lq) * Mp + 16 * i + lr, LI + (size_t)(16 * k + lq) * Mp + 16 * k + lr,
+                         Mp, 16 * (i - k));
         d4 out = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sstep = 0; sstep < 4; ++sstep) {
-          const double a = -f.dinvT[(size_t)i * 256 + (4 * sstep + lq) * 16 + lr];  // -Dinv_i[lr][4s + lq]
-          out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[sstep], out, 0, 0, 0);
+          const double a = f.dinvT[(size_t)i * 256 + (4 * sstep + lq) * 16 + lr];  // Dinv_i[lr][4s + lq]
+          out = __builtin_amdgcn_mfma_f64_16x16x4f64(a, nacc[sstep], out, 0, 0, 0);
         }
         store_tile(out, LI, U, Mp, 16 * i, 16 * k, tile);
       }
@@ -1610,7 +1699,7 @@ __device__ inline void product(int mo, int no, bool lower, const gd* __restrict_
             *lo = l0;
             *hi = h1;
           },
-          [=](int i, int j, const d4& v) { epi(r0 + i, c0 + j, v); });
+          shifted_epi(epi, r0, c0));
     };
     auto strip = [&](int r0, int c0, int nr, int nc, bool low) {  // rows [r0, r0 + nr) x columns [c0, c0 + nc)
       strip_t(std::integral_constant<int, 2>{}, r0, c0, nr, nc, low);
@@ -1645,7 +1734,7 @@ __device__ inline void product(int mo, int no, bool lower, const gd* __restrict_
 // lines per instruction where the k-major form touches 4 whole ones, and the lower-triangular products are 25 .. 30 %
 // slower with them; with one workgroup per CU (M_p >= 288) that costs what the copies cost (320: -1 %, 384: -3 %,
 // 448: +2 %), so the larger fits keep the copies.
-template <int TU, int DMAX, int DC, int WG = 0, bool KMIN = false>
+template <int TU, int DMAX, int DC, int WG = 0, bool KMIN = false, int EG = 4>
 __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* scratch, const gapro_fit_desc& desc, float* __restrict__ o_probs, float* __restrict__ o_probs_new,
                          unsigned char* __restrict__ o_labels, float* __restrict__ o_mu, float* __restrict__ o_var,
                          double* loss_out) {
@@ -1877,18 +1966,35 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     // 16-column tiles go to LDS, or beyond M_p = kFuseMaxMp to the G_KX slot (written two phases later)
     gd* gpart_g = f.mat[B_GKX];
     // G_A[i][n] = 2 g_v[n] sum_j LS[i][j] BM[j][n] + m[i] g_mu[n] - 2 A[i][n] g_v[n]
+    // (two-phase epilogue: the loads of A, m, g_mu, g_v for a group of blocks are issued together, see two_phase_epi)
+    struct GaPre { double a[4], m[4], gvn, gmn; };
     product<WG, TU, false, ORD_ROWS_DESC>(mt, mt, false, LST, BM, Mp, nullptr,
                        [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
-                       [=](int i0, int n0, const d4& v) {
+                       two_phase_epi<EG>(
+                       [=](int i0, int n0) {
                          const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                          const int n = n0 + lr;
-                         const double gvn = gv[n], gmn = gmu[n];
+                         GaPre p;
+                         p.gvn = gv[n];
+                         p.gmn = gmu[n];
+#pragma unroll
+                         for (int r = 0; r < 4; ++r) {
+                           const int i = i0 + lq + 4 * r;
+                           p.a[r] = A[(size_t)i * Mp + n];
+                           p.m[r] = vm[i];
+                         }
+                         return p;
+                       },
+                       [=](int i0, int n0, const d4& v, const GaPre& p) {
+                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+                         const int n = n0 + lr;
+                         const double gvn = p.gvn, gmn = p.gmn;
                          d4 ga;
 #pragma unroll
                          for (int r = 0; r < 4; ++r) {
                            const int i = i0 + lq + 4 * r;
-                           const double a = A[(size_t)i * Mp + n];
-                           ga[r] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
+                           const double a = p.a[r];
+                           ga[r] = 2.0 * gvn * v[r] + p.m[r] * gmn - 2.0 * a * gvn;
                            if constexpr (KMIN) GA[(size_t)i * Mp + n] = ga[r];
                            double pg = a * gmn;
                            pg += __shfl_xor(pg, 1, 64);
@@ -1901,7 +2007,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                            }
                          }
                          if constexpr (!KMIN) store_tile(ga, GA, GAT, Mp, i0, n0, tile);
-                       }, ring);
+                       }), ring);
     __syncthreads();
     for (int i = threadIdx.x; i < Mp; i += NT) {
       double sg = 0.0;
@@ -1915,7 +2021,22 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
     stamp(7);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] BM[j][n] (lower) + KL', Adam on LS fused in the epilogue
-    auto gls_epi = [=](int i0, int j0, const d4& v) {
+    struct LsPre { double l[4], m1[4], m2[4]; };
+    auto gls_epi = two_phase_epi<EG>(
+                      [=](int i0, int j0) {
+                        const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+                        const int j = j0 + lr;
+                        LsPre p;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {  // unconditional: every (i, j) of a tile lies inside the M_p x M_p slots
+                          const size_t o = (size_t)(i0 + lq + 4 * r) * Mp + j;
+                          p.l[r] = LS[o];
+                          p.m1[r] = MLS[o];
+                          p.m2[r] = VLS[o];
+                        }
+                        return p;
+                      },
+                      [=](int i0, int j0, const d4& v, const LsPre& p) {
                         const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
                         const int j = j0 + lr;
                         d4 newv;
@@ -1925,10 +2046,10 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                           const size_t o = (size_t)i * Mp + j;
                           double lnew = 0.0;
                           if (j <= i && i < M) {
-                            const double l = LS[o];
+                            const double l = p.l[r];
                             const double g = 2.0 * v[r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
-                            const double m1 = b1 * MLS[o] + (1.0 - b1) * g;
-                            const double m2 = b2 * VLS[o] + (1.0 - b2) * g * g;
+                            const double m1 = b1 * p.m1[r] + (1.0 - b1) * g;
+                            const double m2 = b2 * p.m2[r] + (1.0 - b2) * g * g;
                             MLS[o] = m1;
                             VLS[o] = m2;
                             lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
@@ -1937,7 +2058,7 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
                           newv[r] = lnew;
                         }
                         store_tile(newv, nullptr, LST, Mp, i0, j0, tile);  // LST[j][i]; zeros above the diagonal
-                      };
+                      });
     auto gls_range = [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; };
     if constexpr (KMIN)  // A and B as they are: both with the contraction index n along their rows
       product<WG, TU, true, ORD_ROWMAJOR, 1, 1>(mt, mt, true, A, BM, Mp, gv, gls_range, gls_epi, ring);
@@ -2208,7 +2329,8 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
   // the reference's two feature widths (xyz+rgb = 6, deep features = 32) get a compile-time D: the distance
   // loops unroll and their LDS reads are issued together; any other D <= 32 runs the generic body
 #define GAPRO_FIT_KM(TUV, DM, DCV, WGV)                                                                       \
-  fit_body<TUV, DM, DCV, WGV, KMIN>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, o_var, loss_slot)
+  fit_body<TUV, DM, DCV, WGV, KMIN, (WPS == 2 ? 4 : 1)>(opt, Zt, Pt, scratch, desc, o_probs, o_probs_new, o_labels, o_mu, \
+                                                        o_var, loss_slot)
 #define GAPRO_FIT_BODY(DM, DCV)                                                                              \
   do {                                                                                                       \
     if (Mp > kFuseMaxMp && Mp % 32 == 0 && !(opt.reserved & 131072) &&                                       \

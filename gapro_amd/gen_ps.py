@@ -754,9 +754,11 @@ def run_worker(filenames, args, device_index):
               "outputs go to %s, never to --save_folder" % out_folder, file=sys.stderr)
     writes = []
     t_first = None
+    n_first = 0
     for outs in (host_only_stream(batches()) if host_only else pipe.run_stream(batches())):
         if t_first is None:
             t_first = time.time()
+            n_first = len(outs)
         scenes, jobs = meta.pop(0)
         t_exp = time.time()
         ready = torch.cuda.current_stream(dev).record_event()  # run_stream ordered the outputs on this stream
@@ -808,6 +810,12 @@ def run_worker(filenames, args, device_index):
           % (device_index, t0 - _T_IMPORT, (t_first - t0) if t_first else 0.0, n_threads, n_procs,
              "native (gapro_pth_*)" if native else "torch.load / torch.save",
              ", host-only measurement mode" if host_only else ""))
+    # the first batch carries the one-off costs of a worker (code objects, the fit workspaces of every pipeline slot:
+    # tens of GB of hipMalloc + fill, the first reads with an empty pipeline); what follows it is the steady state
+    t_end = t0 + dt
+    if t_first is not None and done > n_first and t_end > t_first:
+        print("[gen_ps] device %d: steady state %.2f scenes/s (%d scenes in the %.2f s after the first batch of %d)"
+              % (device_index, (done - n_first) / (t_end - t_first), done - n_first, t_end - t_first, n_first))
     if os.environ.get("GAPRO_DRIVER_TIMES"):
         print("[gen_ps] main-thread seconds: " + ", ".join("%s %.2f" % kv for kv in spent.items()))
     result = dict(done=done, failed=sorted(failed_names), miou={k: [float(x) for x in v] for k, v in miou.items()},

@@ -486,6 +486,10 @@ class Pipeline:
         self._ws.setdefault(slot, None)
         cur = self._ws[slot]
         if cur is None or cur.numel() < n_doubles:
+            if self._last_fit_done is not None:
+                # a launch that may still be running works in the memory about to be released (the fit kernels run on
+                # library-owned streams the caching allocator knows nothing about)
+                self._last_fit_done.synchronize()
             # 30 % headroom: the need of a batch of 256 scenes varies by ~10 %, and growing means a hipMalloc of
             # 10 .. 20 GB per slot plus its fill behind the running fit kernels -- 2 s on a freshly booted box, inside
             # whatever step first exceeds the old size (bench.py's sporadic 980 ms steps against 760 ms launches)
@@ -810,7 +814,14 @@ class Pipeline:
         d_idx = torch.from_numpy(h_idx).to(devc)
         d_init = torch.from_numpy(np.ascontiguousarray(init_mean, dtype=np.float64)).to(devc) \
             if init_mean is not None else None
-        ws = self._workspace(slot, ws_bytes // 8)
+        # ONE workspace for all pipeline slots while launches are serialised (round 4): launch i + 1 starts on the device
+        # when launch i has ended, nothing on the host reads a workspace (results leave through `out` / `stat`), and every
+        # kernel initialises what it reads -- slots were already reused by other fits every third launch.  A worker's
+        # first batches no longer pay three hipMallocs of ~18 GB (~2 s each: the driver clears VRAM on allocation; a
+        # 1201-scene job is 3.5 s of GPU work), and a 256-scene pipeline holds 14 GB of workspace instead of 42.
+        # Tests that inspect trained parameters (keep_debug) and overlapping launches keep a workspace per slot.
+        ws_slot = "shared" if (self.serialize_fits and not keep_debug and not slot.endswith("retry")) else slot
+        ws = self._workspace(ws_slot, ws_bytes // 8)
         no = max(n_out, 1)
         # per-test-superpoint outputs in one device block: probs f32 | probs_new f32 | mu f32 | var f32 | labels u8
         out = torch.empty(no * 17, dtype=torch.uint8, device=devc)

@@ -39,6 +39,8 @@ def one_pass(data_root, save, devices, batch, raw_cache, extra):
             re.findall(r"(\d+) scenes written, (\d+) skipped/failed, ([\d.]+) s", txt)]
     start = [float(a) for a in re.findall(r"start-up ([\d.]+) s", txt)]
     first = [float(a) for a in re.findall(r"first batch out after ([\d.]+) s", txt)]
+    steady = [(float(a), int(b), float(c)) for a, b, c in
+              re.findall(r"steady state ([\d.]+) scenes/s \((\d+) scenes in the ([\d.]+) s", txt)]
     io = re.findall(r"(\d+) loader threads, (\d+) loader processes, ([^,\n]+) file I/O", txt)
     n = sum(d for d, _, _ in done)
     slow = max((t for _, _, t in done), default=0.0)
@@ -49,6 +51,8 @@ def one_pass(data_root, save, devices, batch, raw_cache, extra):
                per_worker_scenes=[d for d, _, _ in done], per_worker_s=[t for _, _, t in done],
                written_files=sum(len([f for f in os.listdir(d) if f.endswith(".pth")])
                                  for d in (save, save + ".DRY_RUN") if os.path.isdir(d)))
+    if steady:  # all workers' scenes after their first batch / the slowest worker's time after its first batch
+        out["steady_scenes_per_s"] = round(sum(b for _, b, _ in steady) / max(c for _, _, c in steady), 2)
     if io:
         out["loader_threads"], out["loader_processes"], out["file_io"] = int(io[0][0]), int(io[0][1]), io[0][2].strip()
     if r.returncode not in (0, 3):
