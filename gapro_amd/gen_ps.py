@@ -431,6 +431,7 @@ def _save_arrays(save_path, arrays, spp_inv=None):
 
 
 _T_IMPORT = time.time()
+_T0_PERF = [0.0]
 
 
 def _chunks(filenames, args, queue):
@@ -568,7 +569,10 @@ def run_worker(filenames, args, device_index):
         procs = mp.get_context("spawn").Pool(n_procs, initializer=_loader_init)
     pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
     pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest of its batch is written
+    if os.environ.get("GAPRO_DRIVER_TIMES"):
+        pipe.trace = []  # host-side stage timeline of the pipeline (printed at the end)
     dev = pipe.device
+    _T0_PERF[0] = time.perf_counter()
     done = failed = 0
     failed_names = []  # scan names of every scene this worker could not write (exit status 3)
     miou = {}          # --eval_pslabel: scan name -> per-instance IoUs (float32), gen_ps.py:116-124
@@ -721,6 +725,8 @@ def run_worker(filenames, args, device_index):
                     failed_names.append(fn.split("/")[-1][:12])
             if not scenes:
                 continue
+            if pipe.trace is not None:
+                pipe.trace.append((time.perf_counter(), -1, "%d scenes of a batch fetched" % len(scenes)))
             t = time.time()
             jobs = [make_job(s["coords_float"], s["mask_feats"], s["spp"], s["instance_cls"], s["instance_box"],
                              s["instance_box_volume"], s["wall_box"], s["wall_box_volume"],
@@ -818,6 +824,9 @@ def run_worker(filenames, args, device_index):
               % (device_index, (done - n_first) / (t_end - t_first), done - n_first, t_end - t_first, n_first))
     if os.environ.get("GAPRO_DRIVER_TIMES"):
         print("[gen_ps] main-thread seconds: " + ", ".join("%s %.2f" % kv for kv in spent.items()))
+        ids = {}
+        for t, bid, name in (pipe.trace or [])[:60]:
+            print("[gen_ps]   %8.3f s  batch %d  %s" % (t - _T0_PERF[0], ids.setdefault(bid, len(ids)), name))
     result = dict(done=done, failed=sorted(failed_names), miou={k: [float(x) for x in v] for k, v in miou.items()},
                   seconds=dt, startup_seconds=t0 - _T_IMPORT, first_batch_seconds=(t_first - t0) if t_first else 0.0,
                   timeout_retries=int(getattr(pipe, "timeout_retries", 0)))
