@@ -460,7 +460,6 @@ def run_worker_dry(filenames, args, rank):
     label files go to <save_folder>.DRY_RUN, never to --save_folder: nothing here is a pseudo-label."""
     import concurrent.futures as cf
 
-    _loader_init()
     out_folder = osp.normpath(args.save_folder) + ".DRY_RUN"
     os.makedirs(out_folder, exist_ok=True)
     print("[gen_ps] WARNING: --dry_run: NO pseudo-labels are generated; all-zero stand-in outputs go to %s"
@@ -547,7 +546,6 @@ def run_worker(filenames, args, device_index):
 
     n_procs = int(getattr(args, "loader_procs", 0))
     n_workers = max(1, int(getattr(args, "n_workers", 1)))  # GPU workers sharing this host (--devices)
-    _loader_init()  # the loader threads of this process call BLAS concurrently: one thread each
     native = pth_io.native_enabled()
     phys = max(1, (os.cpu_count() or 2) // 2)
     n_threads = int(getattr(args, "loader_threads", -1))
@@ -921,7 +919,20 @@ def main(argv=None):
             mine = shard_scenes(filenames, r, len(devices))
         else:  # "lpt", or "queue" without a claim directory (a worker started by hand)
             mine = shard_scenes_lpt(filenames, r, len(devices))
-        result = run_worker_dry(mine, args, r) if args.dry_run else run_worker(mine, args, devices[r])
+        # the loader threads of this process call BLAS concurrently: one BLAS / torch thread each while the worker runs
+        # (restored afterwards: tests and notebooks call main() in-process)
+        prev_threads = torch.get_num_threads()
+        _loader_init()
+        try:
+            result = run_worker_dry(mine, args, r) if args.dry_run else run_worker(mine, args, devices[r])
+        finally:
+            torch.set_num_threads(prev_threads)
+            while _BLAS_LIMIT:
+                lim = _BLAS_LIMIT.pop()
+                try:
+                    lim.restore_original_limits()
+                except Exception:  # noqa: BLE001 - older threadpoolctl
+                    pass
         if args.worker_rank >= 0 and args.job_dir:  # a child of the farm: the parent prints the summary
             return 3 if result["failed"] else 0
         return finish_run(args, [result])
