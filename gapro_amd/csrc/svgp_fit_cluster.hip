@@ -34,6 +34,7 @@
 
 #include "common.h"
 #include "fit_layout.h"
+#include "epilogue.h"
 
 namespace {
 using namespace gapro_fit;
@@ -377,10 +378,8 @@ __device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only
         mma_block(a0, b0, s0);
       }
     }
-#pragma unroll
-    for (int u = 0; u < TU; ++u)
-#pragma unroll
-      for (int v = 0; v < TU; ++v) epi(i0 + 16 * u, j0 + 16 * v, acc[u][v]);
+    run_epilogue<TU * TU>(epi, [&](int b, int* i, int* j) { *i = i0 + 16 * (b / TU); *j = j0 + 16 * (b % TU); },
+                          [&](int b) -> const d4& { return acc[b / TU][b % TU]; });
   }
 }
 
@@ -1475,27 +1474,52 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
       stamp(11);
     } else {
     col_partials(2, Mp, [=](int r, int cc) { return gmu[r] * AT[(size_t)r * Mp + cc]; });
+    // (two-phase epilogue, epilogue.h: the loads of a tile's four blocks are issued before any of its stores)
+    struct GaPre { double a[4], m[4], gvn, gmn; };
     gemm_tn<TU, false, gd, gd, ORD_ROWS_DESC, true>(mt, mt, false, LST, BM, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = 0; *hi = i0 + TS; },
-                      [=](int i0, int n0, const d4& v) {
+                      two_phase_epi<4>(
+                      [=](int i0, int n0) {
                         const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                         const int n = n0 + lr;
-                        const double gvn = gv[n], gmn = gmu[n];
-                        d4 ga;
+                        GaPre p;
+                        p.gvn = gv[n];
+                        p.gmn = gmu[n];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                           const int i = i0 + lq + 4 * r;
-                          const double a = A[(size_t)i * Mp + n];
-                          ga[r] = 2.0 * gvn * v[r] + vm[i] * gmn - 2.0 * a * gvn;
+                          p.a[r] = A[(size_t)i * Mp + n];
+                          p.m[r] = vm[i];
                         }
+                        return p;
+                      },
+                      [=](int i0, int n0, const d4& v, const GaPre& p) {
+                        d4 ga;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ga[r] = 2.0 * p.gvn * v[r] + p.m[r] * p.gmn - 2.0 * p.a[r] * p.gvn;
                         store_tile(ga, GA, GAT, Mp, i0, n0);
-                      });
+                      }));
     cbar();
     stamp(10);
     // G_LS[i][j] = sum_n A[i][n] 2 g_v[n] B[j][n] (lower) + KL', Adam on L_S in the epilogue (L_S^T through the
     // wave's transpose tile: 128-byte rows)
+    struct LsPre { double l[4], m1[4], m2[4]; };
     gemm_tn<TU, true, gd, gd, ORD_ROWMAJOR, true>(mt, mt, true, AT, BMT, Mp, gv, [=](int, int, int* lo, int* hi) { *lo = 0; *hi = Mp; },
-                     [=](int i0, int j0, const d4& v) {
+                     two_phase_epi<4>(
+                     [=](int i0, int j0) {
+                       const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
+                       const int j = j0 + lr;
+                       LsPre p;
+#pragma unroll
+                       for (int r = 0; r < 4; ++r) {  // unconditional: every (i, j) of a tile lies inside the M_p x M_p slots
+                         const size_t o = (size_t)(i0 + lq + 4 * r) * Mp + j;
+                         p.l[r] = LS[o];
+                         p.m1[r] = MLS[o];
+                         p.m2[r] = VLS[o];
+                       }
+                       return p;
+                     },
+                     [=](int i0, int j0, const d4& v, const LsPre& p) {
                        const int ln = threadIdx.x & 63, lr = ln & 15, lq = ln >> 4;
                        const int j = j0 + lr;
                        d4 newv;
@@ -1505,10 +1529,10 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                          const size_t o = (size_t)i * Mp + j;
                          double lnew = 0.0;
                          if (j <= i && i < M) {
-                           const double l = LS[o];
+                           const double l = p.l[r];
                            const double g = 2.0 * v[r] + (l - (i == j ? 1.0 / l : 0.0)) / Nd;
-                           const double m1 = b1 * MLS[o] + (1.0 - b1) * g;
-                           const double m2 = b2 * VLS[o] + (1.0 - b2) * g * g;
+                           const double m1 = b1 * p.m1[r] + (1.0 - b1) * g;
+                           const double m2 = b2 * p.m2[r] + (1.0 - b2) * g * g;
                            MLS[o] = m1;
                            VLS[o] = m2;
                            lnew = l - step_size * m1 / (sqrt(m2) / bc2s + aeps);
@@ -1517,7 +1541,7 @@ __device__ __noinline__ void fit_body(const gapro_fit_options& opt, const gapro_
                          newv[r] = lnew;
                        }
                        store_tile(newv, (gd*)nullptr, LST, Mp, i0, j0);  // LST[j][i]; zeros above the diagonal
-                     });
+                     }));
     // G_KX = LI^T G_A
     gemm_tn<TU, false, gd, gd, ORD_ROWMAJOR, true>(mt, mt, false, f.mat[B_LI], GA, Mp, nullptr,
                       [=](int i0, int, int* lo, int* hi) { *lo = i0; *hi = Mp; },

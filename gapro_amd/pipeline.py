@@ -430,6 +430,13 @@ class Pipeline:
         stage[:tab_tot].copy_(d_tables, non_blocking=True)
 
     # ------------------------------------------------------------------ stage C
+    def _host_threads(self):
+        if getattr(self, "_host_pool", None) is None:
+            import concurrent.futures as cf
+
+            self._host_pool = cf.ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 8)))
+        return self._host_pool
+
     def _schedule(self, job: SceneJob):
         h = job.host
         h["occ_bits"] = np.ascontiguousarray(h["occ_bits_pin"].numpy().view(np.uint64))
@@ -628,8 +635,14 @@ class Pipeline:
         jobs, _mark = state["jobs"], state["mark"]
         if not jobs:
             return
-        for job in jobs:
-            self._schedule(job)
+        # one host thread per scene (gapro_schedule_build is host C++ behind ctypes: no GIL): 256 scenes took 0.45 s on
+        # the main thread, more than half of what a fit launch of that batch lasts -- the product path's steady state
+        # was bound by this thread, not by the GPU
+        if len(jobs) >= 8:
+            list(self._host_threads().map(self._schedule, jobs))
+        else:
+            for job in jobs:
+                self._schedule(job)
         _mark("C schedule")
         n_fits = sum(j.counts.n_fits for j in jobs)
         n_idx = sum(j.counts.n_fit_idx for j in jobs)
@@ -691,7 +704,13 @@ class Pipeline:
         d_tables = torch.empty(tot_s * 20, dtype=torch.uint8, device=devc)
         tab_np = tables.numpy()
         views, off = [], 0
+        offs = []
         for job in jobs:
+            offs.append(off)
+            off += 20 * job.n_spps
+
+        def merge_one(arg):
+            job, off = arg
             S = job.n_spps
             sem_spp = tab_np[off:off + 4 * S].view(np.int32)
             inst_spp = tab_np[off + 4 * S:off + 8 * S].view(np.int32)
@@ -709,9 +728,15 @@ class Pipeline:
                                           _ptr(mu_spp), _ptr(var_spp))
             if rc != 0:
                 raise _lib.GaproError(rc, "gapro_schedule_merge")
-            views.append(off)
             job.host.update(sem_spp=sem_spp.copy(), inst_spp=inst_spp.copy(), prob_spp=prob_spp.copy())
-            off += 20 * S
+
+        # the ordered merge of a scene is host C++ on that scene's own slices: one host thread per scene
+        if len(jobs) >= 8:
+            list(self._host_threads().map(merge_one, zip(jobs, offs)))
+        else:
+            for arg in zip(jobs, offs):
+                merge_one(arg)
+        views = offs
         d_tables.copy_(tables[:tot_s * 20], non_blocking=True)  # one H2D copy for the whole batch
         self._pin_events[state["slot"] + "labels"] = torch.cuda.current_stream(devc).record_event()
         tasks, d_tasks = state["tasks"], state["d_tasks"]

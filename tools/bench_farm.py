@@ -32,9 +32,12 @@ def one_pass(data_root, save, devices, batch, raw_cache, extra):
     cmd = [sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", data_root, "--batch_scenes",
            str(batch), "--devices", devices, "--raw_cache", raw_cache or "none"] + extra
     t = time.time()
-    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, GAPRO_DRIVER_TIMES="1"))
     wall = time.time() - t
     txt = r.stdout
+    for ln in txt.splitlines():  # the workers' own summary and stage timeline, for whoever reads the bench's stderr
+        if ln.startswith("[gen_ps]"):
+            print("    " + ln, file=sys.stderr)
     done = [(int(a), int(b), float(c)) for a, b, c in
             re.findall(r"(\d+) scenes written, (\d+) skipped/failed, ([\d.]+) s", txt)]
     start = [float(a) for a in re.findall(r"start-up ([\d.]+) s", txt)]

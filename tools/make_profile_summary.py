@@ -54,6 +54,18 @@ def main():
     shutil.copy(os.path.join(src, "pmc_summary.txt"), os.path.join(out, a.tag + "_pmc_summary.txt"))
     with open(os.path.join(src, "bench.json")) as fh:
         bench = json.loads(fh.read().strip().splitlines()[-1])
+    # round 4: per-phase tables with matrix-pipe busy shares, per-kernel CU-time split of one launch, per-phase profiles
+    # of the cluster / strip / small kernels, per-size rates, the host ceiling
+    for name, dst in (("phase_tables.md", "_phase_tables.md"), ("fit_timeline.txt", "_fit_timeline.txt"),
+                      ("cluster_prof.log", "_cluster_phases.txt"), ("strip_prof.log", "_strip_phases.txt"),
+                      ("fit_sizes.log", "_fit_sizes.txt"), ("host_ceiling.json", "_host_ceiling.json"),
+                      ("wgloop_peak.txt", "_wgloop_peak.txt")):
+        pth = os.path.join(src, name)
+        if os.path.exists(pth):
+            with open(pth) as fh:
+                txt = "".join(ln for ln in fh if "amdgpu.ids" not in ln)
+            with open(os.path.join(out, a.tag + dst), "w") as fh:
+                fh.write(txt)
 
     # calibration: known byte counts -> bytes per counter unit
     n_bytes = 8 * (1 << 26)
