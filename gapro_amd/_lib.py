@@ -137,6 +137,8 @@ SIGNATURES = {
     "gapro_pth_write": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(PthArray), C.POINTER(_P), C.c_int32]),
     "gapro_pth_last_error": (C.c_char_p, []),
     "gapro_scene_default_feats": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "gapro_scene_instance_boxes": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P,
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 
 # libgapro_hip_debug.so (include/gapro_hip_debug.h): measurement / self-test entry points, loaded on request only

@@ -74,7 +74,7 @@ import torch
 
 from . import pth_io
 from .dist_utils import ClaimQueue, pending_scenes, shard_scenes, shard_scenes_lpt
-from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device
+from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device, getInstanceInfo_native
 from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
 
@@ -156,7 +156,9 @@ def read_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None, sc
 
 def add_instance_info(sc, device=None):
     """gen_ps.py:71-77: the GT boxes of a scene read by read_scene; None when the scene has no instance."""
-    if device is not None:  # the driver: one pass on the device (gapro_instance_info)
+    if device == "host":  # the driver's loader threads: one native pass on the host arrays, before the upload
+        info = getInstanceInfo_native(sc["coords_float"], sc["instance_label"], sc["semantic_label"])
+    elif device is not None:  # one pass on the device (gapro_instance_info)
         info = getInstanceInfo_device(sc["coords_float"], sc["instance_label"], sc["semantic_label"], device=device)
     else:  # no device given: the reference's host function, mirrored
         info = getInstanceInfo(sc["coords_float"], instance_label=sc["instance_label"],
@@ -195,6 +197,7 @@ def write_label_file(save_path, tup):
 
 
 _SHM_KEYS = ("coords_float", "mask_feats", "spp", "semantic_label", "instance_label", "wall_box", "wall_box_volume")
+_INFO_KEYS = ("instance_cls", "instance_box", "instance_box_volume")
 
 
 _RAW_MAGIC = b"GAPRORAW1\n"
@@ -312,6 +315,9 @@ def _read_scene_shm(filename, data_root, use_deepfeat=False, deepfeat_folder=Non
         except OSError as e:  # a full disk must not lose the scene
             print("[gen_ps] raw cache not written for %s: %r" % (filename, e), file=sys.stderr)
     arrs = {k: np.ascontiguousarray(np.asarray(sc[k])) for k in _SHM_KEYS}
+    # GT boxes here, on the host arrays (see read_upload in run_worker); None = a scene without instances
+    info = add_instance_info(dict(sc, coords_float=arrs["coords_float"]), "host")
+    info = {k: info[k] for k in _INFO_KEYS} if info is not None else None
     layout, off = [], 0
     for k in _SHM_KEYS:
         a = arrs[k]
@@ -320,13 +326,13 @@ def _read_scene_shm(filename, data_root, use_deepfeat=False, deepfeat_folder=Non
     try:
         shm = shared_memory.SharedMemory(create=True, size=max(off, 64))
     except OSError:
-        return dict(scan_name=sc["scan_name"], shm=None, arrays=arrs)
+        return dict(scan_name=sc["scan_name"], shm=None, arrays=arrs, info=info)
     try:
         try:  # reserve the pages now: a full /dev/shm must be an error here, not a SIGBUS in the copy below
             os.posix_fallocate(shm._fd, 0, max(off, 64))
         except OSError:  # no room (container with a small /dev/shm): this scene travels through the pipe instead
             shm.unlink()
-            return dict(scan_name=sc["scan_name"], shm=None, arrays=arrs)
+            return dict(scan_name=sc["scan_name"], shm=None, arrays=arrs, info=info)
         for (k, _, _, o) in layout:
             a = arrs[k]
             if a.nbytes:
@@ -334,7 +340,7 @@ def _read_scene_shm(filename, data_root, use_deepfeat=False, deepfeat_folder=Non
         name = shm.name
     finally:
         shm.close()
-    return dict(scan_name=sc["scan_name"], shm=name, layout=layout)
+    return dict(scan_name=sc["scan_name"], shm=name, layout=layout, info=info)
 
 
 def _scene_from_shm(msg, device, stager=None):
@@ -616,7 +622,11 @@ def run_worker(filenames, args, device_index):
         touches the buffers it is given, so it may run beside the generator)."""
         msg = r.get(600)  # a loader that died (e.g. killed for memory) must not hang the run: the scene is skipped
         with torch.cuda.stream(side_stream()):
-            return with_job(add_instance_info(_scene_from_shm(msg, dev, stager()), dev))
+            dev_sc = _scene_from_shm(msg, dev, stager())  # (always: the shared-memory block must be released)
+            if msg.get("info") is None:
+                return None
+            dev_sc.update(msg["info"])
+            return with_job(dev_sc)
 
     def export(path, job, o, ready):
         """Pool thread: device -> host on the thread's stream; pickling and the file write go to a loader process."""
@@ -629,13 +639,16 @@ def run_worker(filenames, args, device_index):
 
     def upload_cached(fn, sc):
         """Pool thread: a raw-cache hit -- the arrays are memory-mapped files, uploaded straight from the page cache."""
+        info = add_instance_info(dict(sc), "host")  # on the mapped host arrays, before the upload (see read_upload)
+        if info is None:
+            return None
         with torch.cuda.stream(side_stream()):
-            dev_sc = dict(scan_name=sc["scan_name"])
+            dev_sc = dict(scan_name=sc["scan_name"], **{k: info[k] for k in _INFO_KEYS})
             for k in _SHM_KEYS:
                 if k not in _DEVICE_DTYPES:
                     dev_sc[k] = np.array(sc[k]) if len(sc[k]) else []
             dev_sc.update(stager().upload({k: sc[k] for k in _SHM_KEYS if k in _DEVICE_DTYPES}, _DEVICE_DTYPES))
-            return with_job(add_instance_info(dev_sc, dev))
+            return with_job(dev_sc)
 
     def scratch():
         if not hasattr(tls, "scratch"):
@@ -655,13 +668,18 @@ def run_worker(filenames, args, device_index):
         """Pool thread, no loader process: native read (GIL released while the payloads are transcoded), host
         preprocessing in NumPy, upload through the thread's pinned stager, GT boxes on the device."""
         sc = read_and_cache(fn)
+        # GT boxes on the HOST arrays, before the upload (gapro_scene_instance_boxes, one native pass): the device form
+        # is a kernel, and a short kernel is not dispatched beside a running fit launch -- every loader thread waited for
+        # the launch to drain once per scene (115 scenes/s of loading beside a launch against 850 without)
+        if add_instance_info(sc, "host") is None:
+            return None
         with torch.cuda.stream(side_stream()):
-            dev_sc = dict(scan_name=sc["scan_name"])
+            dev_sc = dict(scan_name=sc["scan_name"], **{k: sc[k] for k in _INFO_KEYS})
             for k in _SHM_KEYS:
                 if k not in _DEVICE_DTYPES:
                     dev_sc[k] = sc[k]
             dev_sc.update(stager().upload({k: sc[k] for k in _DEVICE_DTYPES}, _DEVICE_DTYPES))
-            return with_job(add_instance_info(dev_sc, dev))
+            return with_job(dev_sc)
 
     def export_native(path, job, o, ready):
         """Pool thread, no loader process: device -> host on the thread's stream, then the native writer."""

@@ -122,6 +122,40 @@ def getInstanceInfo(xyz, instance_label, semantic_label, dataset_name="scannetv2
     return instance_num, instance_cls, instance_box, instance_box_volume, corners_label
 
 
+def getInstanceInfo_native(xyz, instance_label, semantic_label, dataset_name="scannetv2"):
+    """getInstanceInfo (gen_ps_utils.py:195-239) in one native host pass (gapro_scene_instance_boxes), without the
+    corner labels: (instance_num, instance_cls f64[B], instance_box f64[B,6], instance_box_volume f64[B], None), or
+    None without instances -- the same values as getInstanceInfo.  What the gen_ps driver's loader threads use."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    xyz = np.ascontiguousarray(np.asarray(xyz, dtype=np.float64))
+    inst = np.ascontiguousarray(np.asarray(instance_label, dtype=np.float64)).reshape(-1)
+    sem = np.ascontiguousarray(np.asarray(semantic_label, dtype=np.float64)).reshape(-1)
+    n = int(xyz.shape[0])
+    cap = 256
+    nb, inum = C.c_int32(0), C.c_int32(0)
+    while True:
+        box = np.empty((cap, 6), dtype=np.float64)
+        cls = np.empty(cap, dtype=np.float64)
+        vol = np.empty(cap, dtype=np.float64)
+        rc = lib.gapro_scene_instance_boxes(xyz.ctypes.data, inst.ctypes.data, sem.ctypes.data, n,
+                                            1 if dataset_name == "scannetv2" else 0, cap, box.ctypes.data,
+                                            cls.ctypes.data, vol.ctypes.data, C.byref(nb), C.byref(inum))
+        if rc == 0:
+            break
+        if inum.value > cap:
+            cap = int(inum.value)
+            continue
+        raise _lib.GaproError(rc, "gapro_scene_instance_boxes")
+    if nb.value == 0:
+        return None
+    k = int(nb.value)
+    return int(inum.value), cls[:k].copy(), box[:k].copy(), vol[:k].copy(), None
+
+
 def getInstanceInfo_device(xyz, instance_label, semantic_label, dataset_name="scannetv2", device=None,
                            return_corners=False):
     """getInstanceInfo (gen_ps_utils.py:195-239) on the GPU: one pass over the points behind

@@ -437,6 +437,14 @@ const char* gapro_pth_last_error(void);
 /* The reference's default features (gen_ps.py:55: np.concatenate([xyz, rgb], -1) of the UN-aligned coordinates, uploaded
  * as float32 at :84): h_feats[n][6] = float32 of [xyz | rgb], one pass on the host. */
 int gapro_scene_default_feats(const double* h_xyz, const double* h_rgb, int64_t n_points, float* h_feats);
+/* getInstanceInfo (gen_ps_utils.py:195-239) on the HOST in one pass, without the corner labels: boxes
+ * h_box[n_boxes][6] = (min xyz, max xyz), class h_cls (ScanNet: -2 unless -100), volume h_vol, indexed by the rank among
+ * the non-empty instance ids; *instance_num = max id + 1.  cap = rows the output arrays hold; GAPRO_ERR_BAD_ARG with
+ * *instance_num set when it is too small.  For loader threads: the device form (gapro_instance_info) is a kernel and
+ * would wait for a running fit launch to drain. */
+int gapro_scene_instance_boxes(const double* h_xyz, const double* h_inst, const double* h_sem, int64_t n_points,
+                               int32_t scannet, int32_t cap, double* h_box, double* h_cls, double* h_vol,
+                               int32_t* n_boxes, int32_t* instance_num);
 
 /* ------------------------------------------------------------------------------------------
  * Inspection (tests): where a fit's trained parameters live in its workspace.  The measurement / self-test entry points

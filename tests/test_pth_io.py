@@ -235,3 +235,31 @@ def test_abi_status_codes():
     assert lib.gapro_pth_open(b"/nonexistent/file.pth", C.byref(h)) == _lib.GAPRO_ERR_IO
     assert b"nonexistent" in lib.gapro_pth_last_error()
     assert lib.gapro_pth_open(None, C.byref(h)) == -1
+
+
+def test_native_host_passes_equal_the_numpy_mirrors():
+    """The loader threads' native passes: default features (gen_ps.py:55) and GT instance boxes (gen_ps_utils.py:195-239,
+    without the corner labels) -- bit-equal to the NumPy mirrors that are themselves pinned on the reference's golden
+    outputs (tests/test_host_golden.py), including id gaps, -100 labels and a scene without instances."""
+    from gapro_amd.gen_ps_utils import getInstanceInfo, getInstanceInfo_native
+    from gapro_amd.synth import make_scene
+
+    for seed in range(4):
+        sc = make_scene(seed=seed, n_points=9000 + 3000 * seed, n_objects=4 + 3 * seed, with_walls_json=False,
+                        obj_patch=25, plane_patch=80)
+        xyz = sc.aligned_xyz()
+        inst = sc.inst.copy()
+        if seed == 2:  # gaps in the id range and unlabelled points
+            inst[inst == 1] = -100.0
+            inst[inst == 3] = inst.max() + 4
+        a, b = getInstanceInfo(xyz, inst, sc.sem), getInstanceInfo_native(xyz, inst, sc.sem)
+        assert a[0] == b[0]
+        for x, y in zip(a[1:4], b[1:4]):
+            _same(np.asarray(x), np.asarray(y))
+        feats = np.empty((len(xyz), 6), np.float32)
+        assert _lib.load().gapro_scene_default_feats(np.ascontiguousarray(sc.xyz).ctypes.data,
+                                                     np.ascontiguousarray(sc.rgb).ctypes.data, len(xyz),
+                                                     feats.ctypes.data) == 0
+        _same(feats, np.concatenate([sc.xyz, sc.rgb], -1).astype(np.float32))
+    assert getInstanceInfo_native(xyz, np.full(len(xyz), -100.0), sc.sem) is None
+    assert getInstanceInfo(xyz, np.full(len(xyz), -100.0), sc.sem) is None
