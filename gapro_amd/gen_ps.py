@@ -575,6 +575,21 @@ def run_worker(filenames, args, device_index):
     pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest of its batch is written
     if os.environ.get("GAPRO_DRIVER_TIMES"):
         pipe.trace = []  # host-side stage timeline of the pipeline (printed at the end)
+    # The fit workspace is allocated NOW, by a helper thread, while the first scenes are read: its size is only known
+    # after the first batch has been scheduled (~2 s in), and the hipMalloc + clear of ~25 GB then takes another
+    # 1.2 .. 2.4 s before the first launch.  Estimate: ~330 bytes of workspace per point of a batch of ScanNet-like
+    # scenes (14 GB per 256 scenes of the train-split mix) with the usual 30 % headroom, ~91 bytes of scene file per
+    # point; a batch that needs more grows it as before, a smaller one just leaves memory unused (288 GB per GPU).
+    try:
+        sizes = sorted((os.path.getsize(fn) for fn in filenames), reverse=True)
+        nb = max(1, min(int(args.batch_scenes), len(sizes)))
+        # the claim queue hands out the largest files first; a static list comes in name order (a mix: mean + margin)
+        batch_bytes = sum(sizes[:nb]) if getattr(args, "claim_dir", None) else 1.2 * nb * sum(sizes) / max(1, len(sizes))
+        est = int(batch_bytes / 91.0 * 330.0 * 1.3)
+        if not os.environ.get("GAPRO_NO_PREALLOC") and est > (1 << 28):
+            threading.Thread(target=pipe.prealloc_workspace, args=(min(est, 64 << 30),), daemon=True).start()
+    except OSError:
+        pass
     dev = pipe.device
     _T0_PERF[0] = time.perf_counter()
     done = failed = 0

@@ -252,6 +252,9 @@ class Pipeline:
         self.workspace_headroom = 1.3  # growth factor of the fit workspaces over the need that triggers it
         self.serialize_fits = not os.environ.get("GAPRO_OVERLAP_FITS")  # fit launches never overlap (see fit_launch)
         self._last_fit_done = None
+        import threading
+
+        self._ws_lock = threading.Lock()
         # optional HIP-event timing of the fit launches (bench.py): list of (start_event, end_event, flops)
         self.profile_fit = False
         self.fit_events = []
@@ -486,10 +489,21 @@ class Pipeline:
             torch.cuda.current_stream(self.device).wait_stream(st)
         return outs
 
-    def _workspace(self, slot: str, n_doubles: int) -> torch.Tensor:
+    def prealloc_workspace(self, n_bytes: int, slot: str = "shared"):
+        """Allocate the fit workspace ahead of its first use (a driver calls this from a helper thread while the first
+        scenes are still being read: the hipMalloc + clear of ~25 GB takes 1.2 .. 2.4 s, a third of what a worker needs
+        for the whole ScanNet train split).  A later need beyond this size grows it as usual."""
+        with torch.cuda.device(self.device):
+            self._workspace(slot, max(1, int(n_bytes) // 8), headroom=1.0)
+
+    def _workspace(self, slot: str, n_doubles: int, headroom: Optional[float] = None) -> torch.Tensor:
         """Grow-only fit workspace per pipeline slot.  Every registered slot grows together and new memory is
         touched once here: a slot first used inside a timed region would otherwise pay the allocation and the
         first-touch mapping of several GB inside its fit kernel."""
+        with self._ws_lock:
+            return self._workspace_locked(slot, n_doubles, headroom)
+
+    def _workspace_locked(self, slot: str, n_doubles: int, headroom: Optional[float]) -> torch.Tensor:
         self._ws.setdefault(slot, None)
         cur = self._ws[slot]
         if cur is None or cur.numel() < n_doubles:
@@ -500,7 +514,7 @@ class Pipeline:
             # 30 % headroom: the need of a batch of 256 scenes varies by ~10 %, and growing means a hipMalloc of
             # 10 .. 20 GB per slot plus its fill behind the running fit kernels -- 2 s on a freshly booted box, inside
             # whatever step first exceeds the old size (bench.py's sporadic 980 ms steps against 760 ms launches)
-            size = int(n_doubles * self.workspace_headroom) + 1024
+            size = int(n_doubles * (self.workspace_headroom if headroom is None else headroom)) + 1024
             if self.trace is not None:
                 import time as _time
                 self.trace.append((_time.perf_counter(), 0, "workspace grows to %.1f GB per slot" % (size * 8 / 1e9)))
