@@ -183,8 +183,18 @@ def load() -> C.CDLL:
         raise ImportError("libgapro_hip.so not built: run gapro_amd/csrc/build.sh (or __graft_entry__.build()); "
                           "expected at " + LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    default = os.path.join(_HERE, "libgapro_hip.so")
+    host_only = None  # A/B tools point LIB_PATH at a variant build that may predate a host-side helper
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        try:
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        except AttributeError:
+            if os.path.abspath(LIB_PATH) == os.path.abspath(default) or not name.startswith(("gapro_pth_", "gapro_scene_")):
+                raise
+            if host_only is None:
+                host_only = C.CDLL(default)
+            fn = getattr(host_only, name)
+            setattr(lib, name, fn)
         fn.restype = res
         fn.argtypes = args
     _lib = lib

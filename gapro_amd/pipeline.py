@@ -913,6 +913,9 @@ class Pipeline:
                                              float(each[~(is_strip | is_small | is_clus)].sum()),
                                              float(each[is_small].sum()), m, float(each[is_clus].sum())))
             self.last_fit_m = m
+        # the next launch is ordered behind THIS launch's kernels only, not behind the copies below
+        kern_done = torch.cuda.Event()
+        kern_done.record(torch.cuda.current_stream(devc))
         # results travel to pinned host memory on the same stream; nobody waits here
         h_out = self._pinned(slot + "fit_out", no * 17)
         h_stat = self._pinned(slot + "fit_stat", n_fits * 12)
@@ -920,7 +923,8 @@ class Pipeline:
         h_stat[:n_fits * 12].copy_(stat, non_blocking=True)
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(devc))
-        self._last_fit_done = done
+        # (GAPRO_SERIALIZE_ON_COPIES=1, A/B only: order the next launch behind the result copies too, as round 3 did)
+        self._last_fit_done = done if os.environ.get("GAPRO_SERIALIZE_ON_COPIES") else kern_done
         keep = (d_descs, d_idx, d_init, ws, out, stat, feats_spp)  # alive until the launch has finished
         return dict(done=done, h_out=h_out, h_stat=h_stat, no=no, n_fits=n_fits, ws_bytes=ws_bytes, keep=keep,
                     ws=ws if keep_debug else None, descs=descs if keep_debug else None)
