@@ -24,7 +24,9 @@ from gapro_amd import _lib  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--fit-m", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "stream_fit_m.npy"))
+    ap.add_argument("--fit-m", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "train_split_fit_m.npy"),
+                    help="M of every fit of one launch (bench.py GAPRO_DUMP_FIT_M); default: the last step of the train-split "
+                         "workload (round 4); data/stream_fit_m.npy is round 2's 64-seed step")
     ap.add_argument("--t", type=int, default=32)
     ap.add_argument("--d", type=int, default=6)
     ap.add_argument("--bins", type=int, default=24)
