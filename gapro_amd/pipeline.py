@@ -518,10 +518,15 @@ class Pipeline:
             if self.trace is not None:
                 import time as _time
                 self.trace.append((_time.perf_counter(), 0, "workspace grows to %.1f GB per slot" % (size * 8 / 1e9)))
-            for k in list(self._ws):
+            for k in list(self._ws):  # the requested slot, and every slot that is in use (they grow together)
+                if k != slot and self._ws[k] is None:
+                    continue
                 if self._ws[k] is None or self._ws[k].numel() < size:
                     self._ws[k] = None  # release before growing
                     self._ws[k] = torch.zeros(size, dtype=torch.float64, device=self.device)
+            # the fill runs on the allocating thread's stream; the fit kernels that use this memory run on other
+            # streams (another pipeline slot's, the library's): nobody may get the tensor before the fill is done
+            torch.cuda.current_stream(self.device).synchronize()
         return self._ws[slot][:n_doubles]
 
     def run_stream(self, batches):
