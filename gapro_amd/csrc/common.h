@@ -32,6 +32,11 @@ struct gapro_ctx {
   size_t cl_stage_bytes = 0;
   size_t cl_ctl_fits = 0;
   unsigned cl_parity = 0;
+  // fit-ticket counters (gapro_svgp_fit_batch: the workgroups of a fit kernel take their fits in the order in which they
+  // start): kTicketSets sets of kTicketsPerSet counters, one set per launch in turn, zeroed on the launch's stream
+  static constexpr unsigned kTicketSets = 16, kTicketsPerSet = 8;
+  unsigned* d_tickets = nullptr;
+  unsigned ticket_seq = 0;
   // single-scene partition calls stage their one-task batch through this ring (pinned host + device mirror);
   // a slot is reused after kTaskRing further calls, long after the stream has consumed it
   gapro_scene_task* h_task_ring = nullptr;

@@ -47,6 +47,10 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
     gapro_ctx_destroy(ctx);
     return GAPRO_ERR_OOM;
   }
+  if (hipMalloc((void**)&ctx->d_tickets, gapro_ctx::kTicketSets * gapro_ctx::kTicketsPerSet * sizeof(unsigned)) != hipSuccess) {
+    gapro_ctx_destroy(ctx);
+    return GAPRO_ERR_OOM;
+  }
   // [2] carries the small fits: lowest priority, so that they fill what the larger fits leave (longest first)
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
@@ -72,6 +76,7 @@ void gapro_ctx_destroy(gapro_ctx* ctx) {
   if (ctx->h_cl_stage) (void)hipHostFree(ctx->h_cl_stage);
   if (ctx->d_cl_stage) (void)hipFree(ctx->d_cl_stage);
   if (ctx->d_cl_ctl) (void)hipFree(ctx->d_cl_ctl);
+  if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
   delete ctx;
 }
 

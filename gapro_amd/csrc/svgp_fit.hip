@@ -215,6 +215,20 @@ __device__ inline T* uni_ptr(T* p) {
   return (T*)(((unsigned long long)hi << 32) | lo);
 }
 
+// Which fit of its kernel's list this workgroup runs.  Workgroup b of a launch runs on XCD b % 8 whatever that XCD is
+// busy with, so with fit = blockIdx.x an XCD's share of a kernel's fits is fixed before the launch starts, and the XCDs
+// ended a launch up to 55 ms apart (tools/fit_timeline.py) even with their shares balanced by cost.  With a ticket
+// counter (one per kernel of a launch, zeroed by gapro_svgp_fit_batch) a workgroup takes the next fit of the
+// longest-first list when it STARTS; the launcher over-subscribes the grid, the workgroups left without a fit exit at
+// once, and an XCD that frees up earlier simply starts more of them.  A fit's result does not depend on who runs it.
+__device__ inline int claim_fit(unsigned* ticket) {
+  if (!ticket) return blockIdx.x;
+  __shared__ int s_claim;
+  if (threadIdx.x == 0) s_claim = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  return __builtin_amdgcn_readfirstlane(s_claim);
+}
+
 __device__ inline double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -2247,9 +2261,10 @@ __global__ __launch_bounds__(NT, WPS) void k_svgp_fit(int n_fits, int D, const f
                                                  double* __restrict__ ws, float* __restrict__ o_probs,
                                                  float* __restrict__ o_probs_new, unsigned char* __restrict__ o_labels,
                                                  float* __restrict__ o_mu, float* __restrict__ o_var,
-                                                 int* __restrict__ o_status, double* __restrict__ o_loss) {
+                                                 int* __restrict__ o_status, double* __restrict__ o_loss,
+                                                 unsigned* ticket) {
   extern __shared__ double dyn_lds[];
-  const int fit = blockIdx.x;
+  const int fit = claim_fit(ticket);
   if (fit >= n_fits) return;
   const gapro_fit_desc desc = descs[fit];
   const int Mp = gapro_pad_m(desc.m1 + desc.m2, D);
@@ -3066,9 +3081,9 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_strip(int n_fits, int D, con
                                                         float* __restrict__ o_probs_new,
                                                         unsigned char* __restrict__ o_labels, float* __restrict__ o_mu,
                                                         float* __restrict__ o_var, int* __restrict__ o_status,
-                                                        double* __restrict__ o_loss) {
+                                                        double* __restrict__ o_loss, unsigned* ticket) {
   extern __shared__ double dyn_lds[];
-  const int fit = blockIdx.x;
+  const int fit = claim_fit(ticket);
   if (fit >= n_fits) return;
   const gapro_fit_desc desc = descs[fit];
   const int Mp = gapro_pad_m(desc.m1 + desc.m2, D);
@@ -3147,8 +3162,8 @@ __global__ void k_mfma_selftest(const double* __restrict__ P, const double* __re
 // M_p <= 64 has at most 8 tiles per strip product: with 8 waves each wave has one tile and the CU idles through every
 // memory round trip of the fit it hosts.  Here a fit gets 4 waves (256 VGPRs each, no tighter register budget than
 // the 512-thread kernel) and a CU hosts TWO fits.
-extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_dim, size_t lds_bytes,
-                                            const float* d_feats_spp, const int32_t* d_idx,
+extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int n_wg, unsigned* d_ticket, int feat_dim,
+                                            size_t lds_bytes, const float* d_feats_spp, const int32_t* d_idx,
                                             const gapro_fit_desc* d_descs, const double* d_init_mean,
                                             const gapro_fit_options* opt, double* d_workspace, float* d_probs,
                                             float* d_probs_new, uint8_t* d_labels, float* d_mu, float* d_var,
@@ -3157,9 +3172,9 @@ extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_d
   if (lds_bytes > 48 * 1024 &&
       hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
     return GAPRO_ERR_HIP;
-  hipLaunchKernelGGL(kern, dim3(n_fits), dim3(NT), lds_bytes, (hipStream_t)stream, n_fits, feat_dim, d_feats_spp, d_idx,
+  hipLaunchKernelGGL(kern, dim3(n_wg), dim3(NT), lds_bytes, (hipStream_t)stream, n_fits, feat_dim, d_feats_spp, d_idx,
                      d_descs, d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status,
-                     d_fit_loss);
+                     d_fit_loss, d_ticket);
   return hipGetLastError() == hipSuccess ? GAPRO_OK : GAPRO_ERR_HIP;
 }
 // LDS bytes of a small fit in THIS translation unit's layout (NT-dependent reduction scratch)
@@ -3240,8 +3255,8 @@ int gapro_debug_stream(gapro_ctx* ctx, void* stream_, int64_t n, const double* d
 
 }  // extern "C"
 #else
-extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int feat_dim, size_t lds_bytes,
-                                            const float* d_feats_spp, const int32_t* d_idx,
+extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int n_wg, unsigned* d_ticket, int feat_dim,
+                                            size_t lds_bytes, const float* d_feats_spp, const int32_t* d_idx,
                                             const gapro_fit_desc* d_descs, const double* d_init_mean,
                                             const gapro_fit_options* opt, double* d_workspace, float* d_probs,
                                             float* d_probs_new, uint8_t* d_labels, float* d_mu, float* d_var,
@@ -3384,7 +3399,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   auto serpentine = [](std::vector<gapro_fit_desc>& v, size_t lo, size_t hi) {
     for (size_t g0 = lo + 8; g0 + 8 <= hi; g0 += 16) std::reverse(v.begin() + g0, v.begin() + g0 + 8);
   };
-  if (!(route_flags & 512)) {
+  // Default since round 4: ticket counters (claim_fit) -- the fits stay in plain longest-first order and are taken by
+  // the workgroups in the order in which they start; debug bit 18 restores the static mapping fit = blockIdx.x
+  const bool tickets = !(route_flags & 262144) && ctx->d_tickets;
+  if (!(route_flags & 512) && !tickets) {
     serpentine(strip, 0, strip.size());
     serpentine(small, 0, small.size());
     serpentine(staged, 0, nbig);
@@ -3415,6 +3433,15 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       ctx->cl_ctl_fits = 2 * clus.size();
     }
   }
+  // ticket counters of this launch: [0] staged beyond kKminMaxMp, [1] staged "big", [2] the other staged fits, [3] strip,
+  // [4] small.  The sets rotate, so that a set is zeroed again only kTicketSets launches later
+  unsigned* tk = nullptr;
+  if (tickets) {
+    tk = ctx->d_tickets + (size_t)(ctx->ticket_seq++ % gapro_ctx::kTicketSets) * gapro_ctx::kTicketsPerSet;
+    GAPRO_HIP_CHECK(ctx, hipMemsetAsync(tk, 0, gapro_ctx::kTicketsPerSet * sizeof(unsigned), stream));
+  }
+  // grid of a ticketed kernel: twice its fits, so that an XCD (a fixed eighth of the grid) can run up to twice its share
+  auto grid_of = [&](size_t n) { return (int)(tickets ? 2 * n : n); };
   GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_descs, all.data(), all.size() * sizeof(gapro_fit_desc), hipMemcpyHostToDevice,
                                       stream));
   GAPRO_HIP_CHECK(ctx, hipStreamSynchronize(stream));  // `all` is pageable host memory that dies with this call
@@ -3476,27 +3503,27 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     // staged fits go out as two launches side by side: those whose LDS fits a CU twice in the `<4>` build (128 VGPRs,
     // two workgroups per CU: 17 % more fits/s at M <= 256 than one per CU), the larger ones in the `<2>` build (the
     // whole register file, no spills).  Either part with fewer fits than CUs takes `<2>` as well.
-    auto launch = [&](hipStream_t st, size_t first, size_t count, long long lds, bool kmaj) -> int {
+    auto launch = [&](hipStream_t st, size_t first, size_t count, long long lds, bool kmaj, int tslot) -> int {
       const bool one_per_cu = (int)count <= ctx->n_cu || lds > kTwice || (route_flags & 64);
       auto kern = kmaj ? k_svgp_fit<2, false> : one_per_cu ? k_svgp_fit<2, true> : k_svgp_fit<kWavesPerSimd, true>;
       if (lds > 48 * 1024)
         GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kern, dim3((int)count), dim3(NT), (size_t)lds, st, (int)count, (int)feat_dim, d_feats_spp, d_idx,
-                         d_descs + large.size() + first, d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels,
-                         d_mu, d_var, d_fit_status, d_fit_loss);
+      hipLaunchKernelGGL(kern, dim3(grid_of(count)), dim3(NT), (size_t)lds, st, (int)count, (int)feat_dim, d_feats_spp,
+                         d_idx, d_descs + large.size() + first, d_init_mean, *opt, d_workspace, d_probs, d_probs_new,
+                         d_labels, d_mu, d_var, d_fit_status, d_fit_loss, tk ? tk + tslot : nullptr);
       return GAPRO_OK;
     };
     if (nkmaj > 0) {
-      const int rc = launch(s_staged, 0, nkmaj, lds_kmaj, true);
+      const int rc = launch(s_staged, 0, nkmaj, lds_kmaj, true, 0);
       if (rc != GAPRO_OK) return rc;
     }
     if (nbig > nkmaj) {  // M_p <= kKminMaxMp with an LDS need beyond kTwice (wide features): behind the former
-      const int rc = launch(s_staged, nkmaj, nbig - nkmaj, lds_big, false);
+      const int rc = launch(s_staged, nkmaj, nbig - nkmaj, lds_big, false, 1);
       if (rc != GAPRO_OK) return rc;
     }
     if (nbig < staged.size()) {
       hipStream_t st = nbig > 0 ? s_staged2 : s_staged;
-      const int rc = launch(st, nbig, staged.size() - nbig, lds_rest, false);
+      const int rc = launch(st, nbig, staged.size() - nbig, lds_rest, false, 2);
       if (rc != GAPRO_OK) return rc;
       if (st != s_staged) {  // everything staged is finished once s_staged has passed this point
         GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[4], st));
@@ -3511,14 +3538,16 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       GAPRO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)max_lds_strip));
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[2], s_strip));
-    hipLaunchKernelGGL(kern, dim3((int)strip.size()), dim3(NT), (size_t)max_lds_strip, s_strip, (int)strip.size(),
+    hipLaunchKernelGGL(kern, dim3(grid_of(strip.size())), dim3(NT), (size_t)max_lds_strip, s_strip, (int)strip.size(),
                        (int)feat_dim, d_feats_spp, d_idx, d_descs + large.size() + staged.size(), d_init_mean, *opt,
-                       d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+                       d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss,
+                       tk ? tk + 3 : nullptr);
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[3], s_strip));
   }
   if (!small.empty()) {
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[4], s_small));
-    const int rc = gapro_launch_fit_strip_small(s_small, (int)small.size(), feat_dim, (size_t)max_lds_small, d_feats_spp,
+    const int rc = gapro_launch_fit_strip_small(s_small, (int)small.size(), grid_of(small.size()), tk ? tk + 4 : nullptr,
+                                                feat_dim, (size_t)max_lds_small, d_feats_spp,
                                                 d_idx, d_descs + large.size() + staged.size() + strip.size(),
                                                 d_init_mean, opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu,
                                                 d_var, d_fit_status, d_fit_loss);
