@@ -34,7 +34,7 @@ struct gapro_ctx {
   unsigned cl_parity = 0;
   // fit-ticket counters (gapro_svgp_fit_batch: the workgroups of a fit kernel take their fits in the order in which they
   // start): kTicketSets sets of kTicketsPerSet counters, one set per launch in turn, zeroed on the launch's stream
-  static constexpr unsigned kTicketSets = 16, kTicketsPerSet = 8;
+  static constexpr unsigned kTicketSets = 64, kTicketsPerSet = 8;
   unsigned* d_tickets = nullptr;
   unsigned ticket_seq = 0;
   // single-scene partition calls stage their one-task batch through this ring (pinned host + device mirror);
@@ -50,13 +50,20 @@ struct gapro_fit_timing {
   hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/end: staged,
                                                                                                 // strip, small, cluster
   bool used[4] = {false, false, false, false};
+  unsigned* tickets = nullptr;  // the launch's counter set (gapro_ctx::d_tickets): [5..7] = cluster kernel diagnostics
 };
 
 // svgp_fit_cluster.hip
 int gapro_cluster_size(int Mp, bool all);
 size_t gapro_cluster_stage_bytes(int n_fits);
-int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, const int* fit_mp, const int* fit_g,
-                             int feat_dim, void* h_stage, void* d_stage, unsigned* d_ctl, const float* d_feats_spp,
+// two steps: the block table is built and uploaded (and the barrier counters zeroed) on `prep_stream`, which the caller
+// synchronises before it launches the kernel on `stream` -- so that the kernel is the first thing its stream has to do
+// (*out_blocks: grid size; *out_members: workgroups that run a fit, the others are padding and exit at once);
+int gapro_prepare_fit_cluster(hipStream_t prep_stream, int n, const int* fit_index, const int* fit_mp, const int* fit_g,
+                              void* h_stage, void* d_stage, unsigned* d_ctl, int* out_blocks, int* out_members);
+// d_info (may be null): [0] member workgroups started, [1] clusters whose members do NOT share an XCD, [2] clusters
+int gapro_launch_fit_cluster(hipStream_t stream, int n_blocks, int feat_dim, void* d_stage, unsigned* d_ctl,
+                             unsigned* d_info, const float* d_feats_spp,
                              const int* d_idx, const gapro_fit_desc* d_descs, const double* d_init_mean,
                              const gapro_fit_options& opt, double* d_workspace, float* d_probs, float* d_probs_new,
                              unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss);

@@ -3440,6 +3440,32 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     tk = ctx->d_tickets + (size_t)(ctx->ticket_seq++ % gapro_ctx::kTicketSets) * gapro_ctx::kTicketsPerSet;
     GAPRO_HIP_CHECK(ctx, hipMemsetAsync(tk, 0, gapro_ctx::kTicketsPerSet * sizeof(unsigned), stream));
   }
+  // cluster kernel: block table and barrier counters go up on `stream` too, so that after the synchronisation below the
+  // kernel is the first thing its stream has to do
+  int cl_blocks = 0, cl_members = 0;
+  char* cl_d_half = nullptr;
+  unsigned* cl_ctl_half = nullptr;
+  if (!clus.empty()) {
+    std::vector<int> fi(clus.size()), fmp(clus.size()), fg(clus.size());
+    for (size_t k = 0; k < clus.size(); ++k) {
+      fi[k] = (int)(clus_base + k);
+      fmp[k] = gapro_pad_m(clus[k].m1 + clus[k].m2, feat_dim);
+      fg[k] = gapro_cluster_size(fmp[k], true);
+    }
+    // the block table is built in one half of the context's pinned buffer, the halves alternating per launch: the
+    // copy of launch i - 2 has long been consumed (callers collect a launch before they issue the one after next),
+    // so the host never waits for the previous cluster kernel here
+    // (the device copies alternate the same way, so that two launches issued from different streams -- debug bit 1
+    // puts the kernels on the caller's stream -- never share a block table or a barrier counter)
+    const size_t par = ctx->cl_parity & 1;
+    char* h_half = (char*)ctx->h_cl_stage + par * (ctx->cl_stage_bytes / 2);
+    cl_d_half = (char*)ctx->d_cl_stage + par * (ctx->cl_stage_bytes / 2);
+    cl_ctl_half = ctx->d_cl_ctl + par * ctx->cl_ctl_fits * 32;
+    ctx->cl_parity++;
+    const int rc = gapro_prepare_fit_cluster(stream, (int)clus.size(), fi.data(), fmp.data(), fg.data(), h_half, cl_d_half,
+                                             cl_ctl_half, &cl_blocks, &cl_members);
+    if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: cluster block table upload failed");
+  }
   // grid of a ticketed kernel: twice its fits, so that an XCD (a fixed eighth of the grid) can run up to twice its share
   auto grid_of = [&](size_t n) { return (int)(tickets ? 2 * n : n); };
   GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(d_descs, all.data(), all.size() * sizeof(gapro_fit_desc), hipMemcpyHostToDevice,
@@ -3463,33 +3489,20 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   gapro_fit_timing* tm = ctx->armed_timing;
   ctx->armed_timing = nullptr;
   if (tm) {
+    tm->tickets = tk;
     tm->used[0] = !large.empty() || !staged.empty();
     tm->used[1] = !strip.empty();
     tm->used[2] = !small.empty();
     tm->used[3] = !clus.empty();
   }
   if (!clus.empty()) {  // first: the largest fits of the launch, each over several CUs
-    std::vector<int> fi(clus.size()), fmp(clus.size()), fg(clus.size());
-    for (size_t k = 0; k < clus.size(); ++k) {
-      fi[k] = (int)(clus_base + k);
-      fmp[k] = gapro_pad_m(clus[k].m1 + clus[k].m2, feat_dim);
-      fg[k] = gapro_cluster_size(fmp[k], true);
-    }
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[6], s_clus));
-    // the block table is built in one half of the context's pinned buffer, the halves alternating per launch: the
-    // copy of launch i - 2 has long been consumed (callers collect a launch before they issue the one after next),
-    // so the host never waits for the previous cluster kernel here
-    // (the device copies alternate the same way, so that two launches issued from different streams -- debug bit 1
-    // puts the kernels on the caller's stream -- never share a block table or a barrier counter)
-    const size_t par = ctx->cl_parity & 1;
-    char* h_half = (char*)ctx->h_cl_stage + par * (ctx->cl_stage_bytes / 2);
-    char* d_half = (char*)ctx->d_cl_stage + par * (ctx->cl_stage_bytes / 2);
-    unsigned* ctl_half = ctx->d_cl_ctl + par * ctx->cl_ctl_fits * 32;
-    ctx->cl_parity++;
-    const int rc = gapro_launch_fit_cluster(s_clus, (int)clus.size(), fi.data(), fmp.data(), fg.data(), feat_dim,
-                                            h_half, d_half, ctl_half, d_feats_spp, d_idx, d_descs,
-                                            d_init_mean, *opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var,
-                                            d_fit_status, d_fit_loss);
+    // (Round 4, tried: holding the other kernels back until the cluster's members are resident.  They are within 1 .. 15
+    // us anyway, and every cluster sits on one XCD (gapro_fit_timing_cluster_info); what makes the same cluster kernel
+    // take 240 ms in one run of a step and 500 ms in the next is what runs beside it -- LABNOTES R4.4.)
+    const int rc = gapro_launch_fit_cluster(s_clus, cl_blocks, feat_dim, cl_d_half, cl_ctl_half, tk ? tk + 5 : nullptr,
+                                            d_feats_spp, d_idx, d_descs, d_init_mean, *opt, d_workspace, d_probs,
+                                            d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
     if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: cluster kernel launch failed");
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[7], s_clus));
   }
@@ -3634,6 +3647,19 @@ int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5) {
       }
     out_ms5[2] = hi - lo;
   }
+  return GAPRO_OK;
+}
+
+int gapro_fit_timing_cluster_info(gapro_ctx* ctx, gapro_fit_timing* t, int32_t* out3) {
+  if (!ctx || !t || !out3) return GAPRO_ERR_BAD_ARG;
+  out3[0] = out3[1] = out3[2] = 0;
+  if (!t->tickets || !t->used[3]) return GAPRO_OK;
+  GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[7]));
+  unsigned v[3] = {0, 0, 0};
+  GAPRO_HIP_CHECK(ctx, hipMemcpy(v, t->tickets + 5, sizeof(v), hipMemcpyDeviceToHost));
+  out3[0] = (int32_t)v[2];
+  out3[1] = (int32_t)v[1];
+  out3[2] = (int32_t)v[0];
   return GAPRO_OK;
 }
 

@@ -1720,9 +1720,11 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
                                                           float* __restrict__ o_probs, float* __restrict__ o_probs_new,
                                                           unsigned char* __restrict__ o_labels, float* __restrict__ o_mu,
                                                           float* __restrict__ o_var, int* __restrict__ o_status,
-                                                          double* __restrict__ o_loss, unsigned long long bar_ticks) {
+                                                          double* __restrict__ o_loss, unsigned long long bar_ticks,
+                                                          unsigned* info) {
   const ClBlock cb = blocks[blockIdx.x];
   if (cb.fit < 0) return;
+  if (info && threadIdx.x == 0) atomicAdd(info, 1u);  // diagnostics (gapro_fit_timing_cluster_info)
   // test bit 15 of gapro_fit_options.reserved: the last member of every cluster never arrives (as if it had not been
   // given a CU) -- the others must time out and report GAPRO_ERR_TIMEOUT instead of hanging
   if ((opt.reserved & 32768) && cb.G > 1 && cb.g == cb.G - 1) return;
@@ -1777,6 +1779,10 @@ __global__ __launch_bounds__(NT, 2) void k_svgp_fit_cluster(const ClBlock* __res
   for (long long i = ct; i < lay.total; i += CT) base[i] = 0.0;
   cbar();
   if (!(opt.reserved & 256)) detect_same_xcd();  // debug bit 8: always the full barrier
+  if (info && threadIdx.x == 0 && cb.g == 0 && cb.G > 1) {  // diagnostics (gapro_fit_timing_cluster_info)
+    atomicAdd(info + 2, 1u);
+    if (!sh.same_xcd) atomicAdd(info + 1, 1u);
+  }
   const int* my_idx = idx + desc.idx_offset;
   for (int e = ct; e < M * D; e += CT) {
     const int i = e / D, d = e - i * D;
@@ -1858,11 +1864,9 @@ int gapro_cluster_size(int Mp, bool all) {
 // table (>= bytes returned by gapro_cluster_stage_bytes), d_ctl: >= 128 bytes per fit, zeroed here.
 size_t gapro_cluster_stage_bytes(int n_fits) { return (size_t)n_fits * kClMaxG * sizeof(ClBlock) + 8 * kClMaxG * sizeof(ClBlock); }
 
-int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, const int* fit_mp, const int* fit_g,
-                             int feat_dim, void* h_stage, void* d_stage, unsigned* d_ctl, const float* d_feats_spp,
-                             const int* d_idx, const gapro_fit_desc* d_descs, const double* d_init_mean,
-                             const gapro_fit_options& opt, double* d_workspace, float* d_probs, float* d_probs_new,
-                             unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss) {
+int gapro_prepare_fit_cluster(hipStream_t stream, int n, const int* fit_index, const int* fit_mp, const int* fit_g,
+                              void* h_stage, void* d_stage, unsigned* d_ctl, int* out_blocks, int* out_members) {
+  *out_blocks = *out_members = 0;
   if (n <= 0) return GAPRO_OK;
   // windows of 8 clusters (one per XCD label): block base + 8 j + x is member j of the window's x-th cluster
   std::vector<int> order(n);
@@ -1903,9 +1907,23 @@ int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, co
             b.ctl = slot_ctl[x];
           }
         }
+        if (b.fit >= 0) ++*out_members;
         hb[nb++] = b;
       }
   }
+  *out_blocks = nb;
+  if (hipMemsetAsync(d_ctl, 0, (size_t)n * 128, stream) != hipSuccess) return GAPRO_ERR_HIP;
+  if (hipMemcpyAsync(d_stage, h_stage, (size_t)nb * sizeof(ClBlock), hipMemcpyHostToDevice, stream) != hipSuccess)
+    return GAPRO_ERR_HIP;
+  return GAPRO_OK;
+}
+
+int gapro_launch_fit_cluster(hipStream_t stream, int nb, int feat_dim, void* d_stage, unsigned* d_ctl, unsigned* d_info,
+                             const float* d_feats_spp, const int* d_idx, const gapro_fit_desc* d_descs,
+                             const double* d_init_mean, const gapro_fit_options& opt, double* d_workspace, float* d_probs,
+                             float* d_probs_new, unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status,
+                             double* d_fit_loss) {
+  if (nb <= 0) return GAPRO_OK;
   // longest wait at one cluster barrier before the cluster gives up (cbar): 5 s unless the environment says otherwise
   static long long timeout_ms = -1;
   if (timeout_ms < 0) {
@@ -1913,11 +1931,8 @@ int gapro_launch_fit_cluster(hipStream_t stream, int n, const int* fit_index, co
     timeout_ms = e && atoll(e) >= 0 ? atoll(e) : 5000;
   }
   const unsigned long long bar_ticks = (unsigned long long)timeout_ms * 100000ull;  // wall_clock64: 100 MHz
-  if (hipMemsetAsync(d_ctl, 0, (size_t)n * 128, stream) != hipSuccess) return GAPRO_ERR_HIP;
-  if (hipMemcpyAsync(d_stage, h_stage, (size_t)nb * sizeof(ClBlock), hipMemcpyHostToDevice, stream) != hipSuccess)
-    return GAPRO_ERR_HIP;
   hipLaunchKernelGGL(k_svgp_fit_cluster, dim3(nb), dim3(NT), 0, stream, (const ClBlock*)d_stage, feat_dim, d_feats_spp,
                      d_idx, d_descs, d_init_mean, opt, d_workspace, d_ctl, d_probs, d_probs_new, d_labels, d_mu, d_var,
-                     d_fit_status, d_fit_loss, bar_ticks);
+                     d_fit_status, d_fit_loss, bar_ticks, d_info);
   return hipGetLastError() == hipSuccess ? GAPRO_OK : GAPRO_ERR_HIP;
 }

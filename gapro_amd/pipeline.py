@@ -182,6 +182,13 @@ class FitTiming:
             self.ms = (float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]))
         return self.ms
 
+    def cluster_info(self):
+        """(clusters of more than one workgroup, those whose members did not share an XCD, member workgroups) of this
+        launch's cluster kernel; read before 64 further launches."""
+        out = (C.c_int32 * 3)()
+        self.ctx.check(self.ctx.lib.gapro_fit_timing_cluster_info(self.ctx.handle, self.handle, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def offsets(self, ref):
         """(first kernel start, last kernel end) of this launch in ms after the start of launch `ref`."""
         out = (C.c_float * 2)()

@@ -396,6 +396,10 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out);
 void gapro_fit_timing_destroy(gapro_fit_timing* t);
 int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t);
 int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5);
+/* Diagnostics of the cluster kernel of the timed launch (blocks until it has finished; read it before 64 further
+ * launches of this context): out3 = {clusters of more than one workgroup, those whose members did NOT all run on one
+ * XCD (their barriers carry the L2 write-back), member workgroups}. */
+int gapro_fit_timing_cluster_info(gapro_ctx* ctx, gapro_fit_timing* t, int32_t* out3);
 /* Where launch t lies on the time axis of launch ref: out_ms2 = {first kernel start, last kernel end} of t in ms after
  * the start event of ref's first kernel.  Consecutive launches of a pipeline overlap (the next one is enqueued while
  * the tail of the previous one runs, and a start event fires when its stream reaches it, not when the kernel gets
