@@ -704,6 +704,43 @@ def test_cluster_staging_buffer_grows_with_the_launch():
         np.testing.assert_array_equal(a, b)
 
 
+def test_fits_taken_by_ticket_equal_the_static_block_mapping():
+    """Round 4: a workgroup takes the next fit of its kernel's longest-first list when it starts (claim_fit; the grids
+    are over-subscribed, spare workgroups exit) instead of running fit blockIdx.x (gapro_fit_options.reserved bit 18).
+    Who runs a fit must not matter: a launch with more fits than the GPU holds at once, on every single-workgroup
+    kernel, comes out with the same bits either way -- and every fit is run exactly once (a fit claimed twice would
+    race on its workspace, a fit never claimed keeps the status the launcher cannot have written)."""
+    import torch
+    from gapro_amd import gen_ps_utils
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.synth import make_gp_problem
+
+    parts, probs, base = [], [], 0
+    shapes = [(7, 9, 5), (20, 28, 33), (31, 33, 64), (40, 39, 7), (45, 50, 90), (70, 74, 12), (60, 52, 31),
+              (100, 60, 30), (130, 126, 20), (150, 160, 9)]
+    for i, (m1, m2, t) in enumerate(shapes):
+        f, b1, b2, it = make_gp_problem(1300 + i, m1, m2, t, 6)
+        parts.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(parts)
+    many = probs * 90  # 900 fits: small 360, strip 360, staged 180 -- several rounds of workgroups per kernel
+    pipe = gen_ps_utils._pipeline(torch.device("cuda:0"), 6)
+    old = int(pipe.opt.reserved)
+    try:
+        pipe.opt.reserved = old | 262144
+        ref, st_ref = fit_gp_spp_batch(feats, many, training_iter=6, return_status=True)
+    finally:
+        pipe.opt.reserved = old
+    got, st = fit_gp_spp_batch(feats, many, training_iter=6, return_status=True)
+    assert (st_ref == 0).all() and (st == 0).all()
+    singles = [fit_gp_spp_batch(feats, [p], training_iter=6)[0] for p in probs]
+    for k in range(len(many)):
+        for x, y, z in zip(ref[k], got[k], singles[k % len(probs)]):
+            np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(y, z)
+
+
 def test_workgroup_tiled_products_are_bit_identical_to_the_per_wave_products():
     """Round 3: the staged kernel's products through an LDS ring shared by the workgroup (default at
     M_p = 256, 384; everywhere with gapro_fit_options.reserved bit 13; nowhere with bit 17) accumulate every 16 x 16
