@@ -708,8 +708,8 @@ def test_fits_taken_by_ticket_equal_the_static_block_mapping():
     """Round 4: a workgroup takes the next fit of its kernel's longest-first list when it starts (claim_fit; the grids
     are over-subscribed, spare workgroups exit) instead of running fit blockIdx.x (gapro_fit_options.reserved bit 18).
     Who runs a fit must not matter: a launch with more fits than the GPU holds at once, on every single-workgroup
-    kernel, comes out with the same bits either way -- and every fit is run exactly once (a fit claimed twice would
-    race on its workspace, a fit never claimed keeps the status the launcher cannot have written)."""
+    kernel, comes out with the same bits either way, and with the bits of the same fit launched alone (a fit claimed
+    twice would race on its workspace, a fit never claimed would leave its outputs unwritten)."""
     import torch
     from gapro_amd import gen_ps_utils
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
