@@ -37,6 +37,7 @@ def main():
                     "library (libgapro_hip.so) only the launch times by HIP events are printed (A/B runs)")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--no-raise", action="store_true", help="timing experiments that break the arithmetic")
+    ap.add_argument("--dump", default="", help="save the per-fit rows (M, route, start, end, HW_ID, G, start ms, end ms) as .npy")
     args = ap.parse_args()
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), args.lib)
     prof = "prof" in args.lib
@@ -158,6 +159,21 @@ def main():
         tot += cur_e - cur_s
         busy.append(tot / span)
     busy = np.array(busy)
+    # open intervals on one CU at once: a CU holds at most two of these workgroups, so more means that workgroups were
+    # suspended between their start and end stamps (the hardware scheduler's time slicing of queues of one priority)
+    over = []
+    for c in np.unique(cu):
+        k = cu == c
+        ev = sorted([(s_, 1) for s_ in st[k]] + [(e_, -1) for e_ in en[k]], key=lambda t: (t[0], t[1]))
+        cur = mx = 0
+        for _, d_ in ev:
+            cur += d_
+            mx = max(mx, cur)
+        over.append(mx)
+    over = np.array(over)
+    print("  most workgroups open at once on one CU: max %d, CUs with more than 2: %d of %d" % (over.max(), int((over > 2).sum()), len(over)))
+    if args.dump:
+        np.save(args.dump, np.column_stack([a, st, en]))
     print("  CU busy share (union of its workgroups' intervals, cluster members other than leaders not seen): "
           "mean %.2f  min %.2f  p10 %.2f" % (busy.mean(), busy.min(), np.percentile(busy, 10)))
 
