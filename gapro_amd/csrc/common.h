@@ -25,6 +25,7 @@ struct gapro_ctx {
   static constexpr int kFitStreams = 5;
   hipStream_t fit_stream[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_join[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_gate = nullptr;  // end of the cluster kernel: the two-per-CU staged launch starts behind it
   // cluster kernel: block table staging (pinned host + device) and the clusters' barrier counters, grown on demand
   void* h_cl_stage = nullptr;
   void* d_cl_stage = nullptr;

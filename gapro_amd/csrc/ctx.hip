@@ -62,6 +62,10 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
       gapro_ctx_destroy(ctx);
       return GAPRO_ERR_HIP;
     }
+  if (hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming) != hipSuccess) {
+    gapro_ctx_destroy(ctx);
+    return GAPRO_ERR_HIP;
+  }
   *out = ctx;
   return GAPRO_OK;
 }
@@ -75,6 +79,7 @@ void gapro_ctx_destroy(gapro_ctx* ctx) {
     if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     if (ctx->fit_stream[k]) (void)hipStreamDestroy(ctx->fit_stream[k]);
   }
+  if (ctx->ev_gate) (void)hipEventDestroy(ctx->ev_gate);
   if (ctx->h_cl_stage) (void)hipHostFree(ctx->h_cl_stage);
   if (ctx->d_cl_stage) (void)hipFree(ctx->d_cl_stage);
   if (ctx->d_cl_ctl) (void)hipFree(ctx->d_cl_ctl);

@@ -3495,6 +3495,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     tm->used[2] = !small.empty();
     tm->used[3] = !clus.empty();
   }
+  bool gate_staged2 = false;
   if (!clus.empty()) {  // first: the largest fits of the launch, each over several CUs
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[6], s_clus));
     // (Round 4, tried: holding the other kernels back until the cluster's members are resident.  They are within 1 .. 15
@@ -3505,6 +3506,16 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                                             d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
     if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: cluster kernel launch failed");
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[7], s_clus));
+    // gate of the two-per-CU staged launch (below): policy 2 = always behind the cluster kernel (default), 1 = only when
+    // the cluster's members fit the GPU at once, 0 = never (GAPRO_STAGED_GATE; debug bit 19 = never)
+    static int gate_policy = -1;
+    if (gate_policy < 0) {
+      const char* e = getenv("GAPRO_STAGED_GATE");
+      gate_policy = e ? atoi(e) : 2;
+    }
+    gate_staged2 = own && !(route_flags & 524288) &&
+                   (gate_policy == 2 || (gate_policy == 1 && cl_members <= ctx->n_cu));
+    if (gate_staged2) GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_gate, s_clus));
   }
   if (tm && tm->used[0]) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[0], s_staged));
   if (!large.empty())
@@ -3536,6 +3547,15 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     }
     if (nbig < staged.size()) {
       hipStream_t st = nbig > 0 ? s_staged2 : s_staged;
+      // The two-per-CU staged fits are the launch's memory-bound class (3.8 FLOP/B: with the chip to themselves they
+      // sit on the HBM roof), the cluster fits its latency-bound one (a chain of cluster barriers and small products
+      // per Adam step).  Side by side from the start, the same cluster kernel took 230 .. 270 ms or 500 .. 800 ms
+      // depending on which kernels the runtime happened to put on one hardware queue (LABNOTES R4.4); so the order is
+      // explicit: this launch starts when the cluster kernel has ended -- small and strip fits, light on memory, take
+      // the CUs beside the clusters meanwhile.  Same box, 2 x 8 steps: 361 .. 372 scenes/s with 4 or 8 hardware queues
+      // (GPU_MAX_HW_QUEUES), the cluster kernel at its undisturbed time in every step; without the gate 368 / 372 with
+      // the default 4 queues (the lucky mapping) and 351 .. 362 with 8.
+      if (gate_staged2) GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_gate, 0));
       const int rc = launch(st, nbig, staged.size() - nbig, lds_rest, false, 2);
       if (rc != GAPRO_OK) return rc;
       if (st != s_staged) {  // everything staged is finished once s_staged has passed this point
@@ -3558,6 +3578,13 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[3], s_strip));
   }
   if (!small.empty()) {
+    // the small fits start behind the cluster kernel as well (GAPRO_SMALL_GATE=0: at once): beside the clusters run
+    // the whole-CU strip fits and the one-per-CU staged fits, and every CU half the two-per-CU staged fits leave later
+    // goes to a small fit, light on memory, instead of a second memory-bound one -- 367.8 / 367.4 / 362.6 scenes/s
+    // against 364.0 / 363.2 / 356.1, alternating on one box
+    static int gate_small = -1;
+    if (gate_small < 0) gate_small = getenv("GAPRO_SMALL_GATE") ? atoi(getenv("GAPRO_SMALL_GATE")) : 1;
+    if (gate_small && gate_staged2) GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(s_small, ctx->ev_gate, 0));
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[4], s_small));
     const int rc = gapro_launch_fit_strip_small(s_small, (int)small.size(), grid_of(small.size()), tk ? tk + 4 : nullptr,
                                                 feat_dim, (size_t)max_lds_small, d_feats_spp,

@@ -332,7 +332,8 @@ typedef struct {
                               * 16384 = with 8192: in the two-per-CU build only, 131072 = never (round 2's products),
                               * 32768 = TEST: the last member of every cluster never arrives (cluster barrier timeout),
                               * 262144 = workgroup b of a fit kernel runs fit b of its list (default: the workgroups
-                              * take the fits in the order in which they start, claim_fit in csrc/svgp_fit.hip)
+                              * take the fits in the order in which they start, claim_fit in csrc/svgp_fit.hip),
+                              * 524288 = the two-per-CU staged launch is not held back behind the cluster kernel
                               * -- A/B switches of tools/bench_fit.py / fit_timeline.py */
   int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive
                               *      pivot is repeated on K + psd_jitter 10^i I, i < psd_retries (psd_safe_cholesky,

@@ -45,7 +45,11 @@ def main():
     from gapro_amd.pipeline import Pipeline
     from gapro_amd.synth import make_gp_problem
 
-    ms = np.load(args.fit_m).astype(np.int64)
+    if ".npz:" in args.fit_m:  # bench.py's per-step dump (GAPRO_DUMP_FIT_M): file.npz:step3
+        fn, key = args.fit_m.rsplit(":", 1)
+        ms = np.load(fn)[key].astype(np.int64)
+    else:
+        ms = np.load(args.fit_m).astype(np.int64)
     ms = ms[(ms >= args.min_m) & (ms <= args.max_m)]
     rng = np.random.default_rng(0)
     rng.shuffle(ms)
