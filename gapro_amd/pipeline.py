@@ -534,6 +534,9 @@ class Pipeline:
             # the fill runs on the allocating thread's stream; the fit kernels that use this memory run on other
             # streams (another pipeline slot's, the library's): nobody may get the tensor before the fill is done
             torch.cuda.current_stream(self.device).synchronize()
+            if self.trace is not None:
+                import time as _time
+                self.trace.append((_time.perf_counter(), 0, "workspace ready"))
         return self._ws[slot][:n_doubles]
 
     def run_stream(self, batches):
