@@ -127,6 +127,7 @@ SIGNATURES = {
     "gapro_fit_timing_destroy": (None, [_P]),
     "gapro_fit_timing_arm": (C.c_int, [_P, _P]),
     "gapro_fit_timing_read": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
+    "gapro_fit_timing_read_wave": (C.c_int, [_P, _P, C.POINTER(C.c_float)]),
     "gapro_fit_timing_offsets": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
     "gapro_fit_timing_cluster_info": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     "gapro_pth_open": (C.c_int, [C.c_char_p, C.POINTER(_P)]),

@@ -19,12 +19,13 @@ struct gapro_ctx {
   int n_cu = 0;
   std::string last_error;
   gapro_scene_header* h_header_pinned = nullptr;  // pinned staging for the blocking prepare call
-  // The fit kernels run on five library-owned streams ([0] staged / generic kernel, [1] strip kernel, [2] the
+  // The fit kernels run on eight library-owned streams ([0] staged / generic kernel, [1] strip kernel, [2] the
   // small-fit strip kernel, [3] the cluster kernel: large fits spread over several CUs, [4] the staged fits whose LDS
-  // fits a CU twice, when the launch also has larger ones), so that they share the GPU.
-  static constexpr int kFitStreams = 5;
-  hipStream_t fit_stream[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_join[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // fits a CU twice, when the launch also has larger ones, [5..7] the wave-per-fit kernels for M_p = 48, 32, 16), so
+  // that they share the GPU.
+  static constexpr int kFitStreams = 8;
+  hipStream_t fit_stream[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_join[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_gate = nullptr;  // end of the cluster kernel: the two-per-CU staged launch starts behind it
   // cluster kernel: block table staging (pinned host + device) and the clusters' barrier counters, grown on demand
   void* h_cl_stage = nullptr;
@@ -35,7 +36,7 @@ struct gapro_ctx {
   unsigned cl_parity = 0;
   // fit-ticket counters (gapro_svgp_fit_batch: the workgroups of a fit kernel take their fits in the order in which they
   // start): kTicketSets sets of kTicketsPerSet counters, one set per launch in turn, zeroed on the launch's stream
-  static constexpr unsigned kTicketSets = 64, kTicketsPerSet = 8;
+  static constexpr unsigned kTicketSets = 64, kTicketsPerSet = 16;
   unsigned* d_tickets = nullptr;
   unsigned ticket_seq = 0;
   // single-scene partition calls stage their one-task batch through this ring (pinned host + device mirror);
@@ -48,9 +49,10 @@ struct gapro_ctx {
 
 // HIP events around the kernels of one fit launch, recorded on the streams the kernels run on.
 struct gapro_fit_timing {
-  hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // start/end: staged,
-                                                                                                // strip, small, cluster
-  bool used[4] = {false, false, false, false};
+  static constexpr int kKernels = 5;  // staged, strip, small, cluster, wave-per-fit
+  hipEvent_t ev[2 * kKernels] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr};  // start / end of each
+  bool used[kKernels] = {false, false, false, false, false};
   unsigned* tickets = nullptr;  // the launch's counter set (gapro_ctx::d_tickets): [5..7] = cluster kernel diagnostics
 };
 
@@ -68,6 +70,16 @@ int gapro_launch_fit_cluster(hipStream_t stream, int n_blocks, int feat_dim, voi
                              const int* d_idx, const gapro_fit_desc* d_descs, const double* d_init_mean,
                              const gapro_fit_options& opt, double* d_workspace, float* d_probs, float* d_probs_new,
                              unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status, double* d_fit_loss);
+
+// svgp_fit_wave.hip: one wave per fit (M_p <= 48 at feat_dim 6)
+int gapro_fit_wave_max_mp(int feat_dim);            // largest padded size it takes at this feature width (0: none)
+size_t gapro_fit_wave_lds_bytes(int nb, int feat_dim);
+int gapro_fit_wave_per_cu(int nb, int feat_dim);    // fits (waves) per CU of the instantiation for M_p = 16 nb
+int gapro_launch_fit_wave(hipStream_t stream, int nb, int n_fits, int n_wg, unsigned* d_ticket, int feat_dim,
+                          const float* d_feats_spp, const int* d_idx, const gapro_fit_desc* d_descs,
+                          const double* d_init_mean, const gapro_fit_options& opt, double* d_workspace, float* d_probs,
+                          float* d_probs_new, unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status,
+                          double* d_fit_loss);
 
 // Padded size of a fit's M x M matrices: MFMA tiles are 16 wide, so M is rounded up to a multiple of 16 (everything
 // scales with M_p^2 M: rounding M = 80 to 96 instead of 80 costs 1.4x the work).  The staged kernel's 32 x 32 wave tiles

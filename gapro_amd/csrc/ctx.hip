@@ -8,17 +8,17 @@ extern "C" {
 
 int gapro_version(void) { return GAPRO_VERSION; }
 
-// stream priorities of the fit kernels; GAPRO_FIT_PRIO="a,b,c,d,e" (0 = greatest, 1 = middle, 2 = least) overrides
+// stream priorities of the fit kernels; GAPRO_FIT_PRIO="a,b,c,d,e[,f,g,h]" (0 = greatest, 1 = middle, 2 = least) overrides
 static int fit_prio(int k, int least, int greatest) {
   // (rounds 2-3: {0, 0, 2, 0, 0}, the small fits last.  With the fits taken by ticket -- claim_fit, svgp_fit.hip -- one
   // level for all is +2.4 %: small fits beside the cluster kernel load the memory system less than staged ones)
-  static int lvl[gapro_ctx::kFitStreams] = {0, 0, 0, 0, 0};
+  static int lvl[gapro_ctx::kFitStreams] = {0, 0, 0, 0, 0, 0, 0, 0};
   static bool init = false;
   if (!init) {
     init = true;
     if (const char* e = getenv("GAPRO_FIT_PRIO")) {
-      int v[gapro_ctx::kFitStreams];
-      if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
+      int v[gapro_ctx::kFitStreams] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]) >= 5)
         for (int i = 0; i < gapro_ctx::kFitStreams; ++i) lvl[i] = v[i];
     }
   }
@@ -53,7 +53,7 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
     gapro_ctx_destroy(ctx);
     return GAPRO_ERR_OOM;
   }
-  // one priority level for all five since round 4 (fit_prio)
+  // one priority level for all since round 4 (fit_prio)
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   for (int k = 0; k < gapro_ctx::kFitStreams; ++k)

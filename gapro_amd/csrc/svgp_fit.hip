@@ -3265,10 +3265,13 @@ extern "C" long long gapro_fit_strip_small_lds_bytes(int m, int feat_dim);
 
 // 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel, 3 = strip-streaming kernel of the small-fit
 // translation unit (M_p <= 64: 256 threads per fit, two fits per CU), 4 = cluster kernel (one fit over several
-// workgroups).  flags: gapro_fit_options.reserved debug bits (bit 0: never the strip kernels, bit 2: no small-fit
-// kernel, bit 3: no cluster kernel, bit 4: the cluster kernel for every fit it can take, M_p >= 64 and M_p % 32 == 0).
+// workgroups), 5 = the wave-per-fit kernel (svgp_fit_wave.hip: M_p <= 48 at feat_dim 6).  flags:
+// gapro_fit_options.reserved debug bits (bit 0: never the strip kernels, bit 2: no small-fit kernel, bit 3: no cluster
+// kernel, bit 4: the cluster kernel for every fit it can take, M_p >= 64 and M_p % 32 == 0, bit 20: no wave kernel).
 constexpr int kSmallFitMp = 64;
+constexpr int kNoWaveFlag = 1 << 20;
 static int fit_route(int m, int feat_dim, int flags) {
+  if (!(flags & kNoWaveFlag) && gapro_pad_m(m, feat_dim) <= gapro_fit_wave_max_mp(feat_dim)) return 5;
   // large fits: spread over several CUs (svgp_fit_cluster.hip); debug bit 3 keeps them on one workgroup
   if (!(flags & 8) && feat_dim <= 32 && gapro_cluster_size(gapro_pad_m(m, feat_dim), (flags & 16) != 0) > 0) return 4;
   if (!(flags & 1) && strip_ok(m, feat_dim)) {
@@ -3324,7 +3327,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // Routing (gapro_fit_route): strip-streaming kernel, LDS-staged kernel, generic kernel (working set beyond
   // LDS).  Every group is sorted longest processing time first (cost ~ M^3): workgroups are dispatched in
   // block order, so the expensive fits start first and the tail of a launch stays short.
-  std::vector<gapro_fit_desc> strip, small, staged, large, clus;
+  std::vector<gapro_fit_desc> strip, small, staged, large, clus, wave[3];  // wave[nb - 1]: M_p = 16 nb
   strip.reserve(n_fits);
   small.reserve(n_fits);
   long long need = 0, max_lds = 0, max_lds_strip = 0, max_lds_small = 0;
@@ -3348,6 +3351,8 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       max_lds = std::max(max_lds, staged_lds_bytes(m, feat_dim));
     } else if (route == 4) {
       clus.push_back(d);
+    } else if (route == 5) {
+      wave[gapro_pad_m(m, feat_dim) / 16 - 1].push_back(d);
     } else {
       large.push_back(d);
       // beyond the cluster kernel's cap (kClusterMaxMp: its merge inverse keeps one LDS record per pair of panels) a
@@ -3372,6 +3377,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   std::stable_sort(staged.begin(), staged.end(), by_cost);
   std::stable_sort(large.begin(), large.end(), by_cost);
   std::stable_sort(clus.begin(), clus.end(), by_cost);
+  for (auto& w : wave) std::stable_sort(w.begin(), w.end(), by_cost);
   // the staged fits whose LDS fits a CU twice and the larger ones are two launches (see below)
   const long long kTwice = 72 * 1024;
   size_t nbig = 0, nkmaj = 0;  // sorted by M, the LDS need grows with M: [0, nkmaj) M_p > kKminMaxMp, [0, nbig) "big"
@@ -3414,6 +3420,11 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   all.insert(all.end(), small.begin(), small.end());
   const size_t clus_base = all.size();
   all.insert(all.end(), clus.begin(), clus.end());
+  size_t wave_base[3];
+  for (int k = 2; k >= 0; --k) {  // the largest first
+    wave_base[k] = all.size();
+    all.insert(all.end(), wave[k].begin(), wave[k].end());
+  }
   if (!clus.empty()) {  // staging of the cluster kernel: block table + one barrier counter line per fit
     const size_t need_stage = gapro_cluster_stage_bytes((int)clus.size());
     if (2 * need_stage > ctx->cl_stage_bytes) {  // cl_stage_bytes counts BOTH halves; a launch uses one of them
@@ -3434,7 +3445,8 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     }
   }
   // ticket counters of this launch: [0] staged beyond kKminMaxMp, [1] staged "big", [2] the other staged fits, [3] strip,
-  // [4] small.  The sets rotate, so that a set is zeroed again only kTicketSets launches later
+  // [4] small, [5..7] cluster kernel diagnostics, [8..10] wave kernels.  The sets rotate, so that a set is zeroed again
+  // only kTicketSets launches later
   unsigned* tk = nullptr;
   if (tickets) {
     tk = ctx->d_tickets + (size_t)(ctx->ticket_seq++ % gapro_ctx::kTicketSets) * gapro_ctx::kTicketsPerSet;
@@ -3476,8 +3488,8 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   // synchronised, so everything the kernels read is complete (and an event recorded here completes together
   // with the NEXT dispatch of `stream` under this runtime, which would serialise the kernels again).  Both
   // are joined back into `stream` with events.
-  const bool own = !(route_flags & 2) && ctx->fit_stream[0] && ctx->fit_stream[1] && ctx->fit_stream[2] &&
-                   ctx->fit_stream[3] && ctx->fit_stream[4];  // debug bit 1
+  bool own = !(route_flags & 2);  // debug bit 1
+  for (int k = 0; k < gapro_ctx::kFitStreams; ++k) own = own && ctx->fit_stream[k];
   hipStream_t s_staged = own ? ctx->fit_stream[0] : stream;
   hipStream_t s_strip = own ? ctx->fit_stream[1] : stream;
   // (round 4, tried: the small-fit kernel behind the strip kernel on ITS stream, so that the two-per-CU small fits fill
@@ -3494,6 +3506,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     tm->used[1] = !strip.empty();
     tm->used[2] = !small.empty();
     tm->used[3] = !clus.empty();
+    tm->used[4] = !wave[0].empty() || !wave[1].empty() || !wave[2].empty();
   }
   bool gate_staged2 = false;
   if (!clus.empty()) {  // first: the largest fits of the launch, each over several CUs
@@ -3594,6 +3607,33 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: small-fit kernel launch failed");
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[5], s_small));
   }
+  if (!wave[0].empty() || !wave[1].empty() || !wave[2].empty()) {
+    // One wave per fit (svgp_fit_wave.hip), one kernel per block count, side by side on their own streams; the waves
+    // of a kernel take its fits by ticket until none is left.  They touch no memory between their first and last step,
+    // so nothing holds them back: they take whatever wave slots and LDS the other kernels leave.
+    hipStream_t s_wave[3] = {own ? ctx->fit_stream[7] : stream, own ? ctx->fit_stream[6] : stream,
+                             own ? ctx->fit_stream[5] : stream};
+    const int first = !wave[2].empty() ? 2 : !wave[1].empty() ? 1 : 0;
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[8], s_wave[first]));
+    for (int k = 2; k >= 0; --k) {
+      if (wave[k].empty()) continue;
+      const int slots = ctx->n_cu * gapro_fit_wave_per_cu(k + 1, feat_dim);
+      const int n_wg = (int)std::min<size_t>(wave[k].size(), (size_t)std::max(slots, 1));
+      const int rc = gapro_launch_fit_wave(s_wave[k], k + 1, (int)wave[k].size(), n_wg, tk ? tk + 8 + k : nullptr, feat_dim,
+                                           d_feats_spp, d_idx, d_descs + wave_base[k], d_init_mean, *opt, d_workspace,
+                                           d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
+      if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: wave kernel launch failed");
+      if (own && k != first) {  // everything wave-per-fit is finished once s_wave[first] has passed this point
+        GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[5 + k], s_wave[k]));
+        GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(s_wave[first], ctx->ev_join[5 + k], 0));
+      }
+    }
+    if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[9], s_wave[first]));
+    if (own) {
+      GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[5 + first], s_wave[first]));
+      GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[5 + first], 0));
+    }
+  }
   if (own) {
     if (!large.empty() || !staged.empty()) {
       GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join[0], s_staged));
@@ -3624,7 +3664,7 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
   if (!ctx || !out) return GAPRO_ERR_BAD_ARG;
   gapro_fit_timing* t = new (std::nothrow) gapro_fit_timing();
   if (!t) return GAPRO_ERR_OOM;
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * gapro_fit_timing::kKernels; ++i)
     if (hipEventCreate(&t->ev[i]) != hipSuccess) {
       gapro_fit_timing_destroy(t);
       return gapro_fail(ctx, GAPRO_ERR_HIP, "gapro_fit_timing_create: hipEventCreate failed");
@@ -3635,7 +3675,7 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out) {
 
 void gapro_fit_timing_destroy(gapro_fit_timing* t) {
   if (!t) return;
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * gapro_fit_timing::kKernels; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   delete t;
 }
@@ -3643,22 +3683,24 @@ void gapro_fit_timing_destroy(gapro_fit_timing* t) {
 int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
   ctx->armed_timing = t;
-  if (t) t->used[0] = t->used[1] = t->used[2] = t->used[3] = false;
+  if (t) t->used[0] = t->used[1] = t->used[2] = t->used[3] = t->used[4] = false;
   return GAPRO_OK;
 }
 
-int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5) {
-  if (!ctx || !t || !out_ms5) return GAPRO_ERR_BAD_ARG;
+static int fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5, float* out_wave_ms) {
+  constexpr int NK = gapro_fit_timing::kKernels;
   for (int i = 0; i < 5; ++i) out_ms5[i] = 0.f;
-  const int slot[4] = {0, 1, 3, 4};  // staged, strip, small-fit strip, cluster
-  float start[4] = {0.f, 0.f, 0.f, 0.f}, end[4] = {0.f, 0.f, 0.f, 0.f};
+  if (out_wave_ms) *out_wave_ms = 0.f;
+  const int slot[NK] = {0, 1, 3, 4, -1};  // staged, strip, small-fit strip, cluster, wave-per-fit
+  float start[NK] = {0.f, 0.f, 0.f, 0.f, 0.f}, end[NK] = {0.f, 0.f, 0.f, 0.f, 0.f};
   int ref = -1;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < NK; ++k) {
     if (!t->used[k]) continue;
     float ms = 0.f;
     GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[2 * k + 1]));
     GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t->ev[2 * k], t->ev[2 * k + 1]));
-    out_ms5[slot[k]] = ms;
+    if (slot[k] >= 0) out_ms5[slot[k]] = ms;
+    else if (out_wave_ms) *out_wave_ms = ms;
     if (ref < 0) ref = k;
     float off = 0.f;  // start of kernel k relative to the first used kernel's start
     if (k != ref) GAPRO_HIP_CHECK(ctx, hipEventElapsedTime(&off, t->ev[2 * ref], t->ev[2 * k]));
@@ -3667,7 +3709,7 @@ int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5) {
   }
   if (ref >= 0) {
     float lo = 0.f, hi = 0.f;
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NK; ++k)
       if (t->used[k]) {
         lo = start[k] < lo ? start[k] : lo;
         hi = end[k] > hi ? end[k] : hi;
@@ -3675,6 +3717,17 @@ int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5) {
     out_ms5[2] = hi - lo;
   }
   return GAPRO_OK;
+}
+
+int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5) {
+  if (!ctx || !t || !out_ms5) return GAPRO_ERR_BAD_ARG;
+  return fit_timing_read(ctx, t, out_ms5, nullptr);
+}
+
+int gapro_fit_timing_read_wave(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms) {
+  if (!ctx || !t || !out_ms) return GAPRO_ERR_BAD_ARG;
+  float ms5[5];
+  return fit_timing_read(ctx, t, ms5, out_ms);
 }
 
 int gapro_fit_timing_cluster_info(gapro_ctx* ctx, gapro_fit_timing* t, int32_t* out3) {
@@ -3694,13 +3747,13 @@ int gapro_fit_timing_offsets(gapro_ctx* ctx, gapro_fit_timing* ref, gapro_fit_ti
   if (!ctx || !ref || !t || !out_ms2) return GAPRO_ERR_BAD_ARG;
   out_ms2[0] = out_ms2[1] = 0.f;
   int rk = -1;
-  for (int k = 0; k < 4 && rk < 0; ++k)
+  for (int k = 0; k < gapro_fit_timing::kKernels && rk < 0; ++k)
     if (ref->used[k]) rk = k;
   if (rk < 0) return GAPRO_OK;
   GAPRO_HIP_CHECK(ctx, hipEventSynchronize(ref->ev[2 * rk]));
   bool any = false;
   float lo = 0.f, hi = 0.f;
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < gapro_fit_timing::kKernels; ++k) {
     if (!t->used[k]) continue;
     float a = 0.f, b = 0.f;
     GAPRO_HIP_CHECK(ctx, hipEventSynchronize(t->ev[2 * k + 1]));

@@ -1,0 +1,29 @@
+"""Quick check of the wave-per-fit kernel against the float64 oracle and the small-fit kernel (GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from gapro_amd import _lib
+from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+from gapro_amd.gen_ps_utils import _pipeline
+from gapro_amd.synth import make_gp_problem
+from oracle import svgp_oracle as so
+
+lib = _lib.load()
+worst = 0.0
+for (m1, m2, t, iters) in [(1, 2, 1, 50), (3, 4, 5, 50), (7, 9, 20, 50), (8, 8, 16, 3), (10, 13, 33, 50), (16, 16, 32, 50), (15, 17, 7, 0),
+                           (20, 25, 40, 50), (24, 24, 17, 50), (30, 3, 70, 50), (17, 16, 1, 50), (2, 40, 9, 50)]:
+    f, b1, b2, it = make_gp_problem(500 + m1, m1, m2, t, 6)
+    print("M", m1 + m2, "route", lib.gapro_fit_route(m1 + m2, 6), end=" ")
+    out, res = fit_gp_spp_batch(f, [(b1, b2, it)], training_iter=iters, keep_debug=True)
+    probs, probs_new, labels, mu, var = out[0]
+    X = np.concatenate([f[b1], f[b2]]).astype(np.float64)
+    y = np.r_[-np.ones(len(b1)), np.ones(len(b2))]
+    (mu_r, var_r, p_r), st = so.svgp_fit_predict_autograd(X, y, f[it].astype(np.float64), iters, "f64", return_trace=True)
+    ev = np.max(np.abs(var - var_r) / var_r)
+    em = np.max(np.abs(mu - mu_r))
+    ep = np.max(np.abs(probs - p_r))
+    el = abs(float(res["loss"][0]) - st["loss"][-1]) if iters else 0.0
+    worst = max(worst, ev)
+    print("iters %d  var rel %.2e  mu abs %.2e  p abs %.2e  loss abs %.2e  status %s" % (iters, ev, em, ep, el, res["status"]))
+print("worst var rel", worst)

@@ -919,11 +919,13 @@ class Pipeline:
             if flags & 8:  # no cluster kernel: those fits run where they ran in round 1
                 for v in np.unique(m[r == 4]):
                     r[m == v] = 1 if int(v) <= 512 and D <= 32 else 2
+            if flags & (1 << 20):  # no wave-per-fit kernel
+                r[r == 5] = 3
             if flags & 4:
                 r[r == 3] = 0
             if flags & 1:
                 r[(r == 0) | (r == 3)] = 1
-            is_strip, is_small, is_clus = r == 0, r == 3, r == 4
+            is_strip, is_small, is_clus = r == 0, (r == 3) | (r == 5), r == 4  # wave-per-fit counts with the small fits
             self.fit_events.append(FitTiming(ctx, tm, float(each[is_strip].sum()),
                                              float(each[~(is_strip | is_small | is_clus)].sum()),
                                              float(each[is_small].sum()), m, float(each[is_clus].sum())))

@@ -333,7 +333,8 @@ typedef struct {
                               * 32768 = TEST: the last member of every cluster never arrives (cluster barrier timeout),
                               * 262144 = workgroup b of a fit kernel runs fit b of its list (default: the workgroups
                               * take the fits in the order in which they start, claim_fit in csrc/svgp_fit.hip),
-                              * 524288 = the two-per-CU staged launch is not held back behind the cluster kernel
+                              * 524288 = the two-per-CU staged launch is not held back behind the cluster kernel,
+                              * 1048576 = no wave-per-fit kernel (M_p <= 48 runs the small-fit strip kernel)
                               * -- A/B switches of tools/bench_fit.py / fit_timeline.py */
   int32_t psd_retries;       /* 3    gpytorch settings.cholesky_max_tries: a factorisation that meets a non-positive
                               *      pivot is repeated on K + psd_jitter 10^i I, i < psd_retries (psd_safe_cholesky,
@@ -380,7 +381,9 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t f
  * kernel (64 < M_p <= 128), 1 = LDS-staged kernel (128 < M_p < 512 while Z and X fit the LDS: M_p <= 192 at
  * feat_dim 32), 2 = generic kernel (feat_dim > 32), 3 = the small-fit strip kernel (M_p <= 64: 256 threads per fit,
  * two fits per CU), 4 = the cluster kernel (M_p >= 512: one fit spread over 4..32 workgroups with cluster barriers;
- * also, on one workgroup, every fit that fits neither LDS kernel).  M_p = m padded to the MFMA tile. */
+ * also, on one workgroup, every fit that fits neither LDS kernel), 5 = the wave-per-fit kernel (M_p <= 48 at
+ * feat_dim 6: one wavefront trains one fit, eight / four fits per CU, nothing leaves the CU between the first and the
+ * last Adam step).  M_p = m padded to the MFMA tile. */
 int gapro_fit_route(int32_t m, int32_t feat_dim);
 /* Padded size M_p of a fit's M x M matrices (a multiple of 16; of 32 where the kernel that takes the fit needs it):
  * a function of (M, D) only, never of the routing options.  The workspace layout is built on it. */
@@ -397,6 +400,9 @@ int gapro_fit_timing_create(gapro_ctx* ctx, gapro_fit_timing** out);
 void gapro_fit_timing_destroy(gapro_fit_timing* t);
 int gapro_fit_timing_arm(gapro_ctx* ctx, gapro_fit_timing* t);
 int gapro_fit_timing_read(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms5);
+/* Milliseconds of the wave-per-fit kernels of the timed launch (route 5; first start -> last end of its up to three
+ * kernels; 0 when the launch had none).  They are part of gapro_fit_timing_read's span.  Blocks like it. */
+int gapro_fit_timing_read_wave(gapro_ctx* ctx, gapro_fit_timing* t, float* out_ms);
 /* Diagnostics of the cluster kernel of the timed launch (blocks until it has finished; read it before 64 further
  * launches of this context): out3 = {clusters of more than one workgroup, those whose members did NOT all run on one
  * XCD (their barriers carry the L2 write-back), member workgroups}. */

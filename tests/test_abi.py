@@ -84,6 +84,8 @@ def test_padding_and_route_agree_for_every_size_and_feature_width():
                 assert mp % 32 == 0 and mp >= 64, (m, d, mp)
             if r in (0, 3):
                 assert mp <= 128
+            if r == 5:
+                assert mp <= 48 and d == 6
             if r == 2:
                 assert d > 32, (m, d, mp)  # nothing the reference's feature widths produce reaches the generic kernel
             if d > 32:

@@ -167,7 +167,7 @@ def test_s3dis_shaped_scene_matches_oracle():
     fits = [e for e in dbg["events"] if e.kind == "fit"]
     lib = Context.get(0).lib
     routes = {int(lib.gapro_fit_route(len(e.b1_inds) + len(e.b2_inds), 6)) for e in fits}
-    assert {0, 1, 3} <= routes and (routes & {2, 4}), routes  # the scene really exercises every kernel family
+    assert {0, 1, 3, 5} <= routes and (routes & {2, 4}), routes  # the scene really exercises every kernel family
     # fit by fit, on the oracle's pooled features (the partition is compared bit for bit through the masks below)
     got = fit_gp_spp_batch(dbg["part"].feats_spp, [(e.b1_inds, e.b2_inds, e.intersect_inds) for e in fits],
                            training_iter=50)
