@@ -31,9 +31,9 @@
 //   KX; A = LI KX, At;  B = L_S^T A (transient: column sums only);  mu, var;  likelihood -> g_mu, g_v
 //   B, Bt again;  G_LS = tril(At^T GBt);  G_A = m g_mu^T + L_S GB - 2 A diag(g_v), G_At;  Adam on L_S
 //   Pm^T = Phi(-G_A A^T)^T;  G_KX = LI^T G_A;  W = Pm LI;  S = LI^T W, St;  G_Kzz = (S + St) / 2
-//   kernel gradients: W_zx = G_KX o KX, W_zz = G_Kzz o K_ZZ elementwise; their row sums and products with the points
-//   are ONE MFMA product each against [X | 1] resp. [Z | 1]:  R = 2 W_zz [Z | 1] + W_zx [X | 1],
-//   G_Z[k][d] = -(R[k][D] Z[k][d] - R[k][d]) / l^2;  Adam on Z, m, c, rho_s, rho_l
+//   kernel gradients: W_zx = G_KX o KX, W_zz = G_Kzz o K_ZZ elementwise on n-major tiles;
+//   G_Z[k] = -sum_n (2 W_zz[k][n] (Z_k - Z_n) + W_zx[k][n] (Z_k - X_n)) / l^2 in the difference form (as a product
+//   against [Z | 1] / [X | 1] it cancels digits away);  Adam on Z, m, c, rho_s, rho_l
 #include <math.h>
 
 #include "common.h"
@@ -499,8 +499,13 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 
     // ---- the training points in blocks of 16 columns: everything between KX and the gradient sums is column-wise
     // (the strip idea of svgp_fit.hip), so only the M x M sums G_LS, Pm^T and R live across the blocks
-    d4 GLS[NL], PmT[NL], R[NB];
+    d4 GLS[NL], PmT[NL];
     double gm_part[NB];
+    // G_Z[k][d] = -sum_n W[k][n] (Z_k[d] - P_n[d]) / l^2 in the DIFFERENCE form, like svgp_fit.hip: as a product
+    // (rowsum_k Z_k - W P) it loses digits to cancellation, and on tiny fits (M = 3) Adam turns that into 5e-6 in mu.
+    // This lane accumulates column k = 16 kb + lr over the rows n of transposed tiles (n-major: W^T, or the symmetric
+    // W_zz as it is); the four row groups are summed at the end.
+    double gz[NB][DC];
 #pragma unroll
     for (int t = 0; t < NL; ++t) {
       GLS[t] = zero4();
@@ -508,8 +513,9 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-      R[k] = zero4();
       gm_part[k] = 0.0;
+#pragma unroll
+      for (int d = 0; d < DC; ++d) gz[k][d] = 0.0;
     }
     double e_part = 0.0, gc_part = 0.0, gvs_part = 0.0, wsum = 0.0, gl = 0.0;
 #pragma unroll 1
@@ -601,35 +607,30 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 #pragma unroll
         for (int j = 0; j <= i; ++j) PmT[lt(i, j)] = tn_neg(PmT[lt(i, j)], At[j], gt);
       }
-      // kernel gradients through KX: W_zx = G_KX o KX with G_KX = LI^T G_A;  R += W_zx [X | 1]
-      d4 Xe;  // rows n of [X | 1 | 0]
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * n + lq + 4 * r;
-        Xe[r] = lr < DC ? Xt[lr * Mp + row] : (lr == DC ? 1.0 : 0.0);
-      }
-      double pc[DC];
-#pragma unroll
-      for (int d = 0; d < DC; ++d) pc[d] = Xt[d * Mp + col];
+      // kernel gradients through KX: W_zx = G_KX o KX with G_KX = LI^T G_A, transposed through LDS to n-major
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         d4 g = zero4();
 #pragma unroll
         for (int i = k; i < NB; ++i) g = tn(g, li_tile(i, k), GA[i]);
-        d4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[r] *= KX[k][r];
+        const d4 wt = transpose_tile(g, t0);  // rows n = 16 n + lq + 4 r, column k = 16 k + lr
+        double zk[DC];
+#pragma unroll
+        for (int d = 0; d < DC; ++d) zk[d] = Zt[d * Mp + 16 * k + lr];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double s2 = 0.0;  // |Z_k - X_n|^2 again: six subtractions away in LDS
+          double s2 = 0.0;
 #pragma unroll
           for (int d = 0; d < DC; ++d) {
-            const double t = Zt[d * Mp + 16 * k + lq + 4 * r] - pc[d];
+            const double t = zk[d] - Xt[d * Mp + 16 * n + lq + 4 * r];
             s2 += t * t;
+            gz[k][d] += wt[r] * t;
           }
-          w[r] = g[r] * KX[k][r];
-          wsum += w[r];
-          gl += w[r] * s2;
+          wsum += wt[r];
+          gl += wt[r] * s2;
         }
-        R[k] = tn(R[k], transpose_tile(w, t0), Xe);
       }
     }
     const double g_c = wave_sum(gc_part);
@@ -689,7 +690,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
     }
 
     // ---- G_Kzz = LI^T Pm LI, symmetrised:  Pm = Phi(.) (strictly lower + half the diagonal),  W = Pm LI (lower),
-    // S = LI^T W and S^T = W^T LI;  W_zz = sym(G_Kzz) o K_ZZ;  R += 2 W_zz [Z | 1]
+    // S = LI^T W and S^T = W^T LI;  W_zz = sym(G_Kzz) o K_ZZ (symmetric: every tile is n-major as it is)
     double gs = wsum / s;
     {
 #pragma unroll
@@ -711,12 +712,6 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
         }
 #pragma unroll
       for (int n = 0; n < NB; ++n) {
-        d4 Ze;  // rows n of [Z | 1 | 0]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * n + lq + 4 * r;
-          Ze[r] = lr < DC ? Zt[lr * Mp + row] : (lr == DC ? 1.0 : 0.0);
-        }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
           d4 sv = zero4(), st = zero4();  // tile (n, k) of S and of S^T
@@ -727,7 +722,9 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
           }
           const RbfTile kz = rbf_tile<DC, Mp>(Zt, n, Zt, k, -0.5 * inv_l2);
           const int cj = 16 * k + lr;
-          d4 w2;
+          double zk[DC];
+#pragma unroll
+          for (int d = 0; d < DC; ++d) zk[d] = Zt[d * Mp + cj];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * n + lq + 4 * r;
@@ -736,32 +733,39 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
             const double w = gsym * s * kz.e[r];
             gs += gsym * kz.e[r];
             gl += w * kz.d2[r];
-            w2[r] = 2.0 * w;
+#pragma unroll
+            for (int d = 0; d < DC; ++d) gz[k][d] += 2.0 * w * (zk[d] - Zt[d * Mp + row]);
           }
-          R[k] = tn(R[k], w2, Ze);
         }
       }
     }
     gs = wave_sum(gs) + gv_sum;
     gl = wave_sum(gl) / (ell * ell * ell);
 
-    // ---- Adam on Z: G_Z[k][d] = -(R[k][D] Z[k][d] - R[k][d]) / l^2 for lanes lr = d < D
+    // ---- Adam on Z: the four row groups of column k are summed; row group lq then updates d = lq, lq + 4, ...
+    wsync();  // every read of Z of this step is done
 #pragma unroll
-    for (int k = 0; k < NB; ++k)
+    for (int k = 0; k < NB; ++k) {
+      double mine[(DC + 3) / 4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double rowsum = __shfl(R[k][r], (lane & 48) | DC, 64);
-        const int row = 16 * k + lq + 4 * r;
-        if (lr < DC && row < M) {
-          const int o = lr * Mp + row;
-          const double z = Zt[o];
-          const double grad = -inv_l2 * (rowsum * z - R[k][r]);
+      for (int d = 0; d < DC; ++d) {
+        const double v = red_lq(gz[k][d]);
+        if ((d & 3) == lq) mine[d >> 2] = v;
+      }
+      const int pt = 16 * k + lr;
+#pragma unroll
+      for (int e = 0; e < (DC + 3) / 4; ++e) {
+        const int d = lq + 4 * e;
+        if (d < DC && pt < M) {
+          const int o = d * Mp + pt;
+          const double grad = -inv_l2 * mine[e];
           double m1 = mZ[o], m2 = vZ[o];
-          Zt[o] = adam(z, m1, m2, grad, step_size, bc2s);
+          Zt[o] = adam(Zt[o], m1, m2, grad, step_size, bc2s);
           mZ[o] = m1;
           vZ[o] = m2;
         }
       }
+    }
 
     // ---- Adam on m, c, rho_s, rho_l
     wsync();

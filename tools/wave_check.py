@@ -11,9 +11,12 @@ from oracle import svgp_oracle as so
 
 lib = _lib.load()
 worst = 0.0
-for (m1, m2, t, iters) in [(1, 2, 1, 50), (3, 4, 5, 50), (7, 9, 20, 50), (8, 8, 16, 3), (10, 13, 33, 50), (16, 16, 32, 50), (15, 17, 7, 0),
+for (m1, m2, t, iters) in [(1, 2, 1, 50), (-1, 2, 1, 50), (3, 4, 5, 50), (7, 9, 20, 50), (8, 8, 16, 3), (10, 13, 33, 50), (16, 16, 32, 50), (15, 17, 7, 0),
                            (20, 25, 40, 50), (24, 24, 17, 50), (30, 3, 70, 50), (17, 16, 1, 50), (2, 40, 9, 50)]:
-    f, b1, b2, it = make_gp_problem(500 + m1, m1, m2, t, 6)
+    seed = 500 + m1
+    if m1 < 0:  # the problem of tests/test_fit_gpu.py::test_fit_matches_oracle[50-1-2-1-6] (a cancellation canary)
+        m1, seed = 1, 8
+    f, b1, b2, it = make_gp_problem(seed, m1, m2, t, 6)
     print("M", m1 + m2, "route", lib.gapro_fit_route(m1 + m2, 6), end=" ")
     out, res = fit_gp_spp_batch(f, [(b1, b2, it)], training_iter=iters, keep_debug=True)
     probs, probs_new, labels, mu, var = out[0]
