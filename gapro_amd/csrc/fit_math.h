@@ -43,9 +43,43 @@ __device__ inline double lane_bcast(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// a wave-uniform double as a scalar (SGPR pair): loop-invariant values the register allocator would otherwise hold in
+// -- or spill from -- vector registers (VALU instructions take one scalar operand for free)
+__device__ inline double uni_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Cross-lane sums on the VALU (no LDS crossbar: ds_bpermute costs ~100 cycles of latency per hop and __shfl_xor
+// compiles to it).  Lanes l = (lq = l >> 4, lr = l & 15):
+//   v_permlane32_swap exchanges the wave's halves, v_permlane16_swap odd and even rows of 16 (both new on gfx950);
+//   within a row the hops are DPP moves (quad_perm, row_half_mirror, row_mirror).
+// Fixed tree: every lane ends with the same bits.
+template <int CTRL>
+__device__ inline double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double sum_xor32(double v) {  // v[l] + v[l ^ 32]
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ inline double sum_xor16(double v) {  // v[l] + v[l ^ 16]
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// sum over the four rows of 16 lanes: every lane gets the total of its column lr
+__device__ inline double sum_rows(double v) { return sum_xor32(sum_xor16(v)); }
 __device__ inline double wave_sum(double v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);   // quad_perm(1, 0, 3, 2)
+  v += dpp_mov<0x4E>(v);   // quad_perm(2, 3, 0, 1)
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return sum_rows(v);
 }
 
 }  // namespace gapro_fit_math

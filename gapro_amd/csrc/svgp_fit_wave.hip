@@ -66,12 +66,21 @@ struct WaveLds {
   static constexpr int oGv = oGmu + Mp;         // g_v [Mp]
   static constexpr int oTmp = oGv + Mp;         // [Mp]
   static constexpr int oGh = oTmp + Mp;         // Gauss-Hermite nodes [10] and weights [10]
-  static constexpr int oSc = oGh + 20;          // c, rho_s, rho_l and their Adam moments [9]
+  static constexpr int oSc = oGh + 20;          // c, rho_s, rho_l [3] (their Adam moments: registers of lanes 61..63)
+#ifdef GAPRO_PROFILE
+  static constexpr int oProf = oSc + 10;        // phase clocks of the diagnostic build [16] + the last stamp
+  static constexpr int total = (oProf + 18) / 2 * 2;
+#else
   static constexpr int total = (oSc + 9 + 1) / 2 * 2;
+#endif
 };
 
-__device__ inline void wsync() {  // LDS hand-over between the lanes of the one wave
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+// LDS hand-over between the lanes of the one wave.  A wave's LDS operations execute in order, so all this has to do
+// is keep the COMPILER from moving memory accesses across it.  (__builtin_amdgcn_fence(seq_cst, "wavefront", "local")
+// does that too, but this compiler emits s_waitcnt vmcnt(0) for it: every hand-over then also waited for the Adam
+// moments travelling to and from the workspace and for every register spill in flight -- 2.6 us per step at NB = 2.)
+__device__ inline void wsync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
 }
 __device__ inline d4 zero4() { return (d4){0.0, 0.0, 0.0, 0.0}; }
@@ -238,11 +247,13 @@ __device__ __noinline__ LikSums lik_column(const ldsd* gh, double mu, double sd,
 
 // torch.optim.Adam on one tile of tril(L_S) (LDS tile t, row-major) with the gradient tile g of the likelihood term;
 // the KL term (l - 1 / l on the diagonal) / N joins here.  i0, j0: the tile's first row / column; moments in registers.
+// (Inlined: a call boundary waits for every memory operation in flight, and the moments travel through global memory.)
 struct AdamTile {
   d4 m1, m2;
 };
-__device__ __noinline__ AdamTile adam_ls_tile(ldsd* t, d4 g, d4 m1, d4 m2, int i0, int j0, int M, double Nd,
-                                              double step_size, double bc2s) {
+template <bool DIAG>
+__device__ inline AdamTile adam_ls_tile(ldsd* t, d4 g, d4 m1, d4 m2, int i0, int j0, int M, double Nd,
+                                        double step_size, double ibc2s) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   AdamTile o;
 #pragma unroll
@@ -251,10 +262,12 @@ __device__ __noinline__ AdamTile adam_ls_tile(ldsd* t, d4 g, d4 m1, d4 m2, int i
     const bool act = col <= row && row < M;
     const double lv = t[(lq + 4 * r) * 17 + lr];
     const double l = act ? lv : 1.0;
-    const double gr = g[r] + (l - (row == col ? 1.0 / l : 0.0)) / Nd;
+    double kl = l;  // KL term of the ELBO: l - 1 / l on the diagonal (only diagonal tiles pay for the division)
+    if (DIAG) kl -= row == col ? 1.0 / l : 0.0;
+    const double gr = g[r] + kl / Nd;
     const double a1 = 0.9 * m1[r] + (1.0 - 0.9) * gr;
     const double a2 = 0.999 * m2[r] + (1.0 - 0.999) * gr * gr;
-    const double lnew = l - step_size * a1 / (sqrt(a2) / bc2s + 1e-8);
+    const double lnew = l - step_size * a1 / (sqrt(a2) * ibc2s + 1e-8);
     o.m1[r] = act ? a1 : m1[r];
     o.m2[r] = act ? a2 : m2[r];
     if (act) t[(lq + 4 * r) * 17 + lr] = lnew;
@@ -286,7 +299,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
   constexpr int Mp = W::Mp, NL = W::NL;
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int M = desc.m1 + desc.m2, T = desc.t;
-  const double Nd = (double)M;
+  const double Nd = uni_d((double)M);
   ldsd* Zt = L + W::oZ;
   ldsd* Xt = L + W::oX;
   ldsd* mZ = L + W::oMZ;
@@ -307,6 +320,18 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
   int status = GAPRO_OK;
 #ifdef GAPRO_PROFILE
   const unsigned long long t_start = wall_clock64();
+  typedef __attribute__((address_space(3))) unsigned long long ldsu64;
+  ldsu64* prof = (ldsu64*)(L + W::oProf);
+  if (lane < 17) prof[lane] = lane == 16 ? t_start : 0ull;
+  auto stamp = [&](int id) {  // phase clocks (tools/bench_fit.py --profile): time since the previous stamp goes to slot id
+    if (lane == 0) {
+      const unsigned long long t = wall_clock64();
+      prof[id] += t - prof[16];
+      prof[16] = t;
+    }
+  };
+#else
+  auto stamp = [&](int) {};
 #endif
 
   // ---- setup: parameters as gpytorch initialises them (gaussian_process_utils.py:386-403, :14) ----------------
@@ -333,7 +358,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
     gh[lane] = kGhT[lane];
     gh[10 + lane] = kGhW[lane];
   }
-  if (lane < 9) sc[lane] = 0.0;
+  if (lane < 3) sc[lane] = 0.0;
   double mm1 = 0.0, mm2 = 0.0;  // Adam moments of m[lane]
   // Adam moments of tril(L_S): the one piece of state that is touched once per step and nowhere else, so it lives in
   // the fit's workspace slab (B_MLS, B_VLS) in tile order [tile][r][lane] -- 512-byte rows, read at the start of the
@@ -382,11 +407,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
   auto lst_tile = [&](int j, int i) { return ld_tile_t(LS + lt(i, j) * kTS); };  // (L_S^T) tile (j, i), j <= i
   auto li_tile = [&](int i, int k) { return ld_tile(LIm + lt(i, k) * kTS); };    // LI tile (i, k), i >= k
   auto lit_tile = [&](int k, int i) { return ld_tile_t(LIm + lt(i, k) * kTS); }; // (LI^T) tile (k, i), k <= i
-  auto red_lq = [&](double v) {  // sum over the four row groups of a column (lanes l, l ^ 16, l ^ 32, l ^ 48)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-  };
+  auto red_lq = [&](double v) { return sum_rows(v); };  // sum over the four row groups of a column
 
   // ---- factorisation: U = L^T (off-diagonal tiles), Dinv_k, Dinv_k^T -> LI = L^-1 as row-major LDS tiles (LI and
   // LI^T are then the same bytes read with either index pattern, like L_S)
@@ -476,22 +497,29 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 
   double last_loss = 0.0;
   const double b1 = 0.9, b2 = 0.999, aeps = 1e-8;
-  auto adam = [&](double p, double& m1, double& m2, double g, double step_size, double bc2s) {
+  // torch.optim.Adam; ibc2s = 1 / sqrt(1 - beta2^step), one division per step instead of one per element (the
+  // denominator differs from sqrt(v) / sqrt(bc2) + eps in its last bit at most)
+  auto adam = [&](double p, double& m1, double& m2, double g, double step_size, double ibc2s) {
     m1 = b1 * m1 + (1.0 - b1) * g;
     m2 = b2 * m2 + (1.0 - b2) * g * g;
-    return p - step_size * m1 / (sqrt(m2) / bc2s + aeps);
+    return p - step_size * m1 / (sqrt(m2) * ibc2s + aeps);
   };
 
   double b1p = 1.0, b2p = 1.0;  // beta^step as running products (a few ulp from pow(): far inside the oracle tolerance)
   for (int step = 1; step <= opt.training_iter; ++step) {
-    b1p *= b1;
-    b2p *= b2;
-    const double c = sc[0], rho_s = sc[1], rho_l = sc[2];
-    const double s = nl_softplus(rho_s), ell = nl_softplus(rho_l), inv_l2 = 1.0 / (ell * ell);
+    b1p = uni_d(b1p * b1);
+    b2p = uni_d(b2p * b2);
+    // (wave-uniform scalars go through uni_d: in vector registers the allocator spilled them to scratch memory and
+    // reloaded them element by element inside the Adam updates)
+    const double c = uni_d(sc[0]), rho_s = uni_d(sc[1]), rho_l = uni_d(sc[2]);
+    const double sp = nl_softplus(lane == 63 ? rho_l : rho_s);  // one call: lane 63 evaluates the length scale's
+    const double s = lane_bcast(sp, 0), ell = lane_bcast(sp, 63), inv_l2 = uni_d(1.0 / (ell * ell));
     const bool last = step == opt.training_iter;
-    const double bc1 = 1.0 - b1p, bc2s = sqrt(1.0 - b2p);
-    const double step_size = opt.lr / bc1;
+    const double bc1 = 1.0 - b1p, bc2s = uni_d(1.0 / sqrt(1.0 - b2p));  // (bc2s: the RECIPROCAL root, see adam)
+    const double step_size = uni_d(opt.lr / bc1);
+    stamp(0);
     factorize(s, inv_l2);
+    stamp(1);
     if (last && opt.eval_stale_chol) {  // prediction with the factor of the last training step
       double* U = wbase + lay.mat + (long long)B_U * lay.Mp * lay.Mp;
       for (int e = lane; e < NL * kTS; e += 64) U[e] = LIm[e];
@@ -530,6 +558,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 #pragma unroll
         for (int r = 0; r < 4; ++r) KX[k][r] = (16 * k + lq + 4 * r < M && on) ? s * kx.e[r] : 0.0;
       }
+      stamp(2);
       forward_a(KX, A, nullptr);
       // mu, var; likelihood gradients (ten Gauss-Hermite pairs per column over the four row groups of its lanes)
       double mu_raw, vraw;
@@ -539,6 +568,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
       const double var = clamped ? opt.min_variance : vraw;
       const double sd = sqrt(2.0 * var);
       const double y = vy[col];
+      stamp(3);
       const LikSums ls = lik_column(gh, mu, sd, y, on ? 1 : 0, last ? 1 : 0);
       const double E = red_lq(ls.E), dmu = red_lq(ls.dmu), dvar = red_lq(ls.dvar);
       const double ipi = 0.56418958354775628695;  // 1 / sqrt(pi)
@@ -554,6 +584,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
         }
       }
       wsync();
+      stamp(4);
       forward_a(KX, A, &At);     // (A again, and A^T: fewer tiles live across the likelihood call)
       double gmu_r[4], gv_r[4];  // the same two vectors indexed by the ROWS of the transposed tiles
 #pragma unroll
@@ -576,6 +607,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
       for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) gm_part[i] += At[i][r] * gmu_r[r];
+      stamp(5);
       // GB = 2 B diag(g_v);  G_A = m g_mu^T + L_S GB - 2 A diag(g_v)
       d4 GB[NB], GA[NB];
 #pragma unroll
@@ -607,6 +639,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 #pragma unroll
         for (int j = 0; j <= i; ++j) PmT[lt(i, j)] = tn_neg(PmT[lt(i, j)], At[j], gt);
       }
+      stamp(6);
       // kernel gradients through KX: W_zx = G_KX o KX with G_KX = LI^T G_A, transposed through LDS to n-major
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
@@ -632,9 +665,19 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
           gl += wt[r] * s2;
         }
       }
+      stamp(7);
     }
-    const double g_c = wave_sum(gc_part);
-    const double gv_sum = wave_sum(gvs_part);
+    // the Adam moments of tril(L_S) are requested now and arrive behind the sums below
+    d4 MLS[NL], VLS[NL];
+#pragma unroll
+    for (int t = 0; t < NL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        MLS[t][r] = gMLS[(4 * t + r) * 64 + lane];
+        VLS[t][r] = gVLS[(4 * t + r) * 64 + lane];
+      }
+    const double g_c = uni_d(wave_sum(gc_part));
+    const double gv_sum = uni_d(wave_sum(gvs_part));
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const double p = red_lq(gm_part[i]);
@@ -664,31 +707,24 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
       last_loss = -(e_sum / Nd - kl / Nd);
     }
     wsync();  // every read of L_S of this step is done
+    stamp(8);
 
-    // ---- Adam on tril(L_S): all moment tiles are requested before the first update
-    {
-      d4 MLS[NL], VLS[NL];
+    // ---- Adam on tril(L_S)
 #pragma unroll
-      for (int t = 0; t < NL; ++t)
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const int t = lt(i, j);
+        const AdamTile a = i == j ? adam_ls_tile<true>(LS + t * kTS, GLS[t], MLS[t], VLS[t], 16 * i, 16 * j, M, Nd, step_size, bc2s)
+                                  : adam_ls_tile<false>(LS + t * kTS, GLS[t], MLS[t], VLS[t], 16 * i, 16 * j, M, Nd, step_size, bc2s);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          MLS[t][r] = gMLS[(4 * t + r) * 64 + lane];
-          VLS[t][r] = gVLS[(4 * t + r) * 64 + lane];
+          gMLS[(4 * t + r) * 64 + lane] = a.m1[r];
+          gVLS[(4 * t + r) * 64 + lane] = a.m2[r];
         }
-#pragma unroll
-      for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j <= i; ++j) {
-          const int t = lt(i, j);
-          const AdamTile a = adam_ls_tile(LS + t * kTS, GLS[t], MLS[t], VLS[t], 16 * i, 16 * j, M, Nd, step_size, bc2s);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            gMLS[(4 * t + r) * 64 + lane] = a.m1[r];
-            gVLS[(4 * t + r) * 64 + lane] = a.m2[r];
-          }
-        }
-    }
+      }
 
+    stamp(9);
     // ---- G_Kzz = LI^T Pm LI, symmetrised:  Pm = Phi(.) (strictly lower + half the diagonal),  W = Pm LI (lower),
     // S = LI^T W and S^T = W^T LI;  W_zz = sym(G_Kzz) o K_ZZ (symmetric: every tile is n-major as it is)
     double gs = wsum / s;
@@ -739,8 +775,9 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
         }
       }
     }
-    gs = wave_sum(gs) + gv_sum;
-    gl = wave_sum(gl) / (ell * ell * ell);
+    gs = uni_d(wave_sum(gs) + gv_sum);
+    gl = uni_d(wave_sum(gl) / (ell * ell * ell));
+    stamp(10);
 
     // ---- Adam on Z: the four row groups of column k are summed; row group lq then updates d = lq, lq + 4, ...
     wsync();  // every read of Z of this step is done
@@ -752,49 +789,47 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
         const double v = red_lq(gz[k][d]);
         if ((d & 3) == lq) mine[d >> 2] = v;
       }
+      // (no branch around the arithmetic: the updates of a lane are independent chains of divisions and square roots,
+      // and only in one basic block does the compiler interleave them)
       const int pt = 16 * k + lr;
 #pragma unroll
       for (int e = 0; e < (DC + 3) / 4; ++e) {
         const int d = lq + 4 * e;
-        if (d < DC && pt < M) {
-          const int o = d * Mp + pt;
-          const double grad = -inv_l2 * mine[e];
-          double m1 = mZ[o], m2 = vZ[o];
-          Zt[o] = adam(Zt[o], m1, m2, grad, step_size, bc2s);
+        const bool act = d < DC && pt < M;
+        const int o = act ? d * Mp + pt : 0;
+        const double grad = -inv_l2 * mine[e];
+        double m1 = mZ[o], m2 = vZ[o];
+        const double zn = adam(Zt[o], m1, m2, grad, step_size, bc2s);
+        if (act) {
+          Zt[o] = zn;
           mZ[o] = m1;
           vZ[o] = m2;
         }
       }
     }
 
-    // ---- Adam on m, c, rho_s, rho_l
+    // ---- Adam on m, c, rho_s, rho_l: ONE update per lane -- lanes < M hold m (M <= 48), lanes 61, 62, 63 the three
+    // scalars; their moments are the same two registers (mm1, mm2) in every lane
     wsync();
-    if (lane < M) {
-      const double mv = vm[lane];
-      const double g = vtmp[lane] + mv / Nd;
-      vm[lane] = adam(mv, mm1, mm2, g, step_size, bc2s);
-    }
     {
-      double m1 = sc[3], m2 = sc[6];
-      const double cn = adam(c, m1, m2, g_c, step_size, bc2s);
-      double m1s = sc[4], m2s = sc[7];
-      const double rsn = adam(rho_s, m1s, m2s, gs * nl_sigmoid(rho_s), step_size, bc2s);
-      double m1l = sc[5], m2l = sc[8];
-      const double rln = adam(rho_l, m1l, m2l, gl * nl_sigmoid(rho_l), step_size, bc2s);
+      const double sg = nl_sigmoid(lane == 63 ? rho_l : rho_s);  // softplus' for both raw hyperparameters in one call
+      const bool is_m = lane < M;
+      const double pv = is_m ? vm[lane] : (lane == 61 ? c : lane == 62 ? rho_s : rho_l);
+      const double g = is_m ? vtmp[is_m ? lane : 0] + pv / Nd : (lane == 61 ? g_c : (lane == 62 ? gs : gl) * sg);
+      const double pn = adam(pv, mm1, mm2, g, step_size, bc2s);
       wsync();
-      if (lane == 0) {
-        sc[0] = cn; sc[1] = rsn; sc[2] = rln;
-        sc[3] = m1; sc[4] = m1s; sc[5] = m1l;
-        sc[6] = m2; sc[7] = m2s; sc[8] = m2l;
-      }
+      if (is_m) vm[lane] = pn;
+      if (lane >= 61) sc[lane - 61] = pn;
     }
     wsync();
+    stamp(11);
   }
 
   // ------------------------------- prediction (gaussian_process_utils.py:426-438) ------------------------------
   {
-    const double c = sc[0];
-    const double s = nl_softplus(sc[1]), ell = nl_softplus(sc[2]), inv_l2 = 1.0 / (ell * ell);
+    const double c = uni_d(sc[0]);
+    const double sp = nl_softplus(lane == 63 ? sc[2] : sc[1]);
+    const double s = lane_bcast(sp, 0), ell = lane_bcast(sp, 63), inv_l2 = uni_d(1.0 / (ell * ell));
     if (opt.eval_stale_chol && opt.training_iter > 0) {
       const double* U = wbase + lay.mat + (long long)B_U * lay.Mp * lay.Mp;
       for (int e = lane; e < NL * kTS; e += 64) LIm[e] = U[e];
@@ -847,10 +882,11 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
       }
     }
   }
+  stamp(12);
   // a status raised by any lane (the prediction's lanes differ) reaches lane 0: errors are negative, so the minimum
   // over the wave is the most severe code
   for (int o = 32; o > 0; o >>= 1) {
-    const int other = __shfl_xor(status, o, 64);
+    const int other = __shfl_xor(status, o, 64);  // (once per fit: the LDS crossbar will do)
     status = other < status ? other : status;
   }
   if (lane == 0) {
@@ -867,7 +903,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
     unsigned xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    for (int i = 0; i < 25; ++i) scal[24 + i] = 0.0;
+    for (int i = 0; i < 25; ++i) scal[24 + i] = i < 16 ? (double)prof[i] : 0.0;
     scal[24 + 25] = (double)t_start;  // timeline of the launch: tools/fit_timeline.py
     scal[24 + 26] = (double)wall_clock64();
     scal[24 + 27] = (double)(((xcc & 15u) << 16) | (hwid & 0xFFFFu));
@@ -920,7 +956,7 @@ size_t gapro_fit_wave_lds_bytes(int nb, int feat_dim) {
 int gapro_fit_wave_per_cu(int nb, int feat_dim) {
   const size_t lds = gapro_fit_wave_lds_bytes(nb, feat_dim);
   if (!lds) return 0;
-  const int by_lds = (int)((160 * 1024) / lds), by_reg = nb <= 2 ? 8 : 4;
+  const int by_lds = (int)((160 * 1024) / lds), by_reg = nb <= 1 ? 8 : 4;
   return by_lds < by_reg ? by_lds : by_reg;
 }
 
@@ -937,7 +973,7 @@ int gapro_launch_fit_wave(hipStream_t stream, int nb, int n_fits, int n_wg, unsi
                      d_descs, d_init_mean, opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, \
                      d_fit_loss, d_ticket)
   if (nb == 1) GAPRO_WAVE_LAUNCH(1, 2);
-  else if (nb == 2) GAPRO_WAVE_LAUNCH(2, 2);
+  else if (nb == 2) GAPRO_WAVE_LAUNCH(2, 1);
   else GAPRO_WAVE_LAUNCH(3, 1);
 #undef GAPRO_WAVE_LAUNCH
   return hipGetLastError() == hipSuccess ? GAPRO_OK : GAPRO_ERR_HIP;

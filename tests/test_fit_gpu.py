@@ -53,7 +53,8 @@ def _compare(out, ref):
 
 
 @pytest.mark.parametrize("m1,m2,t,d", [(1, 2, 1, 6), (3, 4, 5, 6), (20, 30, 10, 6), (16, 16, 32, 6), (40, 60, 33, 6),
-                                       (70, 80, 100, 6), (10, 12, 75, 32), (120, 136, 40, 6)])
+                                       (70, 80, 100, 6), (10, 12, 75, 32), (120, 136, 40, 6), (10, 13, 33, 6),
+                                       (20, 25, 40, 6), (2, 46, 17, 6)])
 @pytest.mark.parametrize("iters", [0, 3, 50])
 def test_fit_matches_oracle(m1, m2, t, d, iters):
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
@@ -350,6 +351,47 @@ def test_fit_reports_non_finite_inputs_instead_of_returning_garbage():
     assert e.value.code in (-4, -5)
     ok = fit_gp_spp_batch(feats, [(b1, b2, it)], training_iter=5)[0]  # the clean fit alone is fine
     assert np.isfinite(ok[3]).all()
+
+
+def test_wave_kernel_and_small_fit_kernel_agree():
+    """Round 5: fits of M_p <= 48 at D = 6 run one per WAVEFRONT (route 5, svgp_fit_wave.hip: every matrix as MFMA
+    accumulator-layout register tiles, nothing leaves the CU between the first and the last Adam step); with debug bit 20
+    they run on the small-fit strip kernel as in rounds 1-4.  Same arithmetic, different summation orders: the two must
+    agree within float32 output rounding, for every block count (M_p = 16, 32, 48), ragged sizes, T beyond one 16-column
+    block, a supplied initial mean, the stale-Cholesky switch, and a batch in which a wave takes several fits."""
+    import torch
+    from gapro_amd import _lib
+    from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
+    from gapro_amd.gen_ps_utils import _pipeline
+    from gapro_amd.synth import make_gp_problem
+
+    lib = _lib.load()
+    feats_list, probs = [], []
+    base = 0
+    for i, (m1, m2, t) in enumerate([(1, 2, 1), (7, 9, 5), (8, 8, 16), (10, 13, 33), (20, 12, 70), (17, 16, 1), (30, 18, 40),
+                                     (2, 40, 9), (24, 24, 17)]):
+        assert lib.gapro_fit_route(m1 + m2, 6) == 5
+        f, b1, b2, it = make_gp_problem(700 + i, m1, m2, t, 6)
+        feats_list.append(f)
+        probs.append((b1 + base, b2 + base, it + base))
+        base += len(f)
+    feats = np.concatenate(feats_list)
+    rng = np.random.default_rng(5)
+    init = [1e-3 * rng.standard_normal(len(p[0]) + len(p[1])) for p in probs]
+    for pipe_kw, im in ((dict(), None), (dict(eval_stale_chol=True), None), (dict(), init)):
+        pipe = _pipeline(torch.device("cuda", 0), 50, **pipe_kw)  # the pipeline object fit_gp_spp_batch will use
+        old = pipe.opt.reserved
+        wave = fit_gp_spp_batch(feats, probs * 300, training_iter=50, init_mean=None if im is None else im * 300, **pipe_kw)
+        pipe.opt.reserved = old | (1 << 20)
+        try:
+            small = fit_gp_spp_batch(feats, probs, training_iter=50, init_mean=im, **pipe_kw)
+        finally:
+            pipe.opt.reserved = old
+        for k in range(len(probs)):
+            for x, y in zip(wave[k], small[k]):
+                np.testing.assert_allclose(np.asarray(x, np.float64), np.asarray(y, np.float64), rtol=0, atol=2e-6)
+            for x, y in zip(wave[k], wave[k + len(probs) * 299]):  # the 300th copy: another wave, a later ticket
+                np.testing.assert_array_equal(x, y)
 
 
 def test_small_fit_kernel_and_strip_kernel_agree():

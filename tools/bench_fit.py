@@ -193,6 +193,9 @@ def main():
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
                          "s:GKX+PmAcc", "adam", "predict", "s:GKXTstore", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
                          "(diag:stores", "x25", "x26", "x27"]
+            if route == 5 and not (args.flags & (1 << 20)):
+                names = ["hypers", "chol+inv", "kx", "A+colsums", "lik", "At+GLS+Gm", "GB+GA+PmT", "zx grads", "sums+loss",
+                         "adamLS", "W+S+Wzz", "adamZ+m+scal", "predict"] + ["-"] * 15
             from gapro_amd import _lib as _l
             if (route == 4 or args.cluster_all) and not args.no_cluster:
                 names = ["kzz", "chol:diag(leader)", "chol:panel", "chol:trailing", "inverse", "kx", "fwd:colpart",
