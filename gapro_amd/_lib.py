@@ -138,6 +138,19 @@ SIGNATURES = {
     "gapro_pth_close": (None, [_P]),
     "gapro_pth_write": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(PthArray), C.POINTER(_P), C.c_int32]),
     "gapro_pth_last_error": (C.c_char_p, []),
+    # batch feeder of the gen_ps driver (gapro_amd/feeder.py holds the structs)
+    "gapro_feed_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gapro_feed_destroy": (None, [_P]),
+    "gapro_feed_last_error": (C.c_char_p, [_P]),
+    "gapro_feed_submit": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    "gapro_feed_close": (C.c_int, [_P]),
+    "gapro_feed_poll": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "gapro_feed_upload": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P, C.POINTER(C.c_int64)]),
+    "gapro_feed_batch_wait": (C.c_int, [_P, C.c_int64, _P]),
+    "gapro_feed_release_batch": (C.c_int, [_P, C.c_int64]),
+    "gapro_feed_export": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "gapro_feed_export_wait": (C.c_int, [_P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gapro_feed_export_error": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "gapro_scene_default_feats": (C.c_int, [_P, _P, C.c_int64, _P]),
     "gapro_scene_instance_boxes": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P,
                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -191,7 +204,7 @@ def load() -> C.CDLL:
         try:
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
         except AttributeError:
-            if os.path.abspath(LIB_PATH) == os.path.abspath(default) or not name.startswith(("gapro_pth_", "gapro_scene_")):
+            if os.path.abspath(LIB_PATH) == os.path.abspath(default) or not name.startswith(("gapro_pth_", "gapro_scene_", "gapro_feed_")):
                 raise
             if host_only is None:
                 host_only = C.CDLL(default)

@@ -460,6 +460,74 @@ int gapro_scene_instance_boxes(const double* h_xyz, const double* h_inst, const 
                                int32_t* n_boxes, int32_t* instance_num);
 
 /* ------------------------------------------------------------------------------------------
+ * Batch feeder of the gen_ps driver (host threads of the library's own; no Python objects, no GIL; csrc/feeder.hip).
+ * Replaces the per-scene host half of gen_ps.py:36-132: torch.load of the scene tuple and the superpoint ids (:45-46),
+ * the default features from the UN-aligned points (:55), the axis alignment (:58-69), getInstanceInfo (:71-77), the
+ * upload (:83-87), and on the way out the device -> host copies and torch.save of the 5-tuple (:126-132).
+ *
+ *   submit    scene / superpoint / alignment (/ feature) file paths, in the order the scenes are wanted
+ *   poll      wait until the next scenes of that order are loaded into pinned memory; how many, and the device bytes
+ *   upload    one asynchronous copy per scene into the caller's device slab on the feed's own stream; records out
+ *   batch_wait  make a stream wait for a batch's copies
+ *   export    label files: device -> host behind the caller's event, gapro_pth_write; export_wait collects them
+ *
+ * device < 0: host-only mode (gen_ps --dry_run): pageable memory, no copies; `upload` hands out host images and
+ * `export` takes host pointers.  Scenes the native reader does not handle come back with status GAPRO_ERR_UNSUPPORTED
+ * (the caller reads them its own way); a scene without instances has n_instances == 0.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gapro_feed gapro_feed;
+typedef struct gapro_feed_scene {
+  int32_t status;        /* gapro_status of the load */
+  int32_t n_points;      /* N */
+  int32_t n_instances;   /* instance boxes found (getInstanceInfo's non-empty ids) */
+  int32_t feat_dim;      /* D: 6 (xyz + rgb) or the width of the feature file */
+  /* byte offsets of the scene's arrays in the device slab of its upload (256-byte aligned):
+   * coords f64[N,3] (aligned), feats f32[N,D], spp i64[N], sem f64[N], inst f64[N] (the file's label arrays) */
+  int64_t off_coords, off_feats, off_spp, off_sem, off_inst;
+  const double* inst_box;  /* f64[n_instances,6] (min xyz, max xyz), inst_cls f64[n_instances], inst_vol f64[n_instances]: */
+  const double* inst_cls;  /* host memory of the feed, valid until the next gapro_feed_upload                            */
+  const double* inst_vol;
+  void* host_image;      /* host-only mode: base address the offsets are relative to (valid until release_batch) */
+} gapro_feed_scene;
+typedef struct gapro_feed_out {
+  const void* d_sem;     /* i32[n_points] */
+  const void* d_inst;    /* i32[n_points] */
+  const void* d_prob;    /* f32[n_points] */
+  const void* d_mu;      /* f32[n_mu] */
+  const void* d_var;     /* f32[n_mu] */
+  int64_t n_points, n_mu;
+  const char* path;      /* label file to write (atomically) */
+} gapro_feed_out;
+/* n_threads loader / writer threads; budget_bytes caps the pinned memory of scenes loaded but not yet uploaded (plus
+ * label files being written); default_feat_dim = 6 */
+int gapro_feed_create(int32_t device, int32_t n_threads, int64_t budget_bytes, int32_t default_feat_dim,
+                      gapro_feed** out);
+void gapro_feed_destroy(gapro_feed* f);
+const char* gapro_feed_last_error(const gapro_feed* f);
+/* feat_paths may be NULL (default features), and so may its entries */
+int gapro_feed_submit(gapro_feed* f, int32_t n, const char* const* scene_paths, const char* const* spp_paths,
+                      const char* const* align_paths, const char* const* feat_paths);
+/* no further submit: polls stop waiting for scenes that will never come */
+int gapro_feed_close(gapro_feed* f);
+/* Block until min_ready scenes at the head of the order are loaded (fewer when the feed is closed and runs out),
+ * timeout_ms passed (< 0: no limit); *n_ready = loaded scenes in a row from the head (<= max_scenes), *slab_bytes the
+ * device bytes their images need. */
+int gapro_feed_poll(gapro_feed* f, int32_t min_ready, int32_t max_scenes, int32_t timeout_ms, int32_t* n_ready,
+                    int64_t* slab_bytes);
+/* The next n loaded scenes: copies into d_slab (slab_bytes >= what poll reported for them), out[n], *batch_id. */
+int gapro_feed_upload(gapro_feed* f, int32_t n, void* d_slab, int64_t slab_bytes, gapro_feed_scene* out,
+                      int64_t* batch_id);
+int gapro_feed_batch_wait(gapro_feed* f, int64_t batch_id, void* stream);
+/* host-only mode: the images of a batch are no longer needed (device mode: recycles completed batches) */
+int gapro_feed_release_batch(gapro_feed* f, int64_t batch_id);
+/* Queue n label files.  ready_event (hipEvent_t or NULL): recorded by the caller behind the kernels that produce the
+ * arrays; they must stay valid until gapro_feed_export_wait has counted the scene. */
+int gapro_feed_export(gapro_feed* f, int32_t n, const gapro_feed_out* items, void* ready_event);
+/* wait until `until_done` label files (< 0: all queued so far) are written or failed */
+int gapro_feed_export_wait(gapro_feed* f, int64_t until_done, int32_t timeout_ms, int64_t* n_done, int64_t* n_failed);
+int gapro_feed_export_error(gapro_feed* f, int32_t index, char* buf, int32_t cap);
+
+/* ------------------------------------------------------------------------------------------
  * Inspection (tests): where a fit's trained parameters live in its workspace.  The measurement / self-test entry points
  * (gapro_debug_*) are NOT part of this library: include/gapro_hip_debug.h, libgapro_hip_debug.so.
  * ---------------------------------------------------------------------------------------- */

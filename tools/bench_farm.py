@@ -10,10 +10,11 @@ log-normal-sized stream scenes, one file set per scene) while it generates the r
 after the timed region; the result is the `gen_ps_farm` key of the bench line (never `value`).
 
 Every pass writes into a fresh label folder.  Pass 1 reads the `.pth` files as the dataset writer left them (page cache
-warm: the files were just written; a cold first pass additionally pays the disk), pass 2 the same again; with
---raw_cache a third pass maps the raw scene cache the second one wrote.  Rate = scenes / the slowest worker's own clock
-(generator ready -> last file written); start-up (interpreter, library load, loader pool) is reported apart, as is the
-wall clock of the whole command.  Prints one line starting with "JSON ".
+warm: the files were just written; a cold first pass additionally pays the disk), pass 2 the same again.  Rate = scenes
+/ the slowest worker's own clock (generator ready -> last file written); start-up (interpreter, library load) is
+reported apart, as is the wall clock of the whole command.  --share K adds the `share_1ofK` pass: ONE worker over every
+K-th scene of the cost-sorted list -- what one GPU of a K-GPU node gets from the claim queue -- with the wall clock from
+process start: the job a node really runs per GPU is that short.  Prints one line starting with "JSON ".
 """
 import argparse
 import json
@@ -28,9 +29,12 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def one_pass(data_root, save, devices, batch, raw_cache, extra):
+def one_pass(data_root, save, devices, batch, extra, files=None):
+    """files: run over this subset of the scene list (a directory of links is built for it)"""
+    if files is not None:
+        data_root = subset_root(data_root, files, save + ".subset")
     cmd = [sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", save, "--data_root", data_root, "--batch_scenes",
-           str(batch), "--devices", devices, "--raw_cache", raw_cache or "none"] + extra
+           str(batch), "--devices", devices] + extra
     t = time.time()
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, GAPRO_DRIVER_TIMES="1"))
     wall = time.time() - t
@@ -55,12 +59,30 @@ def one_pass(data_root, save, devices, batch, raw_cache, extra):
                written_files=sum(len([f for f in os.listdir(d) if f.endswith(".pth")])
                                  for d in (save, save + ".DRY_RUN") if os.path.isdir(d)))
     if steady:  # all workers' scenes after their first batch / the slowest worker's time after its first batch
-        out["steady_scenes_per_s"] = round(sum(b for _, b, _ in steady) / max(c for _, _, c in steady), 2)
+        out["steady_scenes_per_s"] = round(sum(b for _, b, _ in steady) / max(max(c for _, _, c in steady), 1e-3), 2)
     if io:
         out["loader_threads"], out["loader_processes"], out["file_io"] = int(io[0][0]), int(io[0][1]), io[0][2].strip()
     if r.returncode not in (0, 3):
         out["error"] = (r.stderr or txt)[-600:]
     return out
+
+
+def subset_root(data_root, files, dst):
+    """A dataset root holding links to the given scenes only (train/, superpoints/, scans_transform/, scannet_planes/)."""
+    for sub in ("train", "superpoints", "scans_transform", "scannet_planes"):
+        os.makedirs(os.path.join(dst, sub), exist_ok=True)
+    for f in files:
+        scan = f[:12]
+        os.symlink(os.path.realpath(os.path.join(data_root, "train", f)), os.path.join(dst, "train", f))
+        os.symlink(os.path.realpath(os.path.join(data_root, "superpoints", scan + ".pth")),
+                   os.path.join(dst, "superpoints", scan + ".pth"))
+        os.makedirs(os.path.join(dst, "scans_transform", scan), exist_ok=True)
+        os.symlink(os.path.realpath(os.path.join(data_root, "scans_transform", scan, scan + ".txt")),
+                   os.path.join(dst, "scans_transform", scan, scan + ".txt"))
+        pj = os.path.join(data_root, "scannet_planes", scan + ".json")
+        if os.path.exists(pj):
+            os.symlink(os.path.realpath(pj), os.path.join(dst, "scannet_planes", scan + ".json"))
+    return dst
 
 
 def main():
@@ -69,7 +91,8 @@ def main():
     ap.add_argument("--devices", default="0")
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--raw_cache", action="store_true", help="a further pass over the raw scene cache (opt-in of gen_ps)")
+    ap.add_argument("--share", type=int, default=0, help="K: a further pass of ONE worker over every K-th scene of the "
+                    "cost-sorted list (the share of one GPU of a K-GPU node)")
     ap.add_argument("--gen-ps-args", default="", help="extra arguments for gen_ps, space separated")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
@@ -86,17 +109,23 @@ def main():
                                                                  total_GB=round(sum(sizes) / 1e9, 2)),
                batch_scenes=args.batch, passes=[])
     try:
-        cache = os.path.join(out_root, "rawcache")
         for k in range(args.passes):
-            p = one_pass(args.data_root, os.path.join(out_root, "labels%d" % k), args.devices, args.batch,
-                         cache if (args.raw_cache and k == args.passes - 1) else None, extra)
+            p = one_pass(args.data_root, os.path.join(out_root, "labels%d" % k), args.devices, args.batch, extra)
             p["source"] = ".pth files (pass %d%s)" % (k + 1, ": page cache as the dataset writer left it" if k == 0 else "")
             res["passes"].append(p)
             print("pass %d: %s" % (k + 1, json.dumps(p)), file=sys.stderr, flush=True)
-        if args.raw_cache:
-            p = one_pass(args.data_root, os.path.join(out_root, "labels_raw"), args.devices, args.batch, cache, extra)
-            p["source"] = "raw scene cache written by the previous pass (gen_ps --raw_cache)"
-            res["passes"].append(p)
+        if args.share > 1:
+            # the claim queue hands out the cost-sorted list (largest file first); one of K equally fast workers ends
+            # up with about every K-th scene of it
+            order = [f for _, f in sorted(zip(sizes, files), reverse=True)]
+            mine = order[::args.share]
+            p = one_pass(args.data_root, os.path.join(out_root, "labels_share"), args.devices.split(",")[0], args.batch,
+                         extra, files=mine)
+            p["what"] = ("ONE worker over every %d-th scene of the cost-sorted list (%d scenes): the job of one GPU of a "
+                         "%d-GPU node; wall_s is the whole command from process start" % (args.share, len(mine), args.share))
+            p["projected_node_scenes_per_s"] = round(len(files) / p["wall_s"], 1) if p["wall_s"] > 0 else None
+            res["share_1of%d" % args.share] = p
+            print("share 1/%d: %s" % (args.share, json.dumps(p)), file=sys.stderr, flush=True)
     finally:
         if not args.keep:
             shutil.rmtree(out_root, ignore_errors=True)
