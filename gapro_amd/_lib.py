@@ -141,6 +141,7 @@ SIGNATURES = {
     # batch feeder of the gen_ps driver (gapro_amd/feeder.py holds the structs)
     "gapro_feed_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "gapro_feed_destroy": (None, [_P]),
+    "gapro_feed_detach": (None, [_P]),
     "gapro_feed_last_error": (C.c_char_p, [_P]),
     "gapro_feed_submit": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "gapro_feed_close": (C.c_int, [_P]),

@@ -470,8 +470,7 @@ int gapro_feed_create(int32_t device, int32_t n_threads, int64_t budget_bytes, i
   return GAPRO_OK;
 }
 
-void gapro_feed_destroy(gapro_feed* f) {
-  if (!f) return;
+static void feed_stop_threads(gapro_feed* f) {
   {
     std::lock_guard<std::mutex> lk(f->mu);
     f->stop = true;
@@ -481,6 +480,16 @@ void gapro_feed_destroy(gapro_feed* f) {
   f->cv_ready.notify_all();
   f->cv_export.notify_all();
   for (std::thread& t : f->threads) t.join();
+  f->threads.clear();
+}
+
+void gapro_feed_detach(gapro_feed* f) {
+  if (f) feed_stop_threads(f);  // the staging memory (and this object) stay until the process ends
+}
+
+void gapro_feed_destroy(gapro_feed* f) {
+  if (!f) return;
+  feed_stop_threads(f);
   {
     std::lock_guard<std::mutex> lk(f->mu);
     if (use_gpu(f)) reap_batches(f, true);

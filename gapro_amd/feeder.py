@@ -137,9 +137,12 @@ class NativeFeeder:
                 out.append(buf.value.decode(errors="replace"))
         return out
 
-    def destroy(self):
+    def destroy(self, process_is_exiting: bool = False):
         if self.handle:
-            self.lib.gapro_feed_destroy(self.handle)
+            if process_is_exiting:
+                self.lib.gapro_feed_detach(self.handle)
+            else:
+                self.lib.gapro_feed_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

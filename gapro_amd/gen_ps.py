@@ -215,6 +215,7 @@ _DEVICE_DTYPES = {"coords_float": torch.float64, "mask_feats": torch.float32, "s
 
 _T_IMPORT = time.time()
 _T0_PERF = [0.0]
+_EXIT_AFTER_MAIN = [False]  # set by `python -m gapro_amd.gen_ps`: teardown that only returns memory is left to the exit
 
 
 def _chunks(filenames, args, queue):
@@ -251,7 +252,7 @@ class Worker:
     The FIRST batch is whatever has been loaded `first_window` seconds after the start (at least `first_min` scenes):
     the generator starts after ~0.4 s instead of after a full batch, and the reads are a batch ahead from then on."""
 
-    first_window = 0.30
+    first_window = 0.20
     first_min = 16
 
     def __init__(self, filenames, args, device_index, dry=False):
@@ -555,6 +556,11 @@ class Worker:
                 self._run_dry()
             else:
                 self._prealloc()
+                # (Pipeline.warmup() here -- a small launch through every kernel while the first batch loads -- was tried:
+                # it queues behind the workspace allocation, whose hipMalloc in turn holds up the loaders' pinned
+                # allocations: first batch of 16 scenes at 0.72 s instead of 185 at 0.28 s.  GAPRO_WARMUP=1 for A/B.)
+                if os.environ.get("GAPRO_WARMUP"):
+                    self.pipe.warmup()
                 stream = self._host_only_stream(self.batches()) if host_only else self.pipe.run_stream(self.batches())
                 for outs in stream:
                     if self.t_first is None:
@@ -564,6 +570,7 @@ class Worker:
                     self._export(scenes, jobs, outs, slab)
                     self.spent["export"] += time.time() - t
             n_done, n_failed = self.feeder.export_wait(-1, -1)
+            t_written = time.time()  # the last label file is on disk: the job is done, what follows is teardown
             for msg in self.feeder.export_errors(n_failed):
                 print("[gen_ps] a label file could not be written: %s" % msg, file=sys.stderr)
                 self.failed += 1
@@ -575,8 +582,12 @@ class Worker:
             th = getattr(self, "_prealloc_thread", None)
             if th is not None:
                 th.join()
-            self.feeder.destroy()
-        dt = time.time() - t0
+            t_fin = time.time()
+            self.feeder.destroy(process_is_exiting=_EXIT_AFTER_MAIN[0])
+        dt = t_written - t0
+        if os.environ.get("GAPRO_DRIVER_TIMES"):
+            print("[gen_ps] teardown after the last file: %.2f s (%.2f s of it the feeder's pinned memory)"
+                  % (time.time() - t_written, time.time() - t_fin))
         dev_i, done, failed = self.device_index, self.done, self.failed
         print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.2f s (%.2f scenes/s)"
               % (dev_i, done, failed, dt, done / dt if dt > 0 else 0.0))
@@ -750,4 +761,5 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    _EXIT_AFTER_MAIN[0] = True
     sys.exit(main())

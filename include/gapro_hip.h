@@ -503,6 +503,9 @@ typedef struct gapro_feed_out {
 int gapro_feed_create(int32_t device, int32_t n_threads, int64_t budget_bytes, int32_t default_feat_dim,
                       gapro_feed** out);
 void gapro_feed_destroy(gapro_feed* f);
+/* Stop the threads and leave everything else to the end of the process: unpinning the staging pool of a worker takes
+ * ~0.6 s (8 GB), which a process that is about to exit need not spend.  The handle must not be used afterwards. */
+void gapro_feed_detach(gapro_feed* f);
 const char* gapro_feed_last_error(const gapro_feed* f);
 /* feat_paths may be NULL (default features), and so may its entries */
 int gapro_feed_submit(gapro_feed* f, int32_t n, const char* const* scene_paths, const char* const* spp_paths,
