@@ -126,3 +126,30 @@ def barrier_and_max(elapsed: float, device=None) -> float:
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def effective_cpus() -> int:
+    """CPUs this process can really use: the affinity mask, capped by the cgroup CPU quota (cpu.max of cgroup v2,
+    cfs_quota_us / cfs_period_us of v1).  A container often sees every core of its host (os.cpu_count() = 256 on the
+    MI355X boxes of this pool) behind a quota of a few (16 there): threads beyond the quota are not parallelism, they
+    are throttling -- tools/host_probe.py shows compute scaling stop at 16 threads and fall beyond."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)

@@ -28,7 +28,8 @@ resume mechanism, gen_ps.py:39-41) and every scene is written as the same 5-tupl
     --broadcast_mu_var     write mu/var at point length (what the released data loaders index)
     --loader_threads T     threads of the library's batch feeder (csrc/feeder.hip) that read scenes from disk two
                            batches ahead, preprocess and upload them, and write the label files (default -1 =
-                           min(16, physical cores / (2 W)) per worker for W workers, at least 4).  Round 5: the whole
+                           min(16, usable CPUs / W - 1) per worker for W workers, at least 2; "usable" honours the
+                           cgroup CPU quota, not just the core count the container sees).  Round 5: the whole
                            per-scene host chain -- native file decoding (gapro_pth_*), default features, axis alignment,
                            GT boxes, pinned staging, asynchronous upload; device -> host and the label file on the way
                            out -- runs on these C++ threads; Python moves batches.  (Rounds 1-4: loader processes with a
@@ -63,7 +64,7 @@ import numpy as np
 import torch
 
 from . import _lib, pth_io
-from .dist_utils import ClaimQueue, pending_scenes, shard_scenes, shard_scenes_lpt
+from .dist_utils import ClaimQueue, effective_cpus, pending_scenes, shard_scenes, shard_scenes_lpt
 from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device, getInstanceInfo_native
 from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
@@ -262,10 +263,11 @@ class Worker:
 
         self.args, self.dry, self.device_index = args, dry, device_index
         self.n_workers = max(1, int(getattr(args, "n_workers", 1)))  # GPU workers sharing this host (--devices)
-        phys = max(1, (os.cpu_count() or 2) // 2)
         n_threads = int(getattr(args, "loader_threads", -1))
         if n_threads <= 0:
-            n_threads = min(16, max(4, phys // (2 * self.n_workers)))
+            # the CPUs this container may really use (affinity AND cgroup quota: 16 on the boxes of this pool, which show
+            # 256 cores), shared by the W workers of the host; one is left to the worker's own Python thread
+            n_threads = min(16, max(2, effective_cpus() // self.n_workers - 1))
         self.n_threads = n_threads
         self.filenames = filenames
         self.queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None

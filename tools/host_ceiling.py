@@ -9,8 +9,8 @@ over the arrays (the copy into the pinned staging buffer), and the write of the 
 an emulation of the loader-process pool and found the host capped at 270 .. 350 scenes/s by unpickling.  Round 4: the
 driver itself has a GPU-less mode -- `gen_ps --devices 0,..,W-1 --dry_run` runs W real worker processes (claim queue,
 loader threads, native reader / writer, result files; all-zero stand-in outputs) -- and this tool times exactly that,
-so the figure is the product's own host code, not a model of it.  `--torch-io` also times the same workers with
-GAPRO_NATIVE_PTH=0 (torch.load / torch.save under the GIL, the round-1..3 I/O) for the before / after.
+so the figure is the product's own host code, not a model of it.  Round 5: those workers run the library's batch
+feeder in its host-only mode (the same C++ loader / writer threads as with a GPU, pageable instead of pinned staging).
 
 It deliberately has no GPU in it: on the 1-GPU bench box eight real workers would time-share ONE device.
 Prints per W: delivered scenes/s (all workers together; slowest worker's clock, start-up apart) and the projected
@@ -46,7 +46,7 @@ def measure(workers, data, out_root, native=True, tag="", threads=-1):
     shutil.rmtree(save + ".DRY_RUN", ignore_errors=True)
     shutil.rmtree(save, ignore_errors=True)
     row = {"workers": workers, "loader_threads_per_worker": int(thr[0]) if thr else None, "source": "pth",
-           "file_io": "native (gapro_pth_*)" if native else "torch.load / torch.save",
+           "file_io": "native feeder (gapro_feed_*)",
            "scenes_per_s": round(n / slow, 1) if slow > 0 else 0.0, "slowest_worker_s": round(slow, 2),
            "startup_s": round(max(start, default=0.0), 2), "wall_s": round(wall, 2), "scenes": n}
     if r.returncode != 0:
@@ -62,7 +62,6 @@ def main():
     ap.add_argument("--unique", type=int, default=16, help="scenes generated")
     ap.add_argument("--distinct", type=int, default=512, help="scenes with files of their own (copies of the generated ones)")
     ap.add_argument("--gpu-rate", type=float, default=340.0, help="scenes/s one GPU takes (resident inputs)")
-    ap.add_argument("--torch-io", action="store_true", help="also the round-1..3 I/O (GAPRO_NATIVE_PTH=0)")
     ap.add_argument("--threads", type=int, default=-1, help="loader threads per worker (-1 = gen_ps's own choice)")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
@@ -94,7 +93,7 @@ def main():
         measure(1, data, root, True, "warm")  # page cache, code objects
         rows = []
         for w in [int(x) for x in args.workers.split(",") if x]:
-            for native in ((True, False) if args.torch_io else (True,)):
+            for native in (True,):
                 r = measure(w, data, root, native, "" if native else "t", args.threads)
                 r["projected_farm_scenes_per_s"] = round(min(w * args.gpu_rate, r["scenes_per_s"]), 1)
                 rows.append(r)
