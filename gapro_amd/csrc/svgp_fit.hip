@@ -44,6 +44,7 @@
 
 #include "common.h"
 #include "fit_layout.h"
+#include "fit_math.h"
 #include "epilogue.h"
 #ifdef GAPRO_DEBUG_TU
 #include "../../include/gapro_hip_debug.h"
@@ -1466,7 +1467,8 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
 template <int DMAX, bool ZX, int U, int DC>
 __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const gd* Gm, const gd* GTm,
                                                  const gd* GKXT, double s, double inv_l2, double step_size,
-                                                 double bc2s, ldsd* red, double* gs_out, double* gl_out) {
+                                                 double bc2s, ldsd* red, double* gs_out, double* gl_out,
+                                                 const ldsd* zx_rows = nullptr) {
   const Fit& f = g_sh.f;
   const int Mp = f.Mp, M = f.M, D = DC ? DC : f.D;
   const ColMap cm = col_map(Mp);
@@ -1592,7 +1594,7 @@ __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const
             double sacc = 0.0;
             for (int g = 0; g < cm.G; ++g) sacc += red[e * NT + g * Mp + threadIdx.x];
             const size_t zi = (size_t)threadIdx.x * D + d;
-            if (!ZX) sacc += f.gZ[zi];  // zx part accumulated by the strip loop (raw sums)
+            if (!ZX) sacc += zx_rows ? zx_rows[threadIdx.x * 8 + d] : f.gZ[zi];  // zx part of the strip loop (raw sums)
             const double grad = -inv_l2 * sacc;
             f.gZ[zi] = grad;
             const double m1 = b1 * f.mZ[zi] + (1.0 - b1) * grad;
@@ -2329,7 +2331,8 @@ inline __host__ __device__ int strip_region_doubles(int Mp) {
 }
 inline __host__ __device__ long long strip_lds_bytes(int m, int d) {
   const int Mp = gapro_pad_m(m, d);
-  return 8LL * (2LL * d * Mp + strip_region_doubles(Mp) + 3 * NT + Mp + 4 * SW + 32);
+  // (+ 8 Mp: the per-row kernel-gradient sums of the fused zx pass, narrow features only)
+  return 8LL * (2LL * d * Mp + strip_region_doubles(Mp) + 3 * NT + Mp + 4 * SW + 32 + (d <= 8 ? 8 * Mp : 0));
 }
 inline __host__ __device__ bool strip_ok(int m, int d) {
   return gapro_pad_m(m, d) <= kStripMaxMp && d <= 32 && strip_lds_bytes(m, d) <= kMaxDynLds;
@@ -2629,6 +2632,67 @@ __device__ __noinline__ void adam_ls_tiles(d4 g0, d4 g1, d4 g2, d4 g3, d4 g4, do
 }
 #endif
 
+// Kernel gradients through KX, fused into the strip loop (round 5; narrow features): while G_KX[:, n0 .. n0 + 32) is in
+// LDS, W_zx = G_KX o KX is formed element by element (kernel value recomputed from the staged points, as the gradient
+// pass after the loop did) and summed into per-row accumulators zacc[k][0..5] = sum_n W[k][n] (Z_k - X_n),
+// [6] = sum_n G_KX E, [7] = sum_n W d2.  Four adjacent lanes share a row (eight columns each) and are combined by two
+// DPP hops.  Before: the strip was stored as G_KX^T rows to the workspace (7 % of a step) and read back by the
+// gradient pass, whose zx half was another ~4 % of memory round trips.
+template <int DC>
+__device__ __noinline__ void strip_kgrad_zx(const ldsd* Gs, const ldsd* Zt, const ldsd* Xpts, ldsd* zacc, int n0, int nc,
+                                            double s, double inv_l2) {
+  const Fit& f = g_sh.f;
+  const int Mp = f.Mp, M = f.M;
+  constexpr int D = DC;
+  const int row = threadIdx.x >> 2, cg = threadIdx.x & 3;
+  double acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.0;
+  double gs = 0.0, gl = 0.0;
+  if (row < M) {
+    double zk[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) zk[d] = Zt[d * Mp + row];
+#pragma unroll 2
+    for (int j = 0; j < SW / 4; ++j) {
+      const int n = cg * (SW / 4) + j;
+      if (n < nc) {
+        double t[D];
+        double d2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          t[d] = zk[d] - Xpts[d * Mp + n0 + n];
+          d2 += t[d] * t[d];
+        }
+        const double e = KG_EXP(-0.5 * inv_l2 * d2);
+        const double g = Gs[row * RS + n];
+        const double wx = g * s * e;
+        gs += g * e;
+        gl += wx * d2;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] += wx * t[d];
+      }
+    }
+  }
+  using gapro_fit_math::dpp_mov;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    acc[d] += dpp_mov<0xB1>(acc[d]);  // quad_perm(1, 0, 3, 2)
+    acc[d] += dpp_mov<0x4E>(acc[d]);  // quad_perm(2, 3, 0, 1)
+  }
+  gs += dpp_mov<0xB1>(gs);
+  gs += dpp_mov<0x4E>(gs);
+  gl += dpp_mov<0xB1>(gl);
+  gl += dpp_mov<0x4E>(gl);
+  if (cg == 0 && row < M) {
+    ldsd* z = zacc + row * 8;
+#pragma unroll
+    for (int d = 0; d < D; ++d) z[d] += acc[d];
+    z[6] += gs;
+    z[7] += gl;
+  }
+}
+
 template <int DMAX, int DC>
 __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd* region,
                                const gapro_fit_desc& desc, float* __restrict__ o_probs,
@@ -2650,6 +2714,9 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
   ldsd* var_s = mu_s + SW;
   ldsd* gmu_s = var_s + SW;
   ldsd* gv_s = gmu_s + SW;
+  // narrow features (the reference's xyz + rgb): the zx kernel gradients are summed inside the strip loop
+  constexpr bool kFuseKg = DC > 0 && DC <= 6 && !(DMAX > 8);
+  ldsd* zacc = gv_s + SW + 32;  // [Mp][8], behind the alignment slack of the vectors
   gd* LS = f.mat[B_LS];
   gd* LST = f.mat[B_LST];
 #if GAPRO_NT < 320
@@ -2728,6 +2795,8 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
     const bool last = step == opt.training_iter;
     factorize();
     for (int i = threadIdx.x; i < Mp; i += NT) m_s[i] = vm[i];
+    if (kFuseKg)
+      for (int i = threadIdx.x; i < 8 * Mp; i += NT) zacc[i] = 0.0;
     d4 gls[kAccTiles], gl[kAccTiles];
 #pragma unroll
     for (int q = 0; q < kAccTiles; ++q) {
@@ -2807,11 +2876,16 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       }
       __syncthreads();
       stamp(15);
-      // ---- G_KX^T rows of the strip -> global (the only intermediate that leaves the chip): the kernel
-      // gradient pass after the loop reads G_KX[k][n] as GKXT[n][k], contiguous in k
-      for (int idx = threadIdx.x; idx < Mp * nc; idx += NT) {
-        const int n = idx / Mp, k = idx - n * Mp;
-        GKXT[(size_t)(n0 + n) * Mp + k] = Bs[k * RS + n];
+      if constexpr (kFuseKg) {
+        // ---- kernel gradients through KX while the G_KX strip is on chip (nothing leaves it any more)
+        strip_kgrad_zx<DC>(Bs, Zt, Pt, zacc, n0, nc, s, inv_l2);
+      } else {
+        // ---- G_KX^T rows of the strip -> global (the only intermediate that leaves the chip): the kernel
+        // gradient pass after the loop reads G_KX[k][n] as GKXT[n][k], contiguous in k
+        for (int idx = threadIdx.x; idx < Mp * nc; idx += NT) {
+          const int n = idx / Mp, k = idx - n * Mp;
+          GKXT[(size_t)(n0 + n) * Mp + k] = Bs[k * RS + n];
+        }
       }
       __syncthreads();
       stamp(18);
@@ -2983,8 +3057,17 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       tail(std::integral_constant<int, 1>());
     stamp(13);
     double g_s, g_l;
-    kernel_grads_adam_z<DMAX, true, (DMAX <= 8 ? 8 : 2), DC>(Zt, Pt, Gb, GTb, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s,
-                                                         &g_l);
+    if constexpr (kFuseKg) {
+      const double gs_zx = block_sum((int)threadIdx.x < M ? zacc[threadIdx.x * 8 + 6] : 0.0);
+      const double gl_zx = block_sum((int)threadIdx.x < M ? zacc[threadIdx.x * 8 + 7] : 0.0);
+      kernel_grads_adam_z<DMAX, false, 8, DC>(Zt, Pt, Gb, GTb, GKXT, s, inv_l2, step_size, bc2s, scratch, &g_s, &g_l,
+                                              zacc);
+      g_s += gs_zx;
+      g_l += gl_zx;
+    } else {
+      kernel_grads_adam_z<DMAX, true, (DMAX <= 8 ? 8 : 2), DC>(Zt, Pt, Gb, GTb, GKXT, s, inv_l2, step_size, bc2s, scratch,
+                                                           &g_s, &g_l);
+    }
     g_s += gv_sum;
     g_l /= (ell * ell * ell);
     stamp(14);

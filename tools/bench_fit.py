@@ -191,7 +191,7 @@ def main():
             if not args.force_staged and route in (0, 3):
                 names = ["chol:update", "chol:rest", "inv", "s:fill", "s:A", "chol:diag", "post-strips", "s:B",
                          "GLS+adam", "s:meanvar", "s:lik", "s:scale+GLSacc", "s:GA", "tail", "kgrads+adamZ",
-                         "s:GKX+PmAcc", "adam", "predict", "s:GKXTstore", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
+                         "s:GKX+PmAcc", "adam", "predict", "s:kgrad-zx (D = 6) / GKXTstore", "misc", "kg:loop", "kg:sums", "(diag:factor", "(diag:inverse",
                          "(diag:stores", "x25", "x26", "x27"]
             if route == 5 and not (args.flags & (1 << 20)):
                 names = ["hypers", "chol+inv", "kx", "A+colsums", "lik", "At+GLS+Gm", "GB+GA+PmT", "zx grads", "sums+loss",
