@@ -138,6 +138,7 @@ SIGNATURES = {
     "gapro_pth_close": (None, [_P]),
     "gapro_pth_write": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(PthArray), C.POINTER(_P), C.c_int32]),
     "gapro_pth_last_error": (C.c_char_p, []),
+    "gapro_pth_decoder": (C.c_char_p, []),
     # batch feeder of the gen_ps driver (gapro_amd/feeder.py holds the structs)
     "gapro_feed_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "gapro_feed_destroy": (None, [_P]),

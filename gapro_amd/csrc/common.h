@@ -27,6 +27,10 @@ struct gapro_ctx {
   hipStream_t fit_stream[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_join[kFitStreams] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_gate = nullptr;  // end of the cluster kernel: the two-per-CU staged launch starts behind it
+  // end of the last cluster kernel that used each half of the block-table / barrier-counter staging: the next launch that
+  // reuses a half orders its upload and its counter reset behind it, whatever streams the callers use
+  hipEvent_t ev_clus_half[2] = {nullptr, nullptr};
+  bool clus_half_used[2] = {false, false};
   // cluster kernel: block table staging (pinned host + device) and the clusters' barrier counters, grown on demand
   void* h_cl_stage = nullptr;
   void* d_cl_stage = nullptr;

@@ -62,6 +62,11 @@ int gapro_ctx_create(int device, gapro_ctx** out) {
       gapro_ctx_destroy(ctx);
       return GAPRO_ERR_HIP;
     }
+  if (hipEventCreateWithFlags(&ctx->ev_clus_half[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_clus_half[1], hipEventDisableTiming) != hipSuccess) {
+    gapro_ctx_destroy(ctx);
+    return GAPRO_ERR_HIP;
+  }
   if (hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming) != hipSuccess) {
     gapro_ctx_destroy(ctx);
     return GAPRO_ERR_HIP;
@@ -80,6 +85,8 @@ void gapro_ctx_destroy(gapro_ctx* ctx) {
     if (ctx->fit_stream[k]) (void)hipStreamDestroy(ctx->fit_stream[k]);
   }
   if (ctx->ev_gate) (void)hipEventDestroy(ctx->ev_gate);
+  for (int k = 0; k < 2; ++k)
+    if (ctx->ev_clus_half[k]) (void)hipEventDestroy(ctx->ev_clus_half[k]);
   if (ctx->h_cl_stage) (void)hipHostFree(ctx->h_cl_stage);
   if (ctx->d_cl_stage) (void)hipFree(ctx->d_cl_stage);
   if (ctx->d_cl_ctl) (void)hipFree(ctx->d_cl_ctl);

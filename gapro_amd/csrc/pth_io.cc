@@ -97,13 +97,15 @@ long long decode_scalar(const unsigned char* src, long long n, unsigned char* ds
 #if defined(__x86_64__)
 // 64 input bytes per iteration: lead bytes (>= 0xC0) are dropped with vpcompressb, a byte that follows 0xC3 gets
 // + 0x40 (0xC2 leaves its continuation byte as it is), the last byte's "was a lead / was 0xC3" carries into the next
-// block.  Validation in mask arithmetic: continuation bytes are exactly the successors of lead bytes, and no byte is
-// >= 0xC4.
+// block.  Validation in mask arithmetic: continuation bytes are exactly the successors of lead bytes, and the only
+// lead bytes are 0xC2 and 0xC3 (>= 0xC4: beyond latin-1; 0xC0 / 0xC1: overlong forms, which decode_scalar, decode_bmi2
+// and Python's UTF-8 decoder reject -- ADVICE r04: this tier read 0xC0 0x80 as the byte 0x80).
 __attribute__((target("avx512f,avx512bw,avx512vbmi2,popcnt"))) long long decode_avx512(const unsigned char* src,
                                                                                       long long n, unsigned char* dst,
                                                                                       long long dst_cap) {
   const __m512i vC0 = _mm512_set1_epi8((char)0xC0), vC3 = _mm512_set1_epi8((char)0xC3);
   const __m512i vC4 = _mm512_set1_epi8((char)0xC4), v80 = _mm512_set1_epi8((char)0x80);
+  const __m512i vC2 = _mm512_set1_epi8((char)0xC2);
   const __m512i v40 = _mm512_set1_epi8(0x40);
   unsigned char* d = dst;
   unsigned char* dend = dst + dst_cap;
@@ -116,7 +118,7 @@ __attribute__((target("avx512f,avx512bw,avx512vbmi2,popcnt"))) long long decode_
     const unsigned long long cont = hi & ~lead;
     const unsigned long long c3 = _mm512_cmpeq_epi8_mask(v, vC3);
     const unsigned long long after_lead = (lead << 1) | carry_lead;
-    bad |= (cont ^ after_lead) | _mm512_cmpge_epu8_mask(v, vC4);
+    bad |= (cont ^ after_lead) | _mm512_cmpge_epu8_mask(v, vC4) | (lead & ~_mm512_cmpge_epu8_mask(v, vC2));
     const unsigned long long after_c3 = (c3 << 1) | carry_c3;
     const __m512i fixed = _mm512_mask_add_epi8(v, after_c3, v, v40);
     const unsigned long long keep = ~lead;
@@ -191,19 +193,30 @@ __attribute__((target("bmi2,popcnt"))) long long decode_bmi2(const unsigned char
 }
 #endif
 
+const char* g_decoder_name = "scalar";
 decode_fn pick_decoder() {
   // GAPRO_PTH_DECODER = scalar | bmi2 | avx512 pins a tier (tests run every tier the CPU has)
   const char* force = getenv("GAPRO_PTH_DECODER");
   const std::string want = force ? force : "";
-  if (want == "scalar") return decode_scalar;
+  if (want == "scalar") {
+    g_decoder_name = "scalar";
+    return decode_scalar;
+  }
 #if defined(__x86_64__)
   __builtin_cpu_init();
   const bool has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
                       __builtin_cpu_supports("avx512vbmi2");
   const bool hasbmi = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt");
-  if (has512 && want != "bmi2") return decode_avx512;
-  if (hasbmi) return decode_bmi2;
+  if (has512 && want != "bmi2") {
+    g_decoder_name = "avx512";
+    return decode_avx512;
+  }
+  if (hasbmi) {
+    g_decoder_name = "bmi2";
+    return decode_bmi2;
+  }
 #endif
+  g_decoder_name = "scalar";
   return decode_scalar;
 }
 
@@ -588,6 +601,11 @@ struct gapro_pth_file {
 extern "C" {
 
 const char* gapro_pth_last_error(void) { return t_err.c_str(); }
+
+const char* gapro_pth_decoder(void) {
+  (void)pick_decoder();
+  return g_decoder_name;
+}
 
 void gapro_pth_close(gapro_pth_file* f) {
   if (!f) return;

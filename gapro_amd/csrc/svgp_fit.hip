@@ -3537,7 +3537,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
   }
   // cluster kernel: block table and barrier counters go up on `stream` too, so that after the synchronisation below the
   // kernel is the first thing its stream has to do
-  int cl_blocks = 0, cl_members = 0;
+  int cl_blocks = 0, cl_members = 0, cl_par = 0;
   char* cl_d_half = nullptr;
   unsigned* cl_ctl_half = nullptr;
   if (!clus.empty()) {
@@ -3553,6 +3553,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
     // (the device copies alternate the same way, so that two launches issued from different streams -- debug bit 1
     // puts the kernels on the caller's stream -- never share a block table or a barrier counter)
     const size_t par = ctx->cl_parity & 1;
+    cl_par = (int)par;
+    // this half's previous user may still be running on another stream (overlapping launches, several caller streams):
+    // the upload and the counter reset below wait for it
+    if (ctx->clus_half_used[par]) GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_clus_half[par], 0));
     char* h_half = (char*)ctx->h_cl_stage + par * (ctx->cl_stage_bytes / 2);
     cl_d_half = (char*)ctx->d_cl_stage + par * (ctx->cl_stage_bytes / 2);
     cl_ctl_half = ctx->d_cl_ctl + par * ctx->cl_ctl_fits * 32;
@@ -3602,6 +3606,8 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                                             d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss);
     if (rc != GAPRO_OK) return gapro_fail(ctx, rc, "gapro_svgp_fit_batch: cluster kernel launch failed");
     if (tm) GAPRO_HIP_CHECK(ctx, hipEventRecord(tm->ev[7], s_clus));
+    GAPRO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_clus_half[cl_par], s_clus));
+    ctx->clus_half_used[cl_par] = true;
     // gate of the two-per-CU staged launch (below): policy 2 = always behind the cluster kernel (default), 1 = only when
     // the cluster's members fit the GPU at once, 0 = never (GAPRO_STAGED_GATE; debug bit 19 = never)
     static int gate_policy = -1;

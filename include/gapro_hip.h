@@ -447,6 +447,9 @@ void gapro_pth_close(gapro_pth_file* f);
 int gapro_pth_write(const char* path, int32_t n_arrays, const gapro_pth_array* descs, const void* const* h_data,
                     int32_t as_tuple);
 const char* gapro_pth_last_error(void);
+/* which UTF-8 -> byte transcoder this process uses: "avx512" (VBMI2), "bmi2" or "scalar" (GAPRO_PTH_DECODER pins one;
+ * a tier the CPU lacks falls back to the next) */
+const char* gapro_pth_decoder(void);
 /* The reference's default features (gen_ps.py:55: np.concatenate([xyz, rgb], -1) of the UN-aligned coordinates, uploaded
  * as float32 at :84): h_feats[n][6] = float32 of [xyz | rgb], one pass on the host. */
 int gapro_scene_default_feats(const double* h_xyz, const double* h_rgb, int64_t n_points, float* h_feats);

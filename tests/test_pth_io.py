@@ -154,6 +154,51 @@ def test_damaged_payload_is_an_error_not_garbage(tmp_path):
         pth_io.load_arrays(p)
 
 
+def test_malformed_utf8_is_rejected_by_every_decoder_tier(tmp_path):
+    """the AVX-512 tier accepted the overlong lead bytes 0xC0 / 0xC1 (0xC0 0x80 came out as 0x80) where the
+    scalar and BMI2 tiers -- and Python's own decoder, i.e. torch.load -- reject them.  Every tier this CPU has, in a
+    process of its own: overlong leads, a lead beyond latin-1, a stray continuation byte, a lead with no continuation;
+    in the first 64-byte block and in the scalar tail.  A tier the CPU lacks is skipped, not aliased."""
+    a = np.concatenate([np.full(200, 0x85, np.uint8), np.arange(7, dtype=np.uint8)])  # 0x85 -> C2 85
+    p = str(tmp_path / "ok.pth")
+    torch.save(a, p)
+    raw = bytearray(open(p, "rb").read())
+    start = raw.find(bytes([0xC2, 0x85] * 50))
+    assert start > 0
+    cases = {}
+    for name, pos, new in (("overlong C0 (block)", 10, bytes([0xC0, 0x85])), ("overlong C1 (block)", 20, bytes([0xC1, 0x85])),
+                           ("lead C4 (block)", 30, bytes([0xC4, 0x85])), ("stray continuation (block)", 40, bytes([0x85, 0x85])),
+                           ("lead without continuation (block)", 50, bytes([0xC2, 0x41])),
+                           ("overlong C0 (tail)", 396, bytes([0xC0, 0x85])), ("overlong C1 (tail)", 398, bytes([0xC1, 0x85]))):
+        bad = bytearray(raw)
+        bad[start + pos:start + pos + 2] = new
+        q = str(tmp_path / ("bad%d.pth" % len(cases)))
+        open(q, "wb").write(bytes(bad))
+        cases[name] = q
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gapro_amd import _lib, pth_io\n"
+            "lib = _lib.load()\n"
+            "print('TIER', lib.gapro_pth_decoder().decode())\n"
+            "assert pth_io.load_arrays(%r) is not None\n"
+            "for name, q in %r.items():\n"
+            "    try:\n"
+            "        pth_io.load_arrays(q)\n"
+            "        print('ACCEPTED', name)\n"
+            "    except Exception as e:\n"
+            "        print('rejected', name, type(e).__name__)\n" % (ROOT, p, cases))
+    ran = set()
+    for tier in ("scalar", "bmi2", "avx512"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                           env=dict(os.environ, GAPRO_PTH_DECODER=tier), timeout=120)
+        assert r.returncode == 0, r.stderr
+        got = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("TIER")][0]
+        if got != tier:
+            continue  # this CPU lacks the tier
+        ran.add(tier)
+        assert "ACCEPTED" not in r.stdout and r.stdout.count("rejected") == len(cases), (tier, r.stdout)
+    assert "scalar" in ran
+
+
 def test_preallocated_destinations(tmp_path):
     rng = np.random.default_rng(3)
     tup = _scene_tuple(rng, 300)
