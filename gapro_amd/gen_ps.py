@@ -591,7 +591,7 @@ class Worker:
             print("[gen_ps] teardown after the last file: %.2f s (%.2f s of it the feeder's pinned memory)"
                   % (time.time() - t_written, time.time() - t_fin))
         dev_i, done, failed = self.device_index, self.done, self.failed
-        print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.2f s (%.2f scenes/s)"
+        print("[gen_ps] device %d: %d scenes written, %d skipped/failed, %.3f s (%.2f scenes/s)"
               % (dev_i, done, failed, dt, done / dt if dt > 0 else 0.0))
         # start-up is reported apart from the rate: at ~300 scenes/s a 1201-scene split is a few seconds of work, and
         # the interpreter / library loads of a worker take a noticeable part of that
