@@ -61,13 +61,29 @@ import time
 from glob import glob
 
 import numpy as np
-import torch
 
 from . import _lib, pth_io
 from .dist_utils import ClaimQueue, effective_cpus, pending_scenes, shard_scenes, shard_scenes_lpt
-from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device, getInstanceInfo_native
-from .pipeline import Pipeline, make_job
 from .scannet_planes import get_wall_boxes, read_axis_align_matrix
+
+
+class _LazyModule:
+    """`import torch` on first use.  The parent of a `--devices 0,..,7` run only parses arguments, lists the scenes and
+    starts the workers; importing torch costs it 1.2 s -- a third of what an eight-GPU job over the ScanNet train split
+    then takes.  (The workers import it while their feeder threads are already reading.)"""
+
+    def __init__(self, name):
+        self.__dict__["_name"] = name
+
+    def __getattr__(self, attr):
+        import importlib
+
+        mod = importlib.import_module(self._name)
+        globals()[self._name] = mod  # later uses go straight to the module
+        return getattr(mod, attr)
+
+
+torch = _LazyModule("torch")
 
 
 class SceneScratch:
@@ -147,6 +163,8 @@ def read_scene(filename, data_root, use_deepfeat=False, deepfeat_folder=None, sc
 
 def add_instance_info(sc, device=None):
     """gen_ps.py:71-77: the GT boxes of a scene read by read_scene; None when the scene has no instance."""
+    from .gen_ps_utils import getInstanceInfo, getInstanceInfo_device, getInstanceInfo_native
+
     if device == "host":  # the driver's loader threads: one native pass on the host arrays, before the upload
         info = getInstanceInfo_native(sc["coords_float"], sc["instance_label"], sc["semantic_label"])
     elif device is not None:  # one pass on the device (gapro_instance_info)
@@ -191,9 +209,9 @@ _BLAS_LIMIT = []
 
 
 def _loader_init():
-    """Worker start-up: single-threaded BLAS / torch.  The wall-box geometry of scannet_planes.py is a few 3 x 3
+    """Worker start-up: single-threaded BLAS (torch's own pool is limited by the Worker once torch is imported, beside
+    the feeder threads that are already reading).  The wall-box geometry of scannet_planes.py is a few 3 x 3
     inverses per scene on helper threads; a 128-thread OpenBLAS forks and joins over each of them."""
-    torch.set_num_threads(1)
     try:
         from threadpoolctl import threadpool_limits
 
@@ -205,14 +223,16 @@ def _loader_init():
 def scene_to_device(sc, device):
     """Upload the per-point arrays of a read_scene dict once; add_instance_info and make_job then share them."""
     sc = dict(sc)
-    for k, dt in _DEVICE_DTYPES.items():
+    for k, dt in _device_dtypes().items():
         if not isinstance(sc[k], torch.Tensor):
             sc[k] = torch.from_numpy(np.ascontiguousarray(np.asarray(sc[k]))).to(device=device, dtype=dt)
     return sc
 
 
-_DEVICE_DTYPES = {"coords_float": torch.float64, "mask_feats": torch.float32, "spp": torch.int64,
-                  "semantic_label": torch.float64, "instance_label": torch.float64}
+def _device_dtypes():
+    return {"coords_float": torch.float64, "mask_feats": torch.float32, "spp": torch.int64,
+            "semantic_label": torch.float64, "instance_label": torch.float64}
+
 
 _T_IMPORT = time.time()
 _T0_PERF = [0.0]
@@ -262,6 +282,7 @@ class Worker:
         from .feeder import NativeFeeder
 
         self.args, self.dry, self.device_index = args, dry, device_index
+        self.make_job = None
         self.n_workers = max(1, int(getattr(args, "n_workers", 1)))  # GPU workers sharing this host (--devices)
         n_threads = int(getattr(args, "loader_threads", -1))
         if n_threads <= 0:
@@ -273,13 +294,6 @@ class Worker:
         self.queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
         self.chunks = _chunks(filenames, args, self.queue)
         self.chunks_done = False
-        self.pipe = None
-        if not dry:
-            self.pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
-            self.pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest is written
-            if os.environ.get("GAPRO_DRIVER_TIMES"):
-                self.pipe.trace = []  # host-side stage timeline of the pipeline (printed at the end)
-            self.dev = self.pipe.device
         # pinned staging: scenes loaded but not yet uploaded (two batches of ~11 MB scenes) plus label files in flight
         budget = int(os.environ.get("GAPRO_FEED_BUDGET_MB", "8192")) << 20
         self.feeder = NativeFeeder(-1 if dry else device_index, n_threads, budget)
@@ -294,6 +308,21 @@ class Worker:
         self.out_folder = args.save_folder
         self.t_first = None
         self.n_first = 0
+        # The feeder threads start reading NOW; torch (1.2 s of import) and the generator come up beside them, so that a
+        # worker's start-up is max(imports, first batches) rather than their sum.
+        self._submit_more()
+        self.pipe = None
+        if not dry:
+            from .pipeline import Pipeline, make_job
+
+            self.make_job = make_job
+            self._torch_threads = torch.get_num_threads()
+            torch.set_num_threads(1)  # restored by run(): tests and notebooks call main() in-process
+            self.pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
+            self.pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest is written
+            if os.environ.get("GAPRO_DRIVER_TIMES"):
+                self.pipe.trace = []  # host-side stage timeline of the pipeline (printed at the end)
+            self.dev = self.pipe.device
 
     # ---- input side -------------------------------------------------------------------------------------------
     def _prealloc(self):
@@ -393,7 +422,7 @@ class Worker:
                   semantic_label=view(osem, 8 * n, torch.float64, (n,)),
                   instance_label=view(oinst, 8 * n, torch.float64, (n,)))
         wall_box, wall_vol = self._walls(r.filename)
-        sc["job"] = make_job(sc["coords_float"], sc["mask_feats"], sc["spp"], r.instance_cls, r.instance_box,
+        sc["job"] = self.make_job(sc["coords_float"], sc["mask_feats"], sc["spp"], r.instance_cls, r.instance_box,
                              r.instance_box_volume, wall_box, wall_vol, instance_classes=18, ground_h=0.1,
                              thresh_spp_occu=0.999, device=self.dev,  # :106-110
                              scene_key=zlib.crc32(sc["scan_name"].encode()))
@@ -407,7 +436,7 @@ class Worker:
         if sc is None:
             return None
         sc = scene_to_device(sc, self.dev)
-        sc["job"] = make_job(sc["coords_float"], sc["mask_feats"], sc["spp"], sc["instance_cls"], sc["instance_box"],
+        sc["job"] = self.make_job(sc["coords_float"], sc["mask_feats"], sc["spp"], sc["instance_cls"], sc["instance_box"],
                              sc["instance_box_volume"], sc["wall_box"], sc["wall_box_volume"], instance_classes=18,
                              ground_h=0.1, thresh_spp_occu=0.999, device=self.dev,
                              scene_key=zlib.crc32(sc["scan_name"].encode()))
@@ -586,6 +615,8 @@ class Worker:
                 th.join()
             t_fin = time.time()
             self.feeder.destroy(process_is_exiting=_EXIT_AFTER_MAIN[0])
+            if getattr(self, "_torch_threads", None):
+                torch.set_num_threads(self._torch_threads)
         dt = t_written - t0
         if os.environ.get("GAPRO_DRIVER_TIMES"):
             print("[gen_ps] teardown after the last file: %.2f s (%.2f s of it the feeder's pinned memory)"
@@ -715,12 +746,10 @@ def main(argv=None):
             mine = shard_scenes_lpt(filenames, r, len(devices))
         # the loader threads of this process call BLAS concurrently: one BLAS / torch thread each while the worker runs
         # (restored afterwards: tests and notebooks call main() in-process)
-        prev_threads = torch.get_num_threads()
         _loader_init()
         try:
             result = run_worker_dry(mine, args, r) if args.dry_run else run_worker(mine, args, devices[r])
         finally:
-            torch.set_num_threads(prev_threads)
             while _BLAS_LIMIT:
                 lim = _BLAS_LIMIT.pop()
                 try:
