@@ -294,6 +294,21 @@ class Worker:
         self.queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
         self.chunks = _chunks(filenames, args, self.queue)
         self.chunks_done = False
+        # torch FIRST, then the library: libgapro_hip.so binds to the HIP runtime that is already in the process (torch
+        # ships its own); loaded the other way round, torch.cuda.is_available() comes up False.  So a worker cannot start
+        # reading before its 1.2 s of `import torch` -- only the parent of a --devices run is spared it.
+        self.pipe = None
+        if not dry:
+            from .pipeline import Pipeline, make_job
+
+            self.make_job = make_job
+            self._torch_threads = torch.get_num_threads()
+            torch.set_num_threads(1)  # restored by run(): tests and notebooks call main() in-process
+            self.pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
+            self.pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest is written
+            if os.environ.get("GAPRO_DRIVER_TIMES"):
+                self.pipe.trace = []  # host-side stage timeline of the pipeline (printed at the end)
+            self.dev = self.pipe.device
         # pinned staging: scenes loaded but not yet uploaded (two batches of ~11 MB scenes) plus label files in flight
         budget = int(os.environ.get("GAPRO_FEED_BUDGET_MB", "8192")) << 20
         self.feeder = NativeFeeder(-1 if dry else device_index, n_threads, budget)
@@ -308,21 +323,7 @@ class Worker:
         self.out_folder = args.save_folder
         self.t_first = None
         self.n_first = 0
-        # The feeder threads start reading NOW; torch (1.2 s of import) and the generator come up beside them, so that a
-        # worker's start-up is max(imports, first batches) rather than their sum.
-        self._submit_more()
-        self.pipe = None
-        if not dry:
-            from .pipeline import Pipeline, make_job
-
-            self.make_job = make_job
-            self._torch_threads = torch.get_num_threads()
-            torch.set_num_threads(1)  # restored by run(): tests and notebooks call main() in-process
-            self.pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
-            self.pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest is written
-            if os.environ.get("GAPRO_DRIVER_TIMES"):
-                self.pipe.trace = []  # host-side stage timeline of the pipeline (printed at the end)
-            self.dev = self.pipe.device
+        self._submit_more()  # the feeder threads start reading now, before run() is called
 
     # ---- input side -------------------------------------------------------------------------------------------
     def _prealloc(self):
