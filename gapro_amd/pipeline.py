@@ -163,23 +163,25 @@ class FitTiming:
     """Device-side timing of one fit launch (gapro_fit_timing): HIP events recorded by the library on the
     streams its kernels run on.  read() blocks until the launch has finished."""
 
-    def __init__(self, ctx, handle, flops_strip, flops_staged, flops_small, m, flops_cluster=0.0):
+    def __init__(self, ctx, handle, flops_strip, flops_staged, flops_small, m, flops_cluster=0.0, flops_wave=0.0):
         self.ctx, self.handle = ctx, handle
         self.flops_strip, self.flops_staged, self.flops_small, self.m = flops_strip, flops_staged, flops_small, m
-        self.flops_cluster = flops_cluster
+        self.flops_cluster, self.flops_wave = flops_cluster, flops_wave
         self.ms = None
 
     @property
     def flops(self):
-        return self.flops_strip + self.flops_staged + self.flops_small + self.flops_cluster
+        return self.flops_strip + self.flops_staged + self.flops_small + self.flops_cluster + self.flops_wave
 
     def read(self):
         """(staged kernel ms, strip kernel ms, first start -> last end ms, small-fit strip kernel ms, cluster kernel
-        ms)"""
+        ms, wave-per-fit kernels ms); the span covers all of them"""
         if self.ms is None:
             out = (C.c_float * 5)()
             self.ctx.check(self.ctx.lib.gapro_fit_timing_read(self.ctx.handle, self.handle, out))
-            self.ms = (float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]))
+            w = C.c_float(0.0)
+            self.ctx.check(self.ctx.lib.gapro_fit_timing_read_wave(self.ctx.handle, self.handle, C.byref(w)))
+            self.ms = (float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4]), float(w.value))
         return self.ms
 
     def cluster_info(self):
@@ -963,10 +965,11 @@ class Pipeline:
                 r[r == 3] = 0
             if flags & 1:
                 r[(r == 0) | (r == 3)] = 1
-            is_strip, is_small, is_clus = r == 0, (r == 3) | (r == 5), r == 4  # wave-per-fit counts with the small fits
+            is_strip, is_small, is_clus, is_wave = r == 0, r == 3, r == 4, r == 5
             self.fit_events.append(FitTiming(ctx, tm, float(each[is_strip].sum()),
-                                             float(each[~(is_strip | is_small | is_clus)].sum()),
-                                             float(each[is_small].sum()), m, float(each[is_clus].sum())))
+                                             float(each[~(is_strip | is_small | is_clus | is_wave)].sum()),
+                                             float(each[is_small].sum()), m, float(each[is_clus].sum()),
+                                             float(each[is_wave].sum())))
             self.last_fit_m = m
         # the next launch is ordered behind THIS launch's kernels only, not behind the copies below
         kern_done = torch.cuda.Event()

@@ -115,7 +115,7 @@ def main():
     t0 = a[:, 2].min()
     st, en = (a[:, 2] - t0) / 1e5, (a[:, 3] - t0) / 1e5  # ms
     span = en.max()
-    names = {0: "strip", 1: "staged", 2: "generic", 3: "small", 4: "cluster"}
+    names = {0: "strip", 1: "staged", 2: "generic", 3: "small", 4: "cluster", 5: "wave"}
     print("launch span by workgroup stamps: %.1f ms, %d fits, %d distinct CU ids" % (span, n, len(np.unique(a[:, 4]))))
     tot_cu_ms = 0.0
     for r in sorted(set(a[:, 1].astype(int))):
@@ -129,6 +129,26 @@ def main():
               "%.2f TFLOP  longest fit %.1f ms" % (names[r], k.sum(), st[k].min(), en[k].max(), cu_ms, cu_ms / 256, fl / 1e12,
                                                  dur.max()))
     print("  sum of workgroup-ms / 256 = %.1f ms (a CU hosts 2 workgroups of the small / staged<4> kernels)" % (tot_cu_ms / 256))
+    # CU-time with every workgroup weighted by the share of a CU it holds: strip and the one-per-CU staged fits a whole
+    # CU, the two-per-CU staged (M_p <= 256) and small fits half, a cluster fit its G members (the leader's interval: the
+    # members are resident from the cluster's first barrier to its last), a wave-per-fit fit 1/8 (M_p = 16), 1/4 (32) or
+    # 1/3 (48: three fit one CU's LDS).  Against 256 CUs x the span this is the occupancy the launch really has --
+    # the per-CU busy share at the end of this report cannot see cluster members other than leaders.
+    mp = np.array([float(lib.gapro_fit_padded_m(int(m), args.d)) for m in a[:, 0]])
+    w = np.ones(len(a))
+    rr = a[:, 1].astype(int)
+    w[(rr == 1) & (mp <= 256)] = 0.5
+    w[rr == 3] = 0.5
+    w[rr == 4] = a[rr == 4, 5]
+    w[(rr == 5) & (mp <= 16)] = 1.0 / 8
+    w[(rr == 5) & (mp == 32)] = 1.0 / 4
+    w[(rr == 5) & (mp == 48)] = 1.0 / 3
+    cu_time = float(((en - st) * w).sum())
+    print("  CU-time (workgroup-ms weighted by the share of a CU each holds): %.0f CU-ms = %.1f ms x 256; span %.1f ms -> "
+          "mean CU occupancy %.2f" % (cu_time, cu_time / 256, span, cu_time / (256 * span)))
+    for r in sorted(set(rr)):
+        k = rr == r
+        print("    %-8s %5.1f %% of the CU-time" % (names[r], 100 * float(((en - st) * w)[k].sum()) / cu_time))
     edges = np.linspace(0, span, args.bins + 1)
     print("  active workgroups (x G for cluster fits) at the bin centres:")
     print("  t[ms]   " + " ".join("%8s" % names[r] for r in sorted(names)))

@@ -59,7 +59,8 @@ def main():
     for name, dst in (("phase_tables.md", "_phase_tables.md"), ("fit_timeline.txt", "_fit_timeline.txt"),
                       ("cluster_prof.log", "_cluster_phases.txt"), ("strip_prof.log", "_strip_phases.txt"),
                       ("fit_sizes.log", "_fit_sizes.txt"), ("host_ceiling.json", "_host_ceiling.json"),
-                      ("wgloop_peak.txt", "_wgloop_peak.txt")):
+                      ("wgloop_peak.txt", "_wgloop_peak.txt"), ("kernel_resources.txt", "_kernel_resources.txt"),
+                      ("sq_counters.txt", "_sq_counters.txt"), ("wave_phases.txt", "_wave_phases.txt")):
         pth = os.path.join(src, name)
         if os.path.exists(pth):
             with open(pth) as fh:
@@ -84,7 +85,7 @@ def main():
                                "bytes_per_FETCH_SIZE_unit": fetch_unit, "bytes_per_WRITE_SIZE_unit": write_unit,
                                "note": "guide: FETCH_SIZE is in KiB and reports half of a coalesced streaming read "
                                        "on gfx950 (x2048 B per unit expected); WRITE_SIZE is KiB, exact (x1024)"}}
-    for key, sub in (("cluster_kernel", "k_svgp_fit_cluster"), ("strip_kernel", "k_svgp_fit_strip<"),
+    for key, sub in (("cluster_kernel", "k_svgp_fit_cluster"), ("wave_kernel", "k_svgp_fit_wave"), ("strip_kernel", "k_svgp_fit_strip<"),
                      ("small_strip_kernel", "k_svgp_fit_strip256<"), ("staged_kernel", "k_svgp_fit<"),
                      ("generic_kernel", "k_svgp_fit_large"), ("pool_kernel", "k_pool("), ("stats_kernel", "k_stats("),
                      ("broadcast_kernel", "k_broadcast(")):
@@ -95,7 +96,7 @@ def main():
         traffic[key] = {"launches_profiled": fn, "FETCH_SIZE_mean": fm, "WRITE_SIZE_mean": wm,
                         "read_bytes_per_launch": fm * fetch_unit, "written_bytes_per_launch": wm * write_unit,
                         "hbm_bytes_per_launch": fm * fetch_unit + wm * write_unit}
-    fit_keys = [k for k in ("cluster_kernel", "strip_kernel", "small_strip_kernel", "staged_kernel", "generic_kernel")
+    fit_keys = [k for k in ("cluster_kernel", "wave_kernel", "strip_kernel", "small_strip_kernel", "staged_kernel", "generic_kernel")
                 if k in traffic]
     if fit_keys:  # one gapro_svgp_fit_batch launch = its fit kernels side by side
         traffic["fit_launch"] = {

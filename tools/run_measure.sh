@@ -25,10 +25,18 @@ grep -v "rocclr\|k_scan\|k_flags\|k_rank\|at::native" $O/pmc_summary.txt | cut -
 python tools/phase_table.py --sizes 160,256,320,384,448 --fits 512 --lib libgapro_hip_profsplit.so > $O/phase_tables.md 2>&1
 python tools/phase_table.py --sizes 256 --fits 256 --lib libgapro_hip_profsplit.so >> $O/phase_tables.md 2>&1
 python tools/bench_fit.py --profile --sizes 544,640,768,1024 --fits 16 --reps 1 > $O/cluster_prof.log 2>&1
-python tools/bench_fit.py --profile --sizes 32,48,64,80,96,128 --fits 512 --reps 1 > $O/strip_prof.log 2>&1
+python tools/bench_fit.py --profile --sizes 64,80,96,128 --fits 512 --reps 1 > $O/strip_prof.log 2>&1
+python tools/bench_fit.py --profile --sizes 16,32,48 --fits 2048 --reps 1 > $O/wave_phases.txt 2>&1
 python tools/fit_timeline.py --fit-m $O/train_split_fit_m.npy > $O/fit_timeline.txt 2>&1; grep -v amdgpu $O/fit_timeline.txt | head -12
-python tools/bench_fit.py --sizes 32,64,96,128,160,200,256,320,384,448 --fits 512 --reps 2 > $O/fit_sizes.log 2>&1; grep "^M=" $O/fit_sizes.log
+python tools/bench_fit.py --sizes 16,32,48 --fits 4096 --reps 2 > $O/fit_sizes.log 2>&1
+python tools/bench_fit.py --sizes 64,80,96,128,160,200,256,320,384,448 --fits 512 --reps 2 >> $O/fit_sizes.log 2>&1; grep "^M=" $O/fit_sizes.log
 python tools/mfma_peak.py > $O/wgloop_peak.txt 2>&1
-python tools/host_ceiling.py --workers 1,2,4,8 --torch-io --json $O/host_ceiling.json > $O/host_ceiling.txt 2>&1; grep "^workers" $O/host_ceiling.txt
+python tools/host_ceiling.py --workers 1,2,4,8 --json $O/host_ceiling.json > $O/host_ceiling.txt 2>&1; grep "^workers" $O/host_ceiling.txt
+python tools/host_probe.py > $O/host_probe.txt 2>&1
+# SQ counters of every fit kernel of the final build: matrix-pipe busy, issue stalls, LDS conflicts
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT -d $O/sq -o bench --output-format csv -- python3 $R/bench.py $LIGHT --steps 2 --warmup 1 > $O/sq.log 2>&1
+cd $R
+python tools/pmc_summary.py $O/sq 2>&1 | grep "k_svgp" > $O/sq_counters.txt; cut -c1-150 $O/sq_counters.txt | head -60
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 head -8 $O/stats/bench_kernel_stats.csv | cut -c1-200
