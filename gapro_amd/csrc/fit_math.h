@@ -5,8 +5,37 @@
 #include <math.h>
 
 #include "common.h"
+#include "erfcx_table.h"
 
 namespace gapro_fit_math {
+
+// erfcx(x) = exp(x^2) erfc(x) for x >= 0, the special function of the likelihood phase (two per Gauss-Hermite node pair
+// and training point, 50 times per fit).  The math library's erfcx is ~200 instructions over five data-dependent
+// branches, and the ten node pairs of a point straddle its ranges, so a wave walks several of them.  Here:
+//     erfcx(x) = t Q(t),  t = 2 / (2 + x),  Q = a degree-8 polynomial per sixteenth of t in [0, 1]
+// (tools/gen_erfcx_table.py: interpolation error 3e-17, the evaluation within ~2 ulp of the true value): one division,
+// five 16-byte loads from a 1.3 KB table, eight FMAs, no branch.  x = inf gives 0, NaN stays NaN.
+// -DGAPRO_OCML_ERFCX: the math library's function (A/B builds).
+struct alignas(16) ErfcxRow {
+  double c[10];
+};
+static __constant__ const ErfcxRow kErfcxTab[16] = {GAPRO_ERFCX_TABLE_ROWS};
+__device__ inline double erfcx_tab(double x) {
+#ifdef GAPRO_OCML_ERFCX
+  return erfcx(x);
+#else
+  const double t = 2.0 / (2.0 + x);
+  const double tk = 16.0 * t;
+  int k = (int)tk;
+  k = k > 15 ? 15 : k;
+  const double u = fma(2.0, tk - (double)k, -1.0);
+  const double* c = kErfcxTab[k].c;
+  double p = c[8];
+#pragma unroll
+  for (int j = 7; j >= 0; --j) p = fma(p, u, c[j]);
+  return t * p;
+#endif
+}
 
 // numpy.polynomial.hermite.hermgauss(20): positive nodes (ascending) and their weights; the rule is symmetric.
 // Printed with repr() from NumPy 2.2.  (gpytorch settings.num_gauss_hermite_locs = 20)
@@ -18,6 +47,37 @@ constexpr double kGhW[10] = {0.4622436696006101,     0.28667550536283415,    0.1
                              7.80255647853206e-06,   1.0860693707692782e-07, 4.3993409922731747e-10,
                              2.2293936455341447e-13};
 
+// exp(x) for x <= 0: the RBF kernel values (Cholesky input, K_ZX, both kernel-gradient passes: one per pair of points and
+// step) and the Gaussian factor of the likelihood.  The math library's exp is 56 instructions (overflow, subnormal and
+// directed cases of the full range); here: k = rint(x / ln 2), r = x - k ln 2 (two-part constant, |r| <= 0.347), the Taylor
+// polynomial of degree 13 (remainder 4e-18), v_ldexp -- 22 instructions, ~1 ulp.  Arguments below -745 give the same
+// subnormal-or-zero as -745; NaN stays NaN.  -DGAPRO_OCML_EXP: the math library's function (A/B builds).
+__device__ inline double exp_neg(double x) {
+#ifdef GAPRO_OCML_EXP
+  return exp(x);
+#else
+  x = x < -745.0 ? -745.0 : x;
+  const double k = rint(x * 1.4426950408889634074);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;
+  p = fma(p, r, 2.08767569878681e-09);
+  p = fma(p, r, 2.505210838544172e-08);
+  p = fma(p, r, 2.755731922398589e-07);
+  p = fma(p, r, 2.7557319223985893e-06);
+  p = fma(p, r, 2.48015873015873e-05);
+  p = fma(p, r, 0.0001984126984126984);
+  p = fma(p, r, 0.001388888888888889);
+  p = fma(p, r, 0.008333333333333333);
+  p = fma(p, r, 0.041666666666666664);
+  p = fma(p, r, 0.16666666666666666);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+#endif
+}
+
 __device__ inline double softplus(double x) { return log1p(exp(-fabs(x))) + fmax(x, 0.0); }
 __device__ inline double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
 
@@ -27,13 +87,13 @@ __device__ inline double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
 //   z >= 0:  log Phi = log(1 - e t / 2)         r = e / (sqrt(2 pi) Phi)
 __device__ inline void log_ndtr_ratio(double z, double* lp, double* r) {
   const double rs2 = 0.70710678118654752440;
-  const double t = erfcx(fabs(z) * rs2);
+  const double t = erfcx_tab(fabs(z) * rs2);
   const double hz2 = 0.5 * z * z;
-  const double e = exp(-hz2);
+  const double e = exp_neg(-hz2);
   const bool neg = z < 0.0;
   const double phi_pos = 1.0 - 0.5 * e * t;  // Phi(z) for z >= 0
   *lp = log(neg ? 0.5 * t : phi_pos) - (neg ? hz2 : 0.0);
-  *r = neg ? 0.79788456080286535588 / t : e * 0.39894228040143267794 / phi_pos;
+  *r = (neg ? 0.79788456080286535588 : e * 0.39894228040143267794) / (neg ? t : phi_pos);  // one division
 }
 
 // value of `v` in lane `lane` (wave-uniform, compile-time after unrolling): v_readlane, no LDS crossbar

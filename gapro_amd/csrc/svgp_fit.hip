@@ -138,6 +138,7 @@ inline __host__ __device__ bool staged_ok(int m, int d) {
 
 struct Fit {
   int M, T, D, Mp;
+  int M1;  // train_y = -1 for the first M1 training points, +1 for the others (gaussian_process_utils.py:396-398)
   gd* mat[B_COUNT];
   gd* vec[V_COUNT];
   gd *X, *Z, *mZ, *vZ, *gZ, *Xt, *dinv, *dinvT, *scal;
@@ -189,13 +190,41 @@ __device__ inline double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
 // is absolutely accurate to 1e-16, and log Phi only enters the reported ELBO value.
 __device__ inline void log_ndtr_ratio(double z, double* lp, double* r) {
   const double rs2 = 0.70710678118654752440;
-  const double t = erfcx(fabs(z) * rs2);
+  const double t = gapro_fit_math::erfcx_tab(fabs(z) * rs2);
   const double hz2 = 0.5 * z * z;
-  const double e = exp(-hz2);
+  const double e = gapro_fit_math::exp_neg(-hz2);
   const bool neg = z < 0.0;
   const double phi_pos = 1.0 - 0.5 * e * t;  // Phi(z) for z >= 0
   *lp = log(neg ? 0.5 * t : phi_pos) - (neg ? hz2 : 0.0);
-  *r = neg ? 0.79788456080286535588 / t : e * 0.39894228040143267794 / phi_pos;
+  *r = (neg ? 0.79788456080286535588 : e * 0.39894228040143267794) / (neg ? t : phi_pos);  // one division
+}
+
+// r(z) alone, the same bits as log_ndtr_ratio's: log Phi only enters the ELBO VALUE, which is reported after the last
+// step and read by nobody before it -- 49 of 50 steps need no log (a quarter of the instructions of an evaluation)
+__device__ inline double ndtr_ratio(double z) {
+  const double t = gapro_fit_math::erfcx_tab(fabs(z) * 0.70710678118654752440);
+  const double e = gapro_fit_math::exp_neg(-0.5 * z * z);
+  const bool neg = z < 0.0;
+  return (neg ? 0.79788456080286535588 : e * 0.39894228040143267794) / (neg ? t : 1.0 - 0.5 * e * t);
+}
+// one symmetric pair of Gauss-Hermite nodes (t, weight w) of a point: sums for E (want_e only), dE/dmu, dE/dvar
+__device__ inline void gh_pair(double y, double mu, double sd, double t, double w, bool want_e, double* E, double* dmu,
+                               double* dvar) {
+#ifdef GAPRO_LIK_ALWAYS_LOG  // A/B builds
+  want_e = true;
+#endif
+  if (want_e) {  // workgroup-uniform
+    double lp, r;
+    log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
+    *E += w * lp; *dmu += w * r; *dvar -= w * t * r;
+    log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
+    *E += w * lp; *dmu += w * r; *dvar += w * t * r;
+  } else {
+    double r = ndtr_ratio(y * (mu - sd * t));
+    *dmu += w * r; *dvar -= w * t * r;
+    r = ndtr_ratio(y * (mu + sd * t));
+    *dmu += w * r; *dvar += w * t * r;
+  }
 }
 
 // value of `v` in lane `lane` (wave-uniform, compile-time after unrolling): v_readlane, no LDS crossbar
@@ -866,7 +895,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
         const int row = 16 * ib + lq + 4 * r;
         double v = 0.0;
         if (row < M && col < M) {
-          v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+          v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
           if (row == col) v += jitter;
         } else if (row == col) {
           v = 1.0;
@@ -937,7 +966,7 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
       const int row = 16 * ib + lq + 4 * r;
       double v = 0.0;
       if (row < M && col < M) {
-        v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+        v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
         if (row == col) v += jitter;
       } else if (row == col) {
         v = 1.0;
@@ -1029,7 +1058,7 @@ __device__ __noinline__ void cholesky_fused_lookahead_reg(const ldsd* Zt, ldsd* 
       const int row = 16 * ib + lq + 4 * r;
       double v = 0.0;
       if (row < M && col < M) {
-        v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+        v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
         if (row == col) v += jitter;
       } else if (row == col) {
         v = 1.0;
@@ -1339,7 +1368,7 @@ __device__ __noinline__ void build_kx(const ldsd* Zt, const ldsd* Pt, int ncols,
   const int n = cm.col;
   for (int k = cm.grp; k < Mp; k += cm.G) {
     double v = 0.0;
-    if (k < M && n < ncols) v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Pt, n, D, Mp));
+    if (k < M && n < ncols) v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, k, Pt, n, D, Mp));
     KX[(size_t)k * Mp + n] = v;
   }
 }
@@ -1412,13 +1441,9 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
       const double vraw = f.vec[V_VAR][n];
       const double var = vraw < min_variance ? min_variance : vraw;
       const double sd = sqrt(2.0 * var);
-      const double y = f.vec[V_Y][n];
+      const double y = n < f.M1 ? -1.0 : 1.0;  // train_y, not read from memory (global-memory latency in this chain)
       const double t = c_gh_t[q], w = c_gh_w[q];
-      double lp, r;
-      log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
-      E += w * lp; dmu += w * r; dvar -= w * t * r;
-      log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
-      E += w * lp; dmu += w * r; dvar += w * t * r;
+      gh_pair(y, mu, sd, t, w, want_e, &E, &dmu, &dvar);
     }
     red[threadIdx.x] = E;
     red[NT + threadIdx.x] = dmu;
@@ -1435,7 +1460,7 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
       const double vraw = f.vec[V_VAR][n];
       const bool clamped = vraw < min_variance;
       const double var = clamped ? min_variance : vraw;
-      const double y = f.vec[V_Y][n];
+      const double y = n < f.M1 ? -1.0 : 1.0;  // train_y, not read from memory (global-memory latency in this chain)
       const double g1 = -(ipi * sm * y) / Nd;
       const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
       gmu[n] = g1;
@@ -1462,7 +1487,7 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
 #ifdef GAPRO_X_NOEXP
 #define KG_EXP(x) (1.0 + (x))
 #else
-#define KG_EXP(x) exp(x)
+#define KG_EXP(x) gapro_fit_math::exp_neg(x)
 #endif
 template <int DMAX, bool ZX, int U, int DC>
 __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const gd* Gm, const gd* GTm,
@@ -2188,6 +2213,7 @@ __device__ inline void fit_setup(const gapro_fit_desc& desc, int D, const float*
   gd* base = (gd*)(ws + desc.ws_offset);
   if (threadIdx.x == 0) {
     f.M = desc.m1 + desc.m2;
+    f.M1 = desc.m1;
     f.T = desc.t;
     f.D = D;
     f.Mp = lay.Mp;
@@ -2404,7 +2430,7 @@ __device__ __noinline__ void strip_fill_kx(ldsd* Cs, const ldsd* Zt, const ldsd*
   for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
     const int k = idx / SW, n = idx - k * SW;
     double v = 0.0;
-    if (k < M && n < nc) v = s * exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Xpts, n0 + n, D, Mp));
+    if (k < M && n < nc) v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, k, Xpts, n0 + n, D, Mp));
     Cs[k * RS + n] = v;
   }
   __syncthreads();
@@ -2441,7 +2467,7 @@ __device__ __noinline__ void strip_mean_var(const ldsd* As, const ldsd* Bs, cons
 // gmu_s / gv_s for the strip, and this thread's contributions to sum E, sum g_mu, sum g_v in out3[0..2].
 __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_s, ldsd* gmu_s, ldsd* gv_s, ldsd* sred,
                                               int n0, int nc, double c, double min_variance, double Nd,
-                                              double* out3) {
+                                              bool want_e, double* out3) {
   const Fit& f = g_sh.f;
   const int q = threadIdx.x % 10, nl = threadIdx.x / 10;
   double E = 0.0, dmu = 0.0, dvar = 0.0;
@@ -2451,13 +2477,9 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
     const double vraw = var_s[nl];
     const double var = vraw < min_variance ? min_variance : vraw;
     const double sd = sqrt(2.0 * var);
-    const double y = f.vec[V_Y][n0 + nl];
+    const double y = n0 + nl < f.M1 ? -1.0 : 1.0;  // train_y (see quadrature)
     const double t = c_gh_t[q], w = c_gh_w[q];
-    double lp, r;
-    log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
-    E += w * lp; dmu += w * r; dvar -= w * t * r;
-    log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
-    E += w * lp; dmu += w * r; dvar += w * t * r;
+    gh_pair(y, mu, sd, t, w, want_e, &E, &dmu, &dvar);
   }
   sred[threadIdx.x] = E;
   sred[NT + threadIdx.x] = dmu;
@@ -2475,7 +2497,7 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
     const double vraw = var_s[nl];
     const bool clamped = vraw < min_variance;
     const double var = clamped ? min_variance : vraw;
-    const double y = f.vec[V_Y][n0 + nl];
+    const double y = n0 + nl < f.M1 ? -1.0 : 1.0;  // train_y (see quadrature)
     const double g1 = -(ipi * sm * y) / Nd;
     const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
     gmu_s[nl] = g1;
@@ -2497,7 +2519,7 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
 // 256 threads cover 25 columns per pass: a 32-column strip takes two
 __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_s, ldsd* gmu_s, ldsd* gv_s, ldsd* sred,
                                               int n0, int nc, double c, double min_variance, double Nd,
-                                              double* out3) {
+                                              bool want_e, double* out3) {
   const Fit& f = g_sh.f;
   constexpr int kCols = NT / 10;  // columns per pass: 51 with 512 threads (one pass per strip), 25 with 256
   const int q = threadIdx.x % 10, nl0 = threadIdx.x / 10;
@@ -2511,13 +2533,9 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
       const double vraw = var_s[nl];
       const double var = vraw < min_variance ? min_variance : vraw;
       const double sd = sqrt(2.0 * var);
-      const double y = f.vec[V_Y][n0 + nl];
+      const double y = n0 + nl < f.M1 ? -1.0 : 1.0;  // train_y (see quadrature)
       const double t = c_gh_t[q], w = c_gh_w[q];
-      double lp, r;
-      log_ndtr_ratio(y * (mu - sd * t), &lp, &r);
-      E += w * lp; dmu += w * r; dvar -= w * t * r;
-      log_ndtr_ratio(y * (mu + sd * t), &lp, &r);
-      E += w * lp; dmu += w * r; dvar += w * t * r;
+      gh_pair(y, mu, sd, t, w, want_e, &E, &dmu, &dvar);
     }
     sred[threadIdx.x] = E;
     sred[NT + threadIdx.x] = dmu;
@@ -2534,7 +2552,7 @@ __device__ __noinline__ void strip_likelihood(const ldsd* mu_s, const ldsd* var_
       const double vraw = var_s[nl];
       const bool clamped = vraw < min_variance;
       const double var = clamped ? min_variance : vraw;
-      const double y = f.vec[V_Y][n0 + nl];
+      const double y = n0 + nl < f.M1 ? -1.0 : 1.0;  // train_y (see quadrature)
       const double g1 = -(ipi * sm * y) / Nd;
       const double g2 = clamped ? 0.0 : -(ipi * sv * y / sqrt(2.0 * var)) / Nd;
       gmu_s[nl] = g1;
@@ -2813,7 +2831,7 @@ __device__ void fit_body_strip(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt,
       // ---- likelihood gradients of the strip columns
       {
         double part[3];
-        strip_likelihood(mu_s, var_s, gmu_s, gv_s, sred, n0, nc, c, opt.min_variance, Nd, part);
+        strip_likelihood(mu_s, var_s, gmu_s, gv_s, sred, n0, nc, c, opt.min_variance, Nd, last, part);
         e_tot += part[0];
         gc_part += part[1];
         gvs_part += part[2];
@@ -3194,6 +3212,7 @@ __global__ __launch_bounds__(NT, 2) void k_product_bench(int Mp, int reps, int s
   gd* Cm = Q + (size_t)Mp * Mp;
   if (threadIdx.x == 0) {
     g_sh.f.M = Mp;
+    g_sh.f.M1 = Mp / 2;
     g_sh.f.Mp = Mp;
   }
   __syncthreads();

@@ -98,7 +98,6 @@ __device__ inline d4 tn_neg(d4 acc, const d4& P, const d4& Q) {
 __device__ inline int lt(int i, int j) { return i * (i + 1) / 2 + j; }  // index of lower tile (i, j), i >= j
 
 // library calls that occur at several places of the step, each compiled once
-__device__ __noinline__ double nl_exp(double x) { return exp(x); }
 __device__ __noinline__ double nl_log(double x) { return log(x); }
 __device__ __noinline__ double nl_softplus(double x) { return softplus(x); }
 __device__ __noinline__ double nl_sigmoid(double x) { return sigmoid(x); }
@@ -114,9 +113,10 @@ __device__ __noinline__ LpR nl_log_ndtr_ratio(double z) {
 }
 // r(z) = phi(z) / Phi(z) alone: the 49 steps whose ELBO value nobody reads need no log Phi (same bits as the r above)
 __device__ __noinline__ double nl_ndtr_ratio(double z) {
-  const double t = erfcx(fabs(z) * 0.70710678118654752440);
-  const double e = exp(-0.5 * z * z);
-  return z < 0.0 ? 0.79788456080286535588 / t : e * 0.39894228040143267794 / (1.0 - 0.5 * e * t);
+  const double t = erfcx_tab(fabs(z) * 0.70710678118654752440);
+  const double e = exp_neg(-0.5 * z * z);
+  const bool neg = z < 0.0;
+  return (neg ? 0.79788456080286535588 : e * 0.39894228040143267794) / (neg ? t : 1.0 - 0.5 * e * t);
 }
 
 // Factor the symmetric 16 x 16 block S = L L^T and invert L: Dinv = L^-1 and Dinv^T as accumulator-layout tiles.  The
@@ -208,7 +208,7 @@ __device__ __noinline__ RbfTile rbf_tile(const ldsd* At, int rb, const ldsd* Bt,
       s2 += t * t;
     }
     o.d2[r] = s2;
-    o.e[r] = exp(nh_inv_l2 * s2);
+    o.e[r] = exp_neg(nh_inv_l2 * s2);
   }
   return o;
 }
@@ -860,7 +860,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
               const double t = Zt[d * Mp + row] - xt[d];
               s2 += t * t;
             }
-            KXc[k][r] = (row < M && lr < nc) ? s * nl_exp(-0.5 * inv_l2 * s2) : 0.0;
+            KXc[k][r] = (row < M && lr < nc) ? s * exp_neg(-0.5 * inv_l2 * s2) : 0.0;
           }
         forward_a(KXc, Ac, nullptr);
       }
