@@ -163,6 +163,7 @@ DEBUG_LIB_PATH = os.path.join(_HERE, "libgapro_hip_debug.so")
 DEBUG_SIGNATURES = {
     "gapro_debug_mfma_tn": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32]),
     "gapro_debug_stream": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
+    "gapro_debug_fit_math": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int32]),
     "gapro_debug_mfma_peak": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double)]),
     "gapro_debug_mfma_clock": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]),

@@ -3347,6 +3347,28 @@ int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream_, const double* d_P, const 
 // Debug: streaming kernels with a known byte count in this library's own access pattern (one double per
 // lane, grid-stride), used to calibrate the FETCH_SIZE / WRITE_SIZE counters.  mode 0: read n doubles and
 // write one partial sum per workgroup; mode 1: copy n doubles.
+// Debug: the fit kernels' own special functions (fit_math.h) evaluated elementwise, for tests/test_fit_gpu.py
+__global__ void k_fit_math(long long n, const double* __restrict__ x, double* __restrict__ out, int which) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double lp, r;
+  switch (which) {
+    case 0: out[i] = gapro_fit_math::erfcx_tab(x[i]); break;
+    case 1: out[i] = gapro_fit_math::exp_neg(x[i]); break;
+    case 2: out[i] = ndtr_ratio(x[i]); break;
+    default:
+      log_ndtr_ratio(x[i], &lp, &r);
+      out[i] = which == 3 ? lp : r;
+  }
+}
+int gapro_debug_fit_math(gapro_ctx* ctx, void* stream_, int64_t n, const double* d_x, double* d_out, int32_t which) {
+  if (!ctx || !d_x || !d_out || n <= 0 || which < 0 || which > 4) return GAPRO_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_fit_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, (long long)n, d_x,
+                     d_out, (int)which);
+  GAPRO_LAUNCH_CHECK(ctx);
+  return GAPRO_OK;
+}
+
 int gapro_debug_stream(gapro_ctx* ctx, void* stream_, int64_t n, const double* d_src, double* d_dst, int32_t mode) {
   if (!ctx || !d_src || !d_dst || n <= 0 || mode < 0 || mode > 1) return GAPRO_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_stream_calib, dim3(4096), dim3(256), 0, (hipStream_t)stream_, (long long)n, d_src, d_dst,

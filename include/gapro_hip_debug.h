@@ -19,6 +19,10 @@ extern "C" {
  * v_mfma_f64_16x16x4_f64 lane maps the fit kernel relies on. */
 int gapro_debug_mfma_tn(gapro_ctx* ctx, void* stream, const double* d_P, const double* d_Q, double* d_C,
                         int32_t K);
+/* The fit kernels' special functions (csrc/fit_math.h), elementwise over n doubles: which = 0 erfcx_tab(x) (x >= 0),
+ * 1 exp_neg(x) (x <= 0), 2 ndtr_ratio(x) = phi(x) / Phi(x), 3 / 4 log Phi(x) and the ratio of log_ndtr_ratio.
+ * (tests/test_fit_gpu.py holds them against SciPy.) */
+int gapro_debug_fit_math(gapro_ctx* ctx, void* stream, int64_t n, const double* d_x, double* d_out, int32_t which);
 /* Streaming kernels with a known byte count (one double per lane, grid-stride: the access width of the
  * fit kernel), to calibrate the FETCH_SIZE / WRITE_SIZE counters.  mode 0: read n doubles, one atomic
  * partial sum per wave into d_dst[0..4095]; mode 1: copy n doubles. */

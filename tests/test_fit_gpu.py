@@ -28,6 +28,47 @@ def test_mfma_f64_lane_maps():
     np.testing.assert_array_equal(dC.cpu().numpy(), P.T @ Q)
 
 
+def test_fit_kernels_special_functions_against_scipy():
+    """erfcx_tab / exp_neg / the Mills-ratio forms of csrc/fit_math.h (a 1.3 KB table and a short polynomial instead of
+    the math library's erfcx and exp) against SciPy in float64: a few ulp, over the ranges the likelihood and the RBF
+    kernel reach and far beyond them."""
+    import torch
+    from scipy import special as sp
+
+    from gapro_amd._lib import Context
+
+    ctx = Context.get(0)
+    rng = np.random.default_rng(5)
+
+    def run(x, which):
+        dx = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+        do = torch.empty_like(dx)
+        ctx.check(ctx.dbg.gapro_debug_fit_math(ctx.handle, None, dx.numel(), C.c_void_p(dx.data_ptr()),
+                                                C.c_void_p(do.data_ptr()), which))
+        torch.cuda.synchronize()
+        return do.cpu().numpy()
+
+    def ulps(got, ref):
+        return np.abs(got - ref) / np.spacing(np.abs(ref))
+
+    x = np.concatenate([rng.uniform(0, 12, 200000), 10.0 ** rng.uniform(-300, 300, 20000), [0.0, 0.5, 1.0, 26.0, 1e308]])
+    assert np.allclose(run(x, 0), sp.erfcx(x), rtol=1.2e-15, atol=0)  # (SciPy's own error is up to ~4 ulp near 0)
+    assert run(np.array([np.inf]), 0)[0] == 0.0 and np.isnan(run(np.array([np.nan]), 0)[0])
+    x = -np.concatenate([rng.uniform(0, 60, 200000), 10.0 ** rng.uniform(-300, 2.84, 20000), [0.0, 700.0, 708.0]])
+    assert ulps(run(x, 1), np.exp(x)).max() <= 2
+    assert run(np.array([-800.0, -1e300]), 1).max() <= 5e-324 and np.isnan(run(np.array([np.nan]), 1)[0])
+    # r(z) = phi(z) / Phi(z) and log Phi(z) over both tails (reference: erfcx / log_ndtr, each good to an ulp or two)
+    z = np.concatenate([rng.uniform(-40, 12, 200000), [-1e3, -37.5, -1e-9, 0.0, 1e-9, 8.0, 30.0]])
+    ref_r = np.where(z < 0, np.sqrt(2 / np.pi) / sp.erfcx(-z / np.sqrt(2)),
+                     np.exp(-0.5 * z * z) / np.sqrt(2 * np.pi) / sp.ndtr(z))
+    for which in (2, 4):
+        got = run(z, which)
+        assert np.allclose(got, ref_r, rtol=4e-15, atol=0), np.abs(got / ref_r - 1).max()
+    assert np.array_equal(run(z, 2), run(z, 4))  # the ratio-only form gives the bits of the form with the logarithm
+    got = run(z, 3)
+    assert np.allclose(got, sp.log_ndtr(z), rtol=4e-15, atol=3e-16), np.abs(got - sp.log_ndtr(z)).max()
+
+
 def _oracle(feats, b1, b2, it, iters, init_mean=None):
     from oracle import svgp_oracle as so
 
