@@ -190,9 +190,9 @@ __device__ inline double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); }
 // is absolutely accurate to 1e-16, and log Phi only enters the reported ELBO value.
 __device__ inline void log_ndtr_ratio(double z, double* lp, double* r) {
   const double rs2 = 0.70710678118654752440;
-  const double t = gapro_fit_math::erfcx_tab(fabs(z) * rs2);
+  const double t = gapro_fit_math::lik_erfcx(fabs(z) * rs2);
   const double hz2 = 0.5 * z * z;
-  const double e = gapro_fit_math::exp_neg(-hz2);
+  const double e = gapro_fit_math::rbf_exp(-hz2);
   const bool neg = z < 0.0;
   const double phi_pos = 1.0 - 0.5 * e * t;  // Phi(z) for z >= 0
   *lp = log(neg ? 0.5 * t : phi_pos) - (neg ? hz2 : 0.0);
@@ -202,8 +202,8 @@ __device__ inline void log_ndtr_ratio(double z, double* lp, double* r) {
 // r(z) alone, the same bits as log_ndtr_ratio's: log Phi only enters the ELBO VALUE, which is reported after the last
 // step and read by nobody before it -- 49 of 50 steps need no log (a quarter of the instructions of an evaluation)
 __device__ inline double ndtr_ratio(double z) {
-  const double t = gapro_fit_math::erfcx_tab(fabs(z) * 0.70710678118654752440);
-  const double e = gapro_fit_math::exp_neg(-0.5 * z * z);
+  const double t = gapro_fit_math::lik_erfcx(fabs(z) * 0.70710678118654752440);
+  const double e = gapro_fit_math::rbf_exp(-0.5 * z * z);
   const bool neg = z < 0.0;
   return (neg ? 0.79788456080286535588 : e * 0.39894228040143267794) / (neg ? t : 1.0 - 0.5 * e * t);
 }
@@ -895,7 +895,7 @@ __device__ __noinline__ void cholesky_fused(const ldsd* Zt, ldsd* panel, double 
         const int row = 16 * ib + lq + 4 * r;
         double v = 0.0;
         if (row < M && col < M) {
-          v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+          v = s * gapro_fit_math::rbf_exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
           if (row == col) v += jitter;
         } else if (row == col) {
           v = 1.0;
@@ -966,7 +966,7 @@ __device__ __noinline__ void cholesky_fused_lookahead(const ldsd* Zt, ldsd* pane
       const int row = 16 * ib + lq + 4 * r;
       double v = 0.0;
       if (row < M && col < M) {
-        v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+        v = s * gapro_fit_math::rbf_exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
         if (row == col) v += jitter;
       } else if (row == col) {
         v = 1.0;
@@ -1058,7 +1058,7 @@ __device__ __noinline__ void cholesky_fused_lookahead_reg(const ldsd* Zt, ldsd* 
       const int row = 16 * ib + lq + 4 * r;
       double v = 0.0;
       if (row < M && col < M) {
-        v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
+        v = s * gapro_fit_math::rbf_exp(-0.5 * inv_l2 * sqdist_t(Zt, row, Zt, col, D, Mp));
         if (row == col) v += jitter;
       } else if (row == col) {
         v = 1.0;
@@ -1368,7 +1368,7 @@ __device__ __noinline__ void build_kx(const ldsd* Zt, const ldsd* Pt, int ncols,
   const int n = cm.col;
   for (int k = cm.grp; k < Mp; k += cm.G) {
     double v = 0.0;
-    if (k < M && n < ncols) v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, k, Pt, n, D, Mp));
+    if (k < M && n < ncols) v = s * gapro_fit_math::rbf_exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Pt, n, D, Mp));
     KX[(size_t)k * Mp + n] = v;
   }
 }
@@ -1487,7 +1487,7 @@ __device__ __noinline__ double quadrature(double c, double min_variance, double 
 #ifdef GAPRO_X_NOEXP
 #define KG_EXP(x) (1.0 + (x))
 #else
-#define KG_EXP(x) gapro_fit_math::exp_neg(x)
+#define KG_EXP(x) gapro_fit_math::rbf_exp(x)
 #endif
 template <int DMAX, bool ZX, int U, int DC>
 __device__ __noinline__ void kernel_grads_adam_z(ldsd* Zt, const ldsd* Xt, const gd* Gm, const gd* GTm,
@@ -2430,7 +2430,7 @@ __device__ __noinline__ void strip_fill_kx(ldsd* Cs, const ldsd* Zt, const ldsd*
   for (int idx = threadIdx.x; idx < Mp * SW; idx += NT) {
     const int k = idx / SW, n = idx - k * SW;
     double v = 0.0;
-    if (k < M && n < nc) v = s * gapro_fit_math::exp_neg(-0.5 * inv_l2 * sqdist_t(Zt, k, Xpts, n0 + n, D, Mp));
+    if (k < M && n < nc) v = s * gapro_fit_math::rbf_exp(-0.5 * inv_l2 * sqdist_t(Zt, k, Xpts, n0 + n, D, Mp));
     Cs[k * RS + n] = v;
   }
   __syncthreads();

@@ -98,6 +98,7 @@ __device__ inline d4 tn_neg(d4 acc, const d4& P, const d4& Q) {
 __device__ inline int lt(int i, int j) { return i * (i + 1) / 2 + j; }  // index of lower tile (i, j), i >= j
 
 // library calls that occur at several places of the step, each compiled once
+__device__ __noinline__ double nl_exp(double x) { return rbf_exp(x); }
 __device__ __noinline__ double nl_log(double x) { return log(x); }
 __device__ __noinline__ double nl_softplus(double x) { return softplus(x); }
 __device__ __noinline__ double nl_sigmoid(double x) { return sigmoid(x); }
@@ -113,8 +114,8 @@ __device__ __noinline__ LpR nl_log_ndtr_ratio(double z) {
 }
 // r(z) = phi(z) / Phi(z) alone: the 49 steps whose ELBO value nobody reads need no log Phi (same bits as the r above)
 __device__ __noinline__ double nl_ndtr_ratio(double z) {
-  const double t = erfcx_tab(fabs(z) * 0.70710678118654752440);
-  const double e = exp_neg(-0.5 * z * z);
+  const double t = lik_erfcx(fabs(z) * 0.70710678118654752440);
+  const double e = rbf_exp(-0.5 * z * z);
   const bool neg = z < 0.0;
   return (neg ? 0.79788456080286535588 : e * 0.39894228040143267794) / (neg ? t : 1.0 - 0.5 * e * t);
 }
@@ -208,7 +209,7 @@ __device__ __noinline__ RbfTile rbf_tile(const ldsd* At, int rb, const ldsd* Bt,
       s2 += t * t;
     }
     o.d2[r] = s2;
-    o.e[r] = exp_neg(nh_inv_l2 * s2);
+    o.e[r] = rbf_exp(nh_inv_l2 * s2);
   }
   return o;
 }
@@ -860,7 +861,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
               const double t = Zt[d * Mp + row] - xt[d];
               s2 += t * t;
             }
-            KXc[k][r] = (row < M && lr < nc) ? s * exp_neg(-0.5 * inv_l2 * s2) : 0.0;
+            KXc[k][r] = (row < M && lr < nc) ? s * nl_exp(-0.5 * inv_l2 * s2) : 0.0;
           }
         forward_a(KXc, Ac, nullptr);
       }
