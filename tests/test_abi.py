@@ -30,7 +30,7 @@ def test_debug_entry_points_live_in_their_own_library_and_header():
     assert not [n for n in _declared_symbols() if n.startswith("gapro_debug_")]
     lib = _lib.load()
     names = _declared_symbols("gapro_hip_debug.h")
-    assert len(names) == 6 and all(n.startswith("gapro_debug_") for n in names), names
+    assert len(names) == 7 and all(n.startswith("gapro_debug_") for n in names), names
     dbg = _lib.load_debug()
     for n in names:
         assert hasattr(dbg, n) and n in _lib.DEBUG_SIGNATURES and not hasattr(lib, n), n
