@@ -57,8 +57,14 @@ def main():
         a = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64")
         m = so.svgp_fit_predict_manual(X, y, Xt, 50)
         odv, odp = np.max(np.abs(a[1] - m[1]) / a[1]), np.max(np.abs(a[2] - m[2]))
+        # the fit's own conditioning: ONE input coordinate moved by ONE ulp, same implementation, same thread count
+        Xp = X.copy()
+        Xp[0, 0] = np.nextafter(Xp[0, 0], np.inf)
+        u = so.svgp_fit_predict_autograd(Xp, y, Xt, 50, "f64")
+        udv = np.max(np.abs(u[1] - a[1]) / a[1])
         print("fit %d (M = %d): kernel vs autograd oracle dv %.2e dp %.2e | oracle autograd vs manual dv %.2e dp %.2e | "
-              "ratio %.1f (the test allows 30)" % (k, len(X), dv, dp, odv, odp, dv / odv))
+              "ratio %.1f (the test allows 30) | the autograd oracle with one input moved by one ulp: dv %.2e"
+              % (k, len(X), dv, dp, odv, odp, dv / odv, udv))
     print("%d fits; every other fit within dv %.1e" % (len(fits), worst))
 
 
