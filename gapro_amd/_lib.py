@@ -147,7 +147,7 @@ SIGNATURES = {
     "gapro_feed_submit": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "gapro_feed_close": (C.c_int, [_P]),
     "gapro_feed_poll": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
-    "gapro_feed_upload": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P, C.POINTER(C.c_int64)]),
+    "gapro_feed_upload": (C.c_int, [_P, C.c_int32, _P, C.c_int64, _P, _P, C.POINTER(C.c_int64)]),
     "gapro_feed_batch_wait": (C.c_int, [_P, C.c_int64, _P]),
     "gapro_feed_release_batch": (C.c_int, [_P, C.c_int64]),
     "gapro_feed_export": (C.c_int, [_P, C.c_int32, _P, _P]),

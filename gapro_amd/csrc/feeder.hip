@@ -63,6 +63,7 @@ struct OutItem {  // one label file to write
   gapro_feed_out o{};
   std::string path;
   hipEvent_t ready = nullptr;
+  int64_t seq = 0;  // position in submission order
 };
 
 }  // namespace
@@ -81,7 +82,14 @@ struct gapro_feed {
                          // in order, so a later scene holding the last room while an earlier one waits would deadlock)
   size_t head = 0;       // next scene the consumer gets
   std::deque<OutItem> exports;
-  int64_t exp_submitted = 0, exp_done = 0, exp_failed = 0;
+  // label files: exp_done counts finished writes in ANY order (up to 16 writers); exp_prefix is the number of exports
+  // that are finished as a CONTIGUOUS prefix of the submission order -- the only count a caller may release device
+  // memory by (item k + 1 finishing says nothing about item k still inside its device -> host copies)
+  int64_t exp_submitted = 0, exp_done = 0, exp_failed = 0, exp_prefix = 0;
+  std::deque<char> exp_flags;  // finished flags of exports exp_prefix, exp_prefix + 1, ...
+  int exp_active = 0;          // writers between taking an export and finishing it
+  int budget_waiters = 0;      // loaders whose turn it is and whom only the byte budget holds back
+  bool failed = false;         // an upload failed half way: the feed's order is gone, every later call reports it
   std::vector<std::string> exp_errors;
   bool stop = false, closed = false;
   // pinned block pool
@@ -106,12 +114,33 @@ bool use_gpu(const gapro_feed* f) { return f->device >= 0; }
 
 // turn < 0: a label file (any time); otherwise the scene's index in submission order: its turn comes when every earlier
 // scene has taken (or given up) its block
+void reap_batches(gapro_feed* f, bool wait_all);
+
 Block take_block(gapro_feed* f, int64_t need, std::unique_lock<std::mutex>& lk, long long turn = -1) {
-  // wait for room in the in-flight budget (one scene is always admitted), then first fit from the pool
-  f->cv_space.wait(lk, [&] {
-    return f->stop || ((turn < 0 || (size_t)turn == f->next_alloc) &&
-                       (f->inflight_bytes == 0 || f->inflight_bytes + need <= f->budget_bytes));
-  });
+  // wait for room in the in-flight budget (one scene is always admitted), then first fit from the pool.  The pinned
+  // blocks of uploaded batches come back through reap_batches, which round 5 ran on the consumer's thread only: a
+  // consumer that was itself waiting (gapro_feed_poll for a batch larger than the budget, the final
+  // gapro_feed_export_wait) never reaped, and both sides waited for ever.  So a waiter reaps by itself (a
+  // timed wait: completed copies raise no condition variable), and a loader that only the budget holds back says so
+  // to the poller, which then hands out what is loaded instead of waiting for a count that cannot be reached.
+  bool counted = false;
+  for (;;) {
+    if (f->stop) break;
+    if (use_gpu(f)) reap_batches(f, false);
+    const bool my_turn = turn < 0 || (size_t)turn == f->next_alloc;
+    // a label file (turn < 0) is always admitted: at most one per thread is in flight, its block comes back by itself,
+    // and a writer waiting for room that only loaded-but-untaken scenes hold -- while the poller waits for the
+    // writers -- would be the same deadlock from the other side
+    const bool room = turn < 0 || f->inflight_bytes == 0 || f->inflight_bytes + need <= f->budget_bytes;
+    if (my_turn && room) break;
+    if (turn >= 0 && my_turn && !counted) {
+      counted = true;
+      ++f->budget_waiters;
+      f->cv_ready.notify_all();
+    }
+    f->cv_space.wait_for(lk, std::chrono::milliseconds(2));
+  }
+  if (counted) --f->budget_waiters;
   Block b;
   if (f->stop) return b;
   f->inflight_bytes += need;
@@ -399,16 +428,24 @@ void worker(gapro_feed* f) {
     if (!f->exports.empty()) {
       OutItem w = std::move(f->exports.front());
       f->exports.pop_front();
+      ++f->exp_active;
       lk.unlock();
       std::string err;
       write_labels(f, w, st, &err);
       lk.lock();
+      --f->exp_active;
       ++f->exp_done;
+      f->exp_flags[(size_t)(w.seq - f->exp_prefix)] = 1;
+      while (!f->exp_flags.empty() && f->exp_flags.front()) {
+        f->exp_flags.pop_front();
+        ++f->exp_prefix;
+      }
       if (!err.empty()) {
         ++f->exp_failed;
         f->exp_errors.push_back(err);
       }
       f->cv_export.notify_all();
+      f->cv_ready.notify_all();
       continue;
     }
     const size_t i = f->next_load++;
@@ -537,7 +574,7 @@ int gapro_feed_poll(gapro_feed* f, int32_t min_ready, int32_t max_scenes, int32_
                     int64_t* slab_bytes) {
   if (!f || !n_ready || !slab_bytes || max_scenes <= 0) return GAPRO_ERR_BAD_ARG;
   std::unique_lock<std::mutex> lk(f->mu);
-  if (use_gpu(f)) reap_batches(f, false);
+  if (f->failed) return GAPRO_ERR_HIP;
   auto count = [&](int64_t* bytes) {
     int n = 0;
     int64_t b = 0;
@@ -555,25 +592,68 @@ int gapro_feed_poll(gapro_feed* f, int32_t min_ready, int32_t max_scenes, int32_
     if (f->stop) return true;
     const size_t submitted = f->base + f->items.size() - f->head;  // scenes not yet handed out
     const size_t want = f->closed ? std::min(want_cap, submitted) : want_cap;
-    return (size_t)count(nullptr) >= want || (f->closed && submitted == 0);
+    const size_t have = (size_t)count(nullptr);
+    if (have >= want || (f->closed && submitted == 0)) return true;
+    // The byte budget is smaller than what `want` scenes need (deep features, --batch_scenes 512, S3DIS
+    // rooms): the loader whose turn it is waits for room that only THIS caller can make, by taking what is loaded.
+    // Nothing else will return memory: no upload is in flight (its blocks come back when its copy is done) and no label
+    // file is being written (its block comes back when it is on disk).
+    return have >= 1 && f->budget_waiters > 0 && f->batches.empty() && f->exp_active == 0 && f->exports.empty();
   };
-  if (timeout_ms < 0) f->cv_ready.wait(lk, enough);
-  else f->cv_ready.wait_for(lk, std::chrono::milliseconds(timeout_ms), enough);
+  // (a timed wait: uploads whose copies complete raise no condition variable, and their blocks are what the loaders wait for)
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+  for (;;) {
+    if (use_gpu(f)) reap_batches(f, false);
+    if (enough()) break;
+    auto slice = std::chrono::milliseconds(f->batches.empty() ? 50 : 2);
+    if (timeout_ms >= 0) {
+      const auto now = std::chrono::steady_clock::now();
+      if (now >= t_end) break;
+      slice = std::min(slice, std::chrono::duration_cast<std::chrono::milliseconds>(t_end - now) + std::chrono::milliseconds(1));
+    }
+    f->cv_ready.wait_for(lk, slice);
+  }
   *n_ready = count(slab_bytes);
   return GAPRO_OK;
 }
 
-int gapro_feed_upload(gapro_feed* f, int32_t n, void* d_slab, int64_t slab_bytes, gapro_feed_scene* out,
+int gapro_feed_upload(gapro_feed* f, int32_t n, void* d_slab, int64_t slab_bytes, void* slab_stream, gapro_feed_scene* out,
                       int64_t* batch_id) {
   if (!f || n <= 0 || !out || !batch_id || (use_gpu(f) && (!d_slab || slab_bytes <= 0))) return GAPRO_ERR_BAD_ARG;
   std::unique_lock<std::mutex> lk(f->mu);
+  if (f->failed) {
+    f->last_error = "gapro_feed_upload: an earlier upload failed half way; the feed cannot continue";
+    return GAPRO_ERR_HIP;
+  }
+  // everything is checked BEFORE any state changes (an error return from the middle of the loop left
+  // scenes marked as handed out, their pinned blocks dropped and the caller's name list out of step)
   if (f->head + n > f->base + f->items.size()) return GAPRO_ERR_BAD_ARG;
-  for (int k = 0; k < n; ++k)
-    if (f->items[f->head + k - f->base]->state != 2) return GAPRO_ERR_BAD_ARG;
+  int64_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    const Item& it = *f->items[f->head + k - f->base];
+    if (it.state != 2) return GAPRO_ERR_BAD_ARG;
+    if (it.rec.status == GAPRO_OK) total += it.image_bytes;
+  }
+  if (use_gpu(f) && total > slab_bytes) {
+    f->last_error = "gapro_feed_upload: the device slab is smaller than the size gapro_feed_poll reported";
+    return GAPRO_ERR_BAD_ARG;
+  }
   gapro_feed::Batch b;
   b.id = f->next_batch_id++;
   b.ev = nullptr;
   b.bytes = 0;
+  bool hip_ok = true;
+  if (use_gpu(f) && slab_stream != f->copy_stream) {
+    // The slab may come from a caching allocator (torch's): a block whose previous owner was freed on the host while
+    // its kernels are still queued on the allocating stream.  The copies below run on the feed's own stream, which
+    // nothing orders behind that work, so they wait here for everything queued on the caller's stream so far (ADVICE
+    // r05).  slab_stream = NULL is the legacy default stream.
+    hipEvent_t e = nullptr;
+    hip_ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess &&
+             hipEventRecord(e, (hipStream_t)slab_stream) == hipSuccess &&
+             hipStreamWaitEvent(f->copy_stream, e, 0) == hipSuccess;
+    if (e) (void)hipEventDestroy(e);  // (destroying a recorded event is deferred by the runtime until it completes)
+  }
   int64_t off = 0;
   for (int k = 0; k < n; ++k) {
     Item& it = *f->items[f->head + k - f->base];
@@ -581,15 +661,8 @@ int gapro_feed_upload(gapro_feed* f, int32_t n, void* d_slab, int64_t slab_bytes
     it.state = 3;
     if (it.rec.status != GAPRO_OK) continue;
     if (use_gpu(f)) {
-      if (off + it.image_bytes > slab_bytes) {
-        f->last_error = "gapro_feed_upload: the device slab is smaller than the size gapro_feed_poll reported";
-        return GAPRO_ERR_BAD_ARG;
-      }
-      if (hipMemcpyAsync((char*)d_slab + off, it.blk.p, (size_t)it.image_bytes, hipMemcpyHostToDevice, f->copy_stream) !=
-          hipSuccess) {
-        f->last_error = "gapro_feed_upload: hipMemcpyAsync failed";
-        return GAPRO_ERR_HIP;
-      }
+      hip_ok = hip_ok && hipMemcpyAsync((char*)d_slab + off, it.blk.p, (size_t)it.image_bytes, hipMemcpyHostToDevice,
+                                        f->copy_stream) == hipSuccess;
       out[k].off_coords += off;
       out[k].off_feats += off;
       out[k].off_spp += off;
@@ -612,14 +685,23 @@ int gapro_feed_upload(gapro_feed* f, int32_t n, void* d_slab, int64_t slab_bytes
     ++f->base;
   }
   if (use_gpu(f)) {
-    if (hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventRecord(b.ev, f->copy_stream) != hipSuccess) {
-      f->last_error = "gapro_feed_upload: event record failed";
-      return GAPRO_ERR_HIP;
+    hip_ok = hip_ok && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) == hipSuccess &&
+             hipEventRecord(b.ev, f->copy_stream) == hipSuccess;
+    if (!hip_ok) {
+      // the copies that were queued may still run: wait for them, then the blocks go back through the usual path
+      (void)hipStreamSynchronize(f->copy_stream);
+      if (b.ev) (void)hipEventDestroy(b.ev);
+      b.ev = nullptr;
     }
   }
   *batch_id = b.id;
   f->batches.push_back(std::move(b));  // (host-only mode: the blocks stay with the batch until gapro_feed_release_batch)
+  if (!hip_ok) {
+    f->failed = true;
+    reap_batches(f, false);
+    f->last_error = "gapro_feed_upload: a HIP call failed (event or host -> device copy); the feed stops here";
+    return GAPRO_ERR_HIP;
+  }
   return GAPRO_OK;
 }
 
@@ -665,7 +747,9 @@ int gapro_feed_export(gapro_feed* f, int32_t n, const gapro_feed_out* items, voi
       w.path = items[i].path;
       w.o.path = nullptr;
       w.ready = (hipEvent_t)ready_event;
+      w.seq = f->exp_submitted;
       f->exports.push_back(std::move(w));
+      f->exp_flags.push_back(0);
       ++f->exp_submitted;
     }
   }
@@ -677,10 +761,22 @@ int gapro_feed_export_wait(gapro_feed* f, int64_t until_done, int32_t timeout_ms
   if (!f) return GAPRO_ERR_BAD_ARG;
   std::unique_lock<std::mutex> lk(f->mu);
   const int64_t target = until_done < 0 ? f->exp_submitted : std::min(until_done, f->exp_submitted);
-  auto ok = [&] { return f->stop || f->exp_done >= target; };
-  if (timeout_ms < 0) f->cv_export.wait(lk, ok);
-  else f->cv_export.wait_for(lk, std::chrono::milliseconds(timeout_ms), ok);
-  if (n_done) *n_done = f->exp_done;
+  // n_done = exports finished as a contiguous prefix of the submission order (see exp_prefix)
+  auto ok = [&] { return f->stop || f->exp_prefix >= target; };
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
+  for (;;) {
+    // the writers wait for staging blocks that the last uploads still hold: nobody else is left to reap them
+    if (use_gpu(f)) reap_batches(f, false);
+    if (ok()) break;
+    auto slice = std::chrono::milliseconds(f->batches.empty() ? 50 : 2);
+    if (timeout_ms >= 0) {
+      const auto now = std::chrono::steady_clock::now();
+      if (now >= t_end) break;
+      slice = std::min(slice, std::chrono::duration_cast<std::chrono::milliseconds>(t_end - now) + std::chrono::milliseconds(1));
+    }
+    f->cv_export.wait_for(lk, slice);
+  }
+  if (n_done) *n_done = f->exp_prefix;
   if (n_failed) *n_failed = f->exp_failed;
   return GAPRO_OK;
 }

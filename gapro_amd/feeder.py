@@ -82,11 +82,13 @@ class NativeFeeder:
                                              C.byref(b)))
         return int(n.value), int(b.value)
 
-    def upload(self, n: int, d_slab: int, slab_bytes: int):
-        """The next n loaded scenes into the device slab at address d_slab; returns (batch id, [TakenScene])."""
+    def upload(self, n: int, d_slab: int, slab_bytes: int, slab_stream: int = 0):
+        """The next n loaded scenes into the device slab at address d_slab (allocated on stream `slab_stream`: the copies
+        wait for what is queued there); returns (batch id, [TakenScene])."""
         recs = (FeedScene * n)()
         bid = C.c_int64(0)
-        self._check(self.lib.gapro_feed_upload(self.handle, n, C.c_void_p(d_slab), int(slab_bytes), recs, C.byref(bid)))
+        self._check(self.lib.gapro_feed_upload(self.handle, n, C.c_void_p(d_slab), int(slab_bytes),
+                                               C.c_void_p(slab_stream) if slab_stream else None, recs, C.byref(bid)))
         out = []
         for k in range(n):
             r = recs[k]

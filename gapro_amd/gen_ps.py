@@ -395,8 +395,11 @@ class Worker:
             bid, recs = self.feeder.upload(n, 0, 0)
             return recs, None, bid
         slab = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.dev)
-        bid, recs = self.feeder.upload(n, slab.data_ptr(), nbytes)
-        self.feeder.batch_wait(bid, torch.cuda.current_stream(self.dev).cuda_stream)
+        # the slab comes from the caching allocator on this stream: the feed's copies (its own stream) wait for what is
+        # queued here, e.g. the kernels of the block's previous owner
+        cur = torch.cuda.current_stream(self.dev).cuda_stream
+        bid, recs = self.feeder.upload(n, slab.data_ptr(), nbytes, cur)
+        self.feeder.batch_wait(bid, cur)
         return recs, slab, bid
 
     def _fail(self, fn, why):
@@ -608,14 +611,17 @@ class Worker:
                 self.failed += 1
                 self.done -= 1
                 self.failed_names.append("<write failed: %s>" % msg)
-        finally:  # queued writes are flushed and the threads released whatever happened above
-            self.keep = []
+        finally:
+            # The feeder's threads stop FIRST (a writer finishes the file it is on; on the error path the exports still
+            # queued are dropped -- a restart writes them, skip-if-exists), and only then may the device arrays and the
+            # event they read go back to the allocator (the other order freed memory under a running copy).
             self.wall_pool.shutdown(wait=False)
             th = getattr(self, "_prealloc_thread", None)
             if th is not None:
                 th.join()
             t_fin = time.time()
             self.feeder.destroy(process_is_exiting=_EXIT_AFTER_MAIN[0])
+            self.keep = []
             if getattr(self, "_torch_threads", None):
                 torch.set_num_threads(self._torch_threads)
         dt = t_written - t0

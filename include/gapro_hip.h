@@ -515,13 +515,18 @@ int gapro_feed_submit(gapro_feed* f, int32_t n, const char* const* scene_paths, 
                       const char* const* align_paths, const char* const* feat_paths);
 /* no further submit: polls stop waiting for scenes that will never come */
 int gapro_feed_close(gapro_feed* f);
-/* Block until min_ready scenes at the head of the order are loaded (fewer when the feed is closed and runs out),
- * timeout_ms passed (< 0: no limit); *n_ready = loaded scenes in a row from the head (<= max_scenes), *slab_bytes the
- * device bytes their images need. */
+/* Block until min_ready scenes at the head of the order are loaded (fewer when the feed is closed and runs out, or
+ * when the byte budget holds fewer: the call then returns what IS loaded as soon as no loader can make progress
+ * without the caller taking it -- it never waits for a count the budget cannot hold), or timeout_ms passed (< 0: no
+ * limit); *n_ready = loaded scenes in a row from the head (<= max_scenes), *slab_bytes the device bytes their images
+ * need. */
 int gapro_feed_poll(gapro_feed* f, int32_t min_ready, int32_t max_scenes, int32_t timeout_ms, int32_t* n_ready,
                     int64_t* slab_bytes);
-/* The next n loaded scenes: copies into d_slab (slab_bytes >= what poll reported for them), out[n], *batch_id. */
-int gapro_feed_upload(gapro_feed* f, int32_t n, void* d_slab, int64_t slab_bytes, gapro_feed_scene* out,
+/* The next n loaded scenes: copies into d_slab (slab_bytes >= what poll reported for them), out[n], *batch_id.  The
+ * copies run on the feed's own stream behind everything queued so far on slab_stream (hipStream_t; NULL = the default
+ * stream): the stream the slab was allocated on when it comes from a stream-ordered / caching allocator.  Sizes and
+ * states are validated before anything changes; after a HIP failure (GAPRO_ERR_HIP) the feed refuses further calls. */
+int gapro_feed_upload(gapro_feed* f, int32_t n, void* d_slab, int64_t slab_bytes, void* slab_stream, gapro_feed_scene* out,
                       int64_t* batch_id);
 int gapro_feed_batch_wait(gapro_feed* f, int64_t batch_id, void* stream);
 /* host-only mode: the images of a batch are no longer needed (device mode: recycles completed batches) */
@@ -529,7 +534,9 @@ int gapro_feed_release_batch(gapro_feed* f, int64_t batch_id);
 /* Queue n label files.  ready_event (hipEvent_t or NULL): recorded by the caller behind the kernels that produce the
  * arrays; they must stay valid until gapro_feed_export_wait has counted the scene. */
 int gapro_feed_export(gapro_feed* f, int32_t n, const gapro_feed_out* items, void* ready_event);
-/* wait until `until_done` label files (< 0: all queued so far) are written or failed */
+/* wait until the first `until_done` label files in submission order (< 0: all queued so far) are written or failed;
+ * *n_done = files finished as a CONTIGUOUS PREFIX of the submission order: the arrays of export k may be released
+ * when n_done > k, whatever later exports have finished already */
 int gapro_feed_export_wait(gapro_feed* f, int64_t until_done, int32_t timeout_ms, int64_t* n_done, int64_t* n_failed);
 int gapro_feed_export_error(gapro_feed* f, int32_t index, char* buf, int32_t cap);
 

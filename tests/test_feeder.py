@@ -143,3 +143,84 @@ def test_dry_run_worker_goes_through_the_feeder(tmp_path, capsys):
     for s in scenes:
         tup = torch.load(os.path.join(save + ".DRY_RUN", s.scan_name + ".pth"), weights_only=False)
         assert [len(a) for a in tup[:3]] == [s.n_points] * 3 and tup[0].dtype == np.int32
+
+
+def test_poll_for_more_scenes_than_the_budget_holds_returns_what_is_loaded(tmp_path):
+    """`poll(min_ready = batch, timeout = -1)` with a staging budget smaller than the batch waited for
+    ever -- the loaders blocked on the budget, the poller on the count, and the space only comes back through the
+    poller taking scenes.  Now the poll hands out what is loaded once no loader can make progress; every scene still
+    arrives, in order."""
+    import threading
+
+    from gapro_amd.feeder import NativeFeeder
+
+    root, scenes = _dataset(tmp_path, 8)
+    names = sorted(os.path.join(root, "train", s.scan_name + "_inst_nostuff.pth") for s in scenes)
+    f = NativeFeeder(-1, 3, 300 << 10)  # room for one or two of the eight scenes
+    got, err = [], []
+
+    def consume():
+        try:
+            while True:
+                n, _ = f.poll(8, 8, -1)  # asks for the whole list at once, no time limit
+                if n == 0:
+                    break
+                assert n < 8
+                bid, recs = f.upload(n, 0, 0)
+                got.extend(r.filename for r in recs)
+                assert all(r.status == 0 for r in recs)
+                f.release_batch(bid)
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+
+    try:
+        f.submit(names, root)
+        f.close()
+        t = threading.Thread(target=consume, daemon=True)
+        t.start()
+        t.join(60)
+        assert not t.is_alive(), "gapro_feed_poll is stuck behind the staging budget"
+        assert not err and got == names
+    finally:
+        f.destroy()
+
+
+def test_dry_run_worker_finishes_with_a_budget_smaller_than_a_batch(tmp_path, monkeypatch, capsys):
+    """The same through the driver (the case ADVICE r05 reproduced: GAPRO_FEED_BUDGET_MB=1, --batch_scenes 16)."""
+    from gapro_amd import gen_ps
+
+    root, scenes = _dataset(tmp_path, 12)
+    monkeypatch.setenv("GAPRO_FEED_BUDGET_MB", "1")
+    save = str(tmp_path / "labels")
+    rc = gen_ps.main(["--save_folder", save, "--data_root", root, "--batch_scenes", "16", "--dry_run"])
+    assert rc == 0 and "12 scenes written, 0 skipped/failed" in capsys.readouterr().out
+    assert sorted(os.listdir(save + ".DRY_RUN")) == sorted(s.scan_name + ".pth" for s in scenes)
+
+
+def test_export_wait_counts_a_contiguous_prefix(tmp_path):
+    """n_done of gapro_feed_export_wait is what a caller frees device memory by: exports finished as a prefix of the
+    submission order, not the number of finished writes (a small file queued behind a large one finishes first)."""
+    from gapro_amd.feeder import NativeFeeder
+
+    f = NativeFeeder(-1, 4, 256 << 20)
+    try:
+        rng = np.random.default_rng(0)
+        big = tuple(rng.random(4_000_000).astype(t) for t in (np.int32, np.int32, np.float32)) + \
+            (np.zeros(5, np.float32), np.zeros(5, np.float32))
+        small = tuple(np.zeros(4, t) for t in (np.int32, np.int32, np.float32, np.float32, np.float32))
+        items = [(str(tmp_path / "a.pth"),) + tuple(a.ctypes.data for a in big) + (4_000_000, 5)]
+        items += [(str(tmp_path / ("s%d.pth" % k)),) + tuple(a.ctypes.data for a in small) + (4, 4) for k in range(6)]
+        f.export(items)
+        seen = []
+        while True:
+            done, failed = f.export_wait(0, 0)
+            seen.append(done)
+            if done == 7:
+                break
+            # whenever the count says k, files 0 .. k-1 are complete on disk: the big one first
+            if done >= 1:
+                assert os.path.exists(str(tmp_path / "a.pth"))
+        assert failed == 0 and seen == sorted(seen)
+        assert (f.export_wait(-1, 60000)) == (7, 0)
+    finally:
+        f.destroy()
