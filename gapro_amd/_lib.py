@@ -139,6 +139,10 @@ SIGNATURES = {
     "gapro_pth_write": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(PthArray), C.POINTER(_P), C.c_int32]),
     "gapro_pth_last_error": (C.c_char_p, []),
     "gapro_pth_decoder": (C.c_char_p, []),
+    "gapro_pth_encoder": (C.c_char_p, []),
+    "gapro_pth_crc": (C.c_char_p, []),
+    "gapro_pth_crc32": (C.c_uint32, [_P, C.c_int64]),
+    "gapro_pth_encode_latin1": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     # batch feeder of the gen_ps driver (gapro_amd/feeder.py holds the structs)
     "gapro_feed_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "gapro_feed_destroy": (None, [_P]),
@@ -174,6 +178,24 @@ DEBUG_SIGNATURES = {
 
 _lib: Optional[C.CDLL] = None
 _dbg: Optional[C.CDLL] = None
+
+
+def source_build_id() -> str:
+    """Identity of the kernel sources this tree holds (sha256 over csrc/*.hip|h|cc|cpp and include/*.h, 16 hex digits):
+    bench.py prints it and the committed PMC passes carry it, so that a traffic figure is only ever attached to a
+    bench line of the SAME build."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = []
+    for pat in ("csrc/*.hip", "csrc/*.h", "csrc/*.cc", "csrc/*.cpp", "../include/*.h"):
+        files += glob.glob(os.path.join(_HERE, pat))
+    for fn in sorted(files, key=os.path.basename):
+        h.update(os.path.basename(fn).encode())
+        with open(fn, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def load_debug() -> C.CDLL:

@@ -31,6 +31,7 @@
 #include <unistd.h>
 
 #include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,15 @@
 namespace {
 
 thread_local std::string t_err;
+// resize() without the zero fill: the payload area is overwritten by the encoder right away (a label file is ~3 MB of it)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  template <class U, class... A> void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
 int fail(int code, const std::string& msg) {
   t_err = msg;
   return code;
@@ -220,8 +230,13 @@ decode_fn pick_decoder() {
   return decode_scalar;
 }
 
-// latin-1 -> UTF-8: returns the encoded length; dst needs 2 n bytes of room
-long long encode_utf8(const unsigned char* src, long long n, unsigned char* dst) {
+// ---- latin-1 -> UTF-8 (the writer's half of the transcoding) ---------------------------------------------------------
+// Returns the encoded length; dst needs 2 n + 64 bytes of room (the vector tiers store whole registers).  Round 5's
+// byte loop took 4.6 ms of a core per 150 k-point label file -- half of the host work per scene, which is what caps
+// any number of workers under the pool's CPU quota -- while the reader had three SIMD tiers.
+typedef long long (*encode_fn)(const unsigned char* src, long long n, unsigned char* dst);
+
+long long encode_scalar(const unsigned char* src, long long n, unsigned char* dst) {
   unsigned char* d = dst;
   for (long long i = 0; i < n; ++i) {
     const unsigned b = src[i];
@@ -233,7 +248,105 @@ long long encode_utf8(const unsigned char* src, long long n, unsigned char* dst)
   return (long long)(d - dst);
 }
 
-// ---- CRC-32 (zip), slice-by-8 -----------------------------------------------------------------------------------
+#if defined(__x86_64__)
+// 32 input bytes per iteration, the mirror of decode_avx512: every byte b becomes the 16-bit lane
+// [b < 0x80 ? b : 0xC0 | b >> 6,  0x80 | (b & 0x3F)], and vpcompressb keeps the first byte of every lane and the second
+// one where b >= 0x80.  64 ASCII bytes (label arrays are mostly small integers) are copied as they are.
+__attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt"))) long long encode_avx512(const unsigned char* src,
+                                                                                           long long n,
+                                                                                           unsigned char* dst) {
+  unsigned char* d = dst;
+  long long i = 0;
+  const __m512i v3f = _mm512_set1_epi16(0x3F), v80hi = _mm512_set1_epi16((short)0x8000), vc0 = _mm512_set1_epi16(0xC0);
+  const __m512i v7f = _mm512_set1_epi16(0x7F);
+  while (i + 64 <= n) {
+    const __m512i v = _mm512_loadu_si512((const void*)(src + i));
+    const unsigned long long hi = (unsigned long long)_mm512_movepi8_mask(v);
+    if (!hi) {
+      _mm512_storeu_si512((void*)d, v);
+      d += 64;
+      i += 64;
+      continue;
+    }
+    for (int half = 0; half < 2; ++half) {
+      const __m256i h = _mm256_loadu_si256((const __m256i*)(src + i + 32 * half));
+      const unsigned hm = (unsigned)(hi >> (32 * half));
+      const __m512i x = _mm512_cvtepu8_epi16(h);                         // [b, 0] per lane
+      const __mmask32 big = _mm512_cmpgt_epu16_mask(x, v7f);
+      const __m512i lead = _mm512_or_si512(vc0, _mm512_srli_epi16(x, 6));
+      const __m512i lo = _mm512_mask_blend_epi16(big, x, lead);
+      const __m512i second = _mm512_or_si512(v80hi, _mm512_slli_epi16(_mm512_and_si512(x, v3f), 8));
+      const __m512i lanes = _mm512_or_si512(lo, second);
+      const unsigned long long keep = 0x5555555555555555ULL | _pdep_u64((unsigned long long)hm, 0xAAAAAAAAAAAAAAAAULL);
+      _mm512_storeu_si512((void*)d, _mm512_maskz_compress_epi8(keep, lanes));
+      d += 32 + _mm_popcnt_u32(hm);
+    }
+    i += 64;
+  }
+  return (long long)(d - dst) + encode_scalar(src + i, n - i, d);
+}
+
+// The same four bytes at a time in a 64-bit word for CPUs without AVX-512 VBMI2: pdep spreads the bytes into 16-bit
+// lanes, the two output bytes of every lane are built by SWAR arithmetic, pext drops the second byte of ASCII lanes.
+__attribute__((target("bmi2,popcnt"))) long long encode_bmi2(const unsigned char* src, long long n, unsigned char* dst) {
+  const unsigned long long LO = 0x00FF00FF00FF00FFULL;
+  unsigned char* d = dst;
+  long long i = 0;
+  for (; i + 8 <= n; i += 8) {
+    unsigned long long w;
+    memcpy(&w, src + i, 8);
+    if (!(w & 0x8080808080808080ULL)) {
+      memcpy(d, &w, 8);
+      d += 8;
+      continue;
+    }
+    for (int half = 0; half < 2; ++half) {
+      const unsigned long long x = _pdep_u64((w >> (32 * half)) & 0xFFFFFFFFULL, LO);
+      const unsigned long long h = x & 0x0080008000800080ULL;
+      const unsigned long long hm = (h >> 7) * 0xFFULL;  // 0x00FF in the lanes of bytes >= 0x80
+      const unsigned long long lead = ((x >> 6) & 0x0003000300030003ULL) | 0x00C000C000C000C0ULL;
+      const unsigned long long first = (x & ~hm) | (lead & hm);
+      const unsigned long long second = ((x & 0x003F003F003F003FULL) | 0x0080008000800080ULL) << 8;
+      const unsigned long long packed = _pext_u64(first | second, LO | (hm << 8));
+      memcpy(d, &packed, 8);
+      d += 4 + _mm_popcnt_u64(h);
+    }
+  }
+  return (long long)(d - dst) + encode_scalar(src + i, n - i, d);
+}
+#endif
+
+const char* g_encoder_name = "scalar";
+encode_fn pick_encoder() {
+  // GAPRO_PTH_ENCODER = scalar | bmi2 | avx512 pins a tier (tests run every tier the CPU has)
+  const char* force = getenv("GAPRO_PTH_ENCODER");
+  const std::string want = force ? force : "";
+  if (want != "scalar") {
+#if defined(__x86_64__)
+    __builtin_cpu_init();
+    const bool hasbmi = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt");
+    const bool has512 = hasbmi && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
+                        __builtin_cpu_supports("avx512vbmi2");
+    if (has512 && want != "bmi2") {
+      g_encoder_name = "avx512";
+      return encode_avx512;
+    }
+    if (hasbmi) {
+      g_encoder_name = "bmi2";
+      return encode_bmi2;
+    }
+#endif
+  }
+  g_encoder_name = "scalar";
+  return encode_scalar;
+}
+long long encode_utf8(const unsigned char* src, long long n, unsigned char* dst) {
+  static const encode_fn enc = pick_encoder();
+  return (getenv("GAPRO_PTH_ENCODER") ? pick_encoder() : enc)(src, n, dst);
+}
+
+// ---- CRC-32 (zip) ---------------------------------------------------------------------------------------------------
+// slice-by-8 tables (the portable tier and the tail of the other one)
 struct CrcTable {
   unsigned t[8][256];
   CrcTable() {
@@ -246,9 +359,8 @@ struct CrcTable {
       for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xFF];
   }
 };
-unsigned crc32_buf(const unsigned char* p, size_t n) {
+unsigned crc32_table(const unsigned char* p, size_t n, unsigned c) {  // c: running state (already inverted)
   static const CrcTable T;
-  unsigned c = 0xFFFFFFFFu;
   while (n >= 8) {
     unsigned long long w;
     memcpy(&w, p, 8);
@@ -259,10 +371,103 @@ unsigned crc32_buf(const unsigned char* p, size_t n) {
     n -= 8;
   }
   while (n--) c = T.t[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
-  return c ^ 0xFFFFFFFFu;
+  return c;
 }
 
-// ---- the pickle subset ------------------------------------------------------------------------------------------
+#if defined(__x86_64__)
+// Carry-less-multiply folding (Gopal et al., "Fast CRC computation for generic polynomials using PCLMULQDQ", the
+// bit-reflected form for the zip polynomial 0xEDB88320): four 128-bit lanes folded across 64 bytes per iteration with
+// x^(512+-32) mod P, then 4 -> 1 lanes with x^(128+-32), 128 -> 64 -> 32 bits by one more fold and a Barrett
+// reduction.  n >= 64 and a multiple of 16; returns the running state.  Held to the table tier on every length by
+// tests/test_pth_io.py.
+__attribute__((target("pclmul,sse4.1"))) unsigned crc32_clmul(const unsigned char* buf, size_t len, unsigned crc) {
+  const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596LL, 0x0154442bd4LL);
+  const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009eLL, 0x01751997d0LL);
+  const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124LL);
+  const __m128i poly = _mm_set_epi64x(0x01f7011641LL, 0x01db710641LL);
+  __m128i x1 = _mm_loadu_si128((const __m128i*)(buf + 0x00)), x2 = _mm_loadu_si128((const __m128i*)(buf + 0x10));
+  __m128i x3 = _mm_loadu_si128((const __m128i*)(buf + 0x20)), x4 = _mm_loadu_si128((const __m128i*)(buf + 0x30));
+  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+  buf += 64;
+  len -= 64;
+  while (len >= 64) {
+    const __m128i a1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), a2 = _mm_clmulepi64_si128(x2, k1k2, 0x00);
+    const __m128i a3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), a4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, k1k2, 0x11);
+    x2 = _mm_clmulepi64_si128(x2, k1k2, 0x11);
+    x3 = _mm_clmulepi64_si128(x3, k1k2, 0x11);
+    x4 = _mm_clmulepi64_si128(x4, k1k2, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, a1), _mm_loadu_si128((const __m128i*)(buf + 0x00)));
+    x2 = _mm_xor_si128(_mm_xor_si128(x2, a2), _mm_loadu_si128((const __m128i*)(buf + 0x10)));
+    x3 = _mm_xor_si128(_mm_xor_si128(x3, a3), _mm_loadu_si128((const __m128i*)(buf + 0x20)));
+    x4 = _mm_xor_si128(_mm_xor_si128(x4, a4), _mm_loadu_si128((const __m128i*)(buf + 0x30)));
+    buf += 64;
+    len -= 64;
+  }
+  // (a macro, not a lambda: a lambda does not inherit this function's target attribute)
+#define GAPRO_CRC_FOLD(acc, next) \
+  _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(acc, k3k4, 0x11), _mm_clmulepi64_si128(acc, k3k4, 0x00)), next)
+  x1 = GAPRO_CRC_FOLD(x1, x2);
+  x1 = GAPRO_CRC_FOLD(x1, x3);
+  x1 = GAPRO_CRC_FOLD(x1, x4);
+  while (len >= 16) {
+    x1 = GAPRO_CRC_FOLD(x1, _mm_loadu_si128((const __m128i*)buf));
+    buf += 16;
+    len -= 16;
+  }
+#undef GAPRO_CRC_FOLD
+  // 128 -> 64 bits
+  const __m128i mask32 = _mm_setr_epi32(~0, 0, ~0, 0);
+  __m128i t = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+  x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), t);
+  t = _mm_srli_si128(x1, 4);
+  x1 = _mm_and_si128(x1, mask32);
+  x1 = _mm_xor_si128(_mm_clmulepi64_si128(x1, k5, 0x00), t);
+  // Barrett reduction to 32 bits
+  t = _mm_and_si128(x1, mask32);
+  t = _mm_clmulepi64_si128(t, poly, 0x10);
+  t = _mm_and_si128(t, mask32);
+  t = _mm_clmulepi64_si128(t, poly, 0x00);
+  x1 = _mm_xor_si128(x1, t);
+  return (unsigned)_mm_extract_epi32(x1, 1);
+}
+#endif
+
+const char* g_crc_name = "table";
+bool pick_crc_clmul() {
+  // GAPRO_PTH_CRC = table | clmul pins a tier
+  const char* force = getenv("GAPRO_PTH_CRC");
+  if (force && std::string(force) == "table") {
+    g_crc_name = "table";
+    return false;
+  }
+#if defined(__x86_64__)
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) {
+    g_crc_name = "clmul";
+    return true;
+  }
+#endif
+  g_crc_name = "table";
+  return false;
+}
+unsigned crc32_buf(const unsigned char* p, size_t n) {
+  static const bool clmul_default = pick_crc_clmul();
+  const bool clmul = getenv("GAPRO_PTH_CRC") ? pick_crc_clmul() : clmul_default;
+  unsigned c = 0xFFFFFFFFu;
+#if defined(__x86_64__)
+  if (clmul && n >= 64) {
+    const size_t m = n & ~(size_t)15;
+    c = crc32_clmul(p, m, c);
+    p += m;
+    n -= m;
+  }
+#else
+  (void)clmul;
+#endif
+  return crc32_table(p, n, c) ^ 0xFFFFFFFFu;
+}
+
 struct Val;
 typedef std::shared_ptr<Val> VP;
 enum Kind { V_NONE, V_BOOL, V_INT, V_STR, V_BYTES, V_ENCBYTES, V_GLOBAL, V_TUPLE, V_LIST, V_MARK, V_DTYPE, V_NDARRAY };
@@ -607,6 +812,23 @@ const char* gapro_pth_decoder(void) {
   return g_decoder_name;
 }
 
+const char* gapro_pth_encoder(void) {
+  (void)pick_encoder();
+  return g_encoder_name;
+}
+
+const char* gapro_pth_crc(void) {
+  (void)pick_crc_clmul();
+  return g_crc_name;
+}
+
+uint32_t gapro_pth_crc32(const void* data, int64_t n) { return data && n >= 0 ? crc32_buf((const unsigned char*)data, (size_t)n) : 0; }
+
+int64_t gapro_pth_encode_latin1(const void* src, int64_t n, void* dst, int64_t dst_cap) {
+  if (!src || !dst || n < 0 || dst_cap < 2 * n + 64) return GAPRO_ERR_BAD_ARG;
+  return encode_utf8((const unsigned char*)src, n, (unsigned char*)dst);
+}
+
 void gapro_pth_close(gapro_pth_file* f) {
   if (!f) return;
   if (f->map && f->owned) free((void*)f->map);
@@ -847,7 +1069,7 @@ int gapro_scene_instance_boxes(const double* h_xyz, const double* h_inst, const 
 // ---- writer -----------------------------------------------------------------------------------------------------
 namespace {
 struct Buf {
-  std::vector<unsigned char> v;
+  std::vector<unsigned char, NoInitAlloc<unsigned char>> v;
   void b(unsigned x) { v.push_back((unsigned char)x); }
   void u16(unsigned x) { b(x & 0xFF); b((x >> 8) & 0xFF); }
   void u32(unsigned long long x) { for (int i = 0; i < 4; ++i) b((unsigned)(x >> (8 * i)) & 0xFF); }
@@ -867,8 +1089,17 @@ int gapro_pth_write(const char* path, int32_t n_arrays, const gapro_pth_array* d
                     int32_t as_tuple) {
   if (!path || n_arrays <= 0 || !descs || !h_data || (!as_tuple && n_arrays != 1))
     return fail(GAPRO_ERR_BAD_ARG, "gapro_pth_write: bad argument");
-  Buf pk;
-  pk.v.reserve(1 << 20);
+  // One pickle buffer per writer thread, kept at its capacity between files: a fresh 3 .. 6 MB vector per file is an
+  // mmap, ~1500 first-touch page faults and (growing array by array) three reallocations with copies -- 3 of the 4 ms
+  // a label file took once the transcoder and the CRC were vectorised.
+  static thread_local Buf pk_tls;
+  Buf& pk = pk_tls;
+  pk.v.clear();
+  {
+    size_t bound = 4096;
+    for (int a = 0; a < n_arrays; ++a) bound += 2 * (size_t)(descs[a].nbytes > 0 ? descs[a].nbytes : 0) + 512;
+    pk.v.reserve(bound);
+  }
   pk.b(0x80); pk.b(2);
   if (as_tuple) pk.b('(');
   for (int a = 0; a < n_arrays; ++a) {
@@ -909,7 +1140,7 @@ int gapro_pth_write(const char* path, int32_t n_arrays, const gapro_pth_array* d
     const size_t len_at = pk.v.size();
     pk.u32(0);
     const size_t at = pk.v.size();
-    pk.v.resize(at + 2 * (size_t)d.nbytes);
+    pk.v.resize(at + 2 * (size_t)d.nbytes + 64);  // (+ 64: the vector tiers store whole registers)
     const long long enc = encode_utf8((const unsigned char*)h_data[a], d.nbytes, pk.v.data() + at);
     pk.v.resize(at + (size_t)enc);
     if (enc > 0xFFFFFFFFLL) return fail(GAPRO_ERR_UNSUPPORTED, "gapro_pth_write: payload beyond 4 GiB");

@@ -329,9 +329,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) d2 lds_d2;
 typedef __attribute__((address_space(1))) d2 g_d2;
 
+#ifdef GAPRO_GEMM_INLINE  // A/B build (round 6, profiles/r06_spill_traffic.md): no call, no callee-saved register traffic
+#define GAPRO_GEMM_ATTR __forceinline__
+#else
+#define GAPRO_GEMM_ATTR __noinline__
+#endif
 template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, bool TRIM = false, int PK = 0, int QK = 0,
           typename KRange, typename Epi>
-__device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
+__device__ GAPRO_GEMM_ATTR void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
                                      const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
                                      Epi epi) {
   mo_tiles = uni(mo_tiles);

@@ -450,6 +450,14 @@ const char* gapro_pth_last_error(void);
 /* which UTF-8 -> byte transcoder this process uses: "avx512" (VBMI2), "bmi2" or "scalar" (GAPRO_PTH_DECODER pins one;
  * a tier the CPU lacks falls back to the next) */
 const char* gapro_pth_decoder(void);
+/* the writer's tiers: byte -> UTF-8 transcoder "avx512" / "bmi2" / "scalar" (GAPRO_PTH_ENCODER pins one) and zip CRC-32
+ * "clmul" (PCLMULQDQ folding) / "table" (slice-by-8; GAPRO_PTH_CRC pins one) */
+const char* gapro_pth_encoder(void);
+const char* gapro_pth_crc(void);
+/* the two writer primitives on their own (tests hold every tier to the scalar one): CRC-32 of n bytes; latin-1 -> UTF-8
+ * of n bytes into dst (dst_cap >= 2 n + 64), returns the encoded length or a negative gapro_status */
+uint32_t gapro_pth_crc32(const void* data, int64_t n);
+int64_t gapro_pth_encode_latin1(const void* src, int64_t n, void* dst, int64_t dst_cap);
 /* The reference's default features (gen_ps.py:55: np.concatenate([xyz, rgb], -1) of the UN-aligned coordinates, uploaded
  * as float32 at :84): h_feats[n][6] = float32 of [xyz | rgb], one pass on the host. */
 int gapro_scene_default_feats(const double* h_xyz, const double* h_rgb, int64_t n_points, float* h_feats);

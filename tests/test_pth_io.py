@@ -308,3 +308,58 @@ def test_native_host_passes_equal_the_numpy_mirrors():
         _same(feats, np.concatenate([sc.xyz, sc.rgb], -1).astype(np.float32))
     assert getInstanceInfo_native(xyz, np.full(len(xyz), -100.0), sc.sem) is None
     assert getInstanceInfo(xyz, np.full(len(xyz), -100.0), sc.sem) is None
+
+
+def test_every_encoder_and_crc_tier_agrees_with_the_scalar_one(monkeypatch):
+    """The writer's two primitives: latin-1 -> UTF-8 in the AVX-512 VBMI2 / BMI2 / scalar tiers and
+    the zip CRC-32 by PCLMULQDQ folding / slice-by-8 tables, on every byte value at every offset modulo 64 and on every
+    length around the tiers' block sizes -- against Python's own encoder and zlib.crc32.  (A tier the CPU lacks falls
+    back to the next one and must still agree.)"""
+    import ctypes as C
+    import zlib
+
+    from gapro_amd import _lib
+
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    cases = [b"", b"\x80", b"\x7f" * 63 + b"\xff"]
+    for off in range(0, 70):
+        cases.append(bytes(off) + bytes(range(256)) + rng.integers(0, 256, 300 + off, dtype=np.uint8).tobytes()
+                     + b"\xc3" * 130 + b"\x7f" * 67 + b"\x80" * 129 + rng.integers(0, 128, 200, dtype=np.uint8).tobytes())
+    for n in list(range(0, 200)) + [255, 256, 257, 1023, 4096 + 17, 100_003]:
+        cases.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    seen_enc, seen_crc = set(), set()
+    for tier in ("scalar", "bmi2", "avx512"):
+        monkeypatch.setenv("GAPRO_PTH_ENCODER", tier)
+        seen_enc.add(lib.gapro_pth_encoder().decode())
+        for raw in cases:
+            want = raw.decode("latin1").encode("utf-8")
+            dst = C.create_string_buffer(2 * len(raw) + 64)
+            n = lib.gapro_pth_encode_latin1(raw, len(raw), dst, len(dst))
+            assert n == len(want) and dst.raw[:n] == want, (tier, len(raw))
+    for tier in ("table", "clmul"):
+        monkeypatch.setenv("GAPRO_PTH_CRC", tier)
+        seen_crc.add(lib.gapro_pth_crc().decode())
+        for raw in cases:
+            assert lib.gapro_pth_crc32(raw, len(raw)) == zlib.crc32(raw), (tier, len(raw))
+    assert "scalar" in seen_enc and "table" in seen_crc
+
+
+def test_label_files_of_every_writer_tier_are_byte_equal(tmp_path, monkeypatch):
+    from gapro_amd import pth_io
+
+    rng = np.random.default_rng(3)
+    n, s = 50_000, 900
+    arrs = (rng.integers(-100, 19, n).astype(np.int32), rng.integers(-100, 40, n).astype(np.int32),
+            rng.random(n).astype(np.float32), rng.normal(size=s).astype(np.float32), rng.random(s).astype(np.float32))
+    blobs = []
+    for enc, crc in (("scalar", "table"), ("bmi2", "clmul"), ("avx512", "clmul")):
+        monkeypatch.setenv("GAPRO_PTH_ENCODER", enc)
+        monkeypatch.setenv("GAPRO_PTH_CRC", crc)
+        p = str(tmp_path / "scene0000_00.pth")
+        assert pth_io.save_arrays(p, arrs)
+        with open(p, "rb") as fh:
+            blobs.append(fh.read())
+        for a, b in zip(torch.load(p, weights_only=False), arrs):
+            _same(a, b)
+    assert blobs[0] == blobs[1] == blobs[2]

@@ -41,8 +41,10 @@ def test_kat_set_covers_both_feature_widths_and_every_kernel_route():
 @pytest.mark.parametrize("name", KATS)
 def test_oracle_reproduces_its_frozen_vectors(name):
     z, X, y, Xt = _kat(name)
-    if len(X) > 160:
-        pytest.skip("the large vectors are compared on the GPU box only (CPU time)")
+    if len(X) > 160 and not os.environ.get("GAPRO_RUN_SLOW"):
+        # minutes of CPU per vector: run once per round in the build container with GAPRO_RUN_SLOW=1 (the output is
+        # committed as profiles/rNN_kat_slow.txt), so that the large vectors are re-derived SOMEWHERE
+        pytest.skip("slow: GAPRO_RUN_SLOW=1 python -m pytest tests/test_svgp_kat.py -k frozen_vectors")
     (mu, var, p), st = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64", return_trace=True)
     np.testing.assert_allclose(st["loss"], z["loss"], rtol=1e-9)
     np.testing.assert_allclose(var, z["var"], rtol=1e-7)

@@ -12,6 +12,7 @@ import json
 import os
 import re
 import shutil
+import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -79,7 +80,12 @@ def main():
     write_unit = n_bytes * (w_launches / 2) / w_sum if w_sum else None  # half of the launches (mode 1) write n_bytes
     pf = counters(os.path.join(src, "pmc_fetch", "bench_counter_collection.csv"))
     pw = counters(os.path.join(src, "pmc_write", "bench_counter_collection.csv"))
-    traffic = {"workload": {"name": a.workload, "scenes_per_step": a.scenes_per_step, "points": a.points,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gapro_amd._lib import source_build_id
+
+    # the kernels these counters belong to: bench.py attaches the figure only to lines of the same build
+    traffic = {"build": bench.get("build_id") or source_build_id(),
+               "workload": {"name": a.workload, "scenes_per_step": a.scenes_per_step, "points": a.points,
                             "feat_dim": a.feat_dim, "distinct": a.distinct},
                "calibration": {"kernel": "k_stream_calib (one double per lane, grid-stride, 512 MiB per pass)",
                                "bytes_per_FETCH_SIZE_unit": fetch_unit, "bytes_per_WRITE_SIZE_unit": write_unit,
