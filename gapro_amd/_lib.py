@@ -120,6 +120,8 @@ SIGNATURES = {
     "gapro_fit_plan_workspace": (C.c_int64, [_P, C.c_int32, C.c_int32]),
     "gapro_svgp_fit_batch": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.POINTER(FitOptions), _P,
                                        C.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
+    "gapro_svgp_fit_batch_ex": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.POINTER(FitOptions), _P,
+                                          C.c_size_t, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gapro_fit_workspace_layout": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P]),
     "gapro_fit_route": (C.c_int, [C.c_int32, C.c_int32]),
     "gapro_fit_padded_m": (C.c_int, [C.c_int32, C.c_int32]),
@@ -144,6 +146,26 @@ SIGNATURES = {
     "gapro_pth_crc32": (C.c_uint32, [_P, C.c_int64]),
     "gapro_pth_encode_latin1": (C.c_int64, [_P, C.c_int64, _P, C.c_int64]),
     # batch feeder of the gen_ps driver (gapro_amd/feeder.py holds the structs)
+    "gapro_dev_alloc": (C.c_int, [_P, C.c_size_t, _P, C.POINTER(C.c_void_p)]),
+    "gapro_dev_free": (C.c_int, [_P, _P]),
+    "gapro_dev_trim": (C.c_int, [_P]),
+    "gapro_dev_stats": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int64)]),
+    "gapro_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "gapro_host_free": (C.c_int, [_P, _P]),
+    "gapro_stream_create": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "gapro_stream_destroy": (C.c_int, [_P, _P]),
+    "gapro_stream_sync": (C.c_int, [_P, _P]),
+    "gapro_device_sync": (C.c_int, [_P]),
+    "gapro_event_create": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_void_p)]),
+    "gapro_event_destroy": (C.c_int, [_P, _P]),
+    "gapro_event_record": (C.c_int, [_P, _P, _P]),
+    "gapro_stream_wait_event": (C.c_int, [_P, _P, _P]),
+    "gapro_event_sync": (C.c_int, [_P, _P]),
+    "gapro_event_query": (C.c_int, [_P, _P]),
+    "gapro_event_elapsed_ms": (C.c_int, [_P, _P, _P, C.POINTER(C.c_float)]),
+    "gapro_memcpy_async": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int32, _P]),
+    "gapro_memset_async": (C.c_int, [_P, _P, C.c_int32, C.c_size_t, _P]),
     "gapro_feed_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "gapro_feed_destroy": (None, [_P]),
     "gapro_feed_detach": (None, [_P]),

@@ -5,7 +5,7 @@
 # stamps (libgapro_hip_prof.so: never used by the product or the tests).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-srcs=(ctx.hip feeder.hip partition.hip svgp_fit.hip svgp_fit_small.hip svgp_fit_wave.hip svgp_fit_large.hip svgp_fit_cluster.hip labels.hip consumer.hip schedule.cpp pth_io.cc)
+srcs=(ctx.hip devmem.hip feeder.hip partition.hip svgp_fit.hip svgp_fit_small.hip svgp_fit_wave.hip svgp_fit_large.hip svgp_fit_cluster.hip labels.hip consumer.hip schedule.cpp pth_io.cc)
 # libgapro_hip_debug.so: measurement / self-test entry points (include/gapro_hip_debug.h), never loaded by the product
 debug_srcs=(svgp_fit_debug.hip debug_peak.hip)
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-pass-failed)

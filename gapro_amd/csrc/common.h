@@ -49,7 +49,9 @@ struct gapro_ctx {
   gapro_scene_task* d_task_ring = nullptr;
   unsigned task_pos = 0;
   struct gapro_fit_timing* armed_timing = nullptr;  // consumed by the next gapro_svgp_fit_batch
+  void* arena = nullptr;  // device-memory arena (devmem.hip), created on first use
 };
+void gapro_arena_destroy(gapro_ctx* ctx);  // devmem.hip
 
 // HIP events around the kernels of one fit launch, recorded on the streams the kernels run on.
 struct gapro_fit_timing {

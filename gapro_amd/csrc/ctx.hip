@@ -91,6 +91,7 @@ void gapro_ctx_destroy(gapro_ctx* ctx) {
   if (ctx->d_cl_stage) (void)hipFree(ctx->d_cl_stage);
   if (ctx->d_cl_ctl) (void)hipFree(ctx->d_cl_ctl);
   if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
+  gapro_arena_destroy(ctx);
   delete ctx;
 }
 

@@ -3392,6 +3392,36 @@ extern "C" int gapro_launch_fit_strip_small(void* stream, int n_fits, int n_wg, 
                                             int32_t* d_fit_status, double* d_fit_loss);
 extern "C" long long gapro_fit_strip_small_lds_bytes(int m, int feat_dim);
 
+// Conditioning figure of every fit of a launch (round 6): every kernel leaves the inverses of the 16 x 16 diagonal blocks of
+// its LAST Cholesky factor in the fit's workspace (f.dinv: the triangular solves read them; the wave-per-fit kernel, which
+// keeps L^-1 on chip, stores the diagonal on its way out), and the diagonal of L^-1 is 1 / L_jj.  One wave per fit:
+// cond[slot] = (max_j L_jj / min_j L_jj)^2 over the M real rows -- a lower bound of cond_2(K_ZZ + jitter I) that costs a
+// few hundred loads per fit.  Fits whose sigma^2 no float64 implementation reproduces to 1e-4 are exactly
+// the ones where this figure is large; the caller gets it next to the status instead of finding out from an oracle.
+__global__ __launch_bounds__(256) void k_fit_cond(int n_fits, int D, const gapro_fit_desc* __restrict__ descs,
+                                                  const double* __restrict__ ws, double* __restrict__ out) {
+  const int fit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (fit >= n_fits) return;
+  const gapro_fit_desc d = descs[fit];
+  const int M = d.m1 + d.m2;
+  const Layout lay = make_layout(M, d.t, D);
+  const double* dinv = ws + d.ws_offset + lay.dinv;
+  double rmin = 1e300, rmax = 0.0;
+  for (int j = lane; j < M; j += 64) {
+    const double r = fabs(dinv[(size_t)(j >> 4) * 256 + 17 * (j & 15)]);
+    rmin = fmin(rmin, r);
+    rmax = fmax(rmax, r);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    rmin = fmin(rmin, __shfl_xor(rmin, o, 64));
+    rmax = fmax(rmax, __shfl_xor(rmax, o, 64));
+  }
+  if (lane == 0) {
+    const double q = rmax / rmin;  // = max L_jj / min L_jj
+    out[d.slot] = q * q;
+  }
+}
+
 // 0 = strip-streaming kernel, 1 = LDS-staged kernel, 2 = generic kernel, 3 = strip-streaming kernel of the small-fit
 // translation unit (M_p <= 64: 256 threads per fit, two fits per CU), 4 = cluster kernel (one fit over several
 // workgroups), 5 = the wave-per-fit kernel (svgp_fit_wave.hip: M_p <= 48 at feat_dim 6).  flags:
@@ -3444,6 +3474,16 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
                          const double* d_init_mean, const gapro_fit_options* opt, double* d_workspace,
                          size_t workspace_bytes, float* d_probs, float* d_probs_new, uint8_t* d_labels, float* d_mu,
                          float* d_var, int32_t* d_fit_status, double* d_fit_loss) {
+  return gapro_svgp_fit_batch_ex(ctx, stream_, n_fits, feat_dim, d_feats_spp, d_idx, h_descs, d_descs, d_init_mean, opt,
+                                 d_workspace, workspace_bytes, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status,
+                                 d_fit_loss, nullptr);
+}
+
+int gapro_svgp_fit_batch_ex(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t feat_dim, const float* d_feats_spp,
+                            const int32_t* d_idx, const gapro_fit_desc* h_descs, gapro_fit_desc* d_descs,
+                            const double* d_init_mean, const gapro_fit_options* opt, double* d_workspace,
+                            size_t workspace_bytes, float* d_probs, float* d_probs_new, uint8_t* d_labels, float* d_mu,
+                            float* d_var, int32_t* d_fit_status, double* d_fit_loss, double* d_fit_cond) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
   if (n_fits == 0) return GAPRO_OK;
   if (n_fits < 0 || feat_dim <= 0 || !d_feats_spp || !d_idx || !h_descs || !d_descs || !opt || !d_workspace ||
@@ -3787,6 +3827,10 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream_, int32_t n_fits, int32_t 
       GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[3], 0));
     }
   }
+  // conditioning figures, behind every kernel of the launch (they have been joined into `stream` above)
+  if (d_fit_cond)
+    hipLaunchKernelGGL(k_fit_cond, dim3((n_fits + 3) / 4), dim3(256), 0, stream, (int)n_fits, (int)feat_dim, d_descs,
+                       d_workspace, d_fit_cond);
   GAPRO_LAUNCH_CHECK(ctx);
   return GAPRO_OK;
 }

@@ -890,6 +890,12 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
     const int other = __shfl_xor(status, o, 64);  // (once per fit: the LDS crossbar will do)
     status = other < status ? other : status;
   }
+  // the diagonal of L^-1 (= 1 / L_jj of the last factorisation) where the other kernels keep their Dinv blocks: the
+  // launch's conditioning figures are read from there (k_fit_cond, svgp_fit.hip)
+  if (lane < M) {
+    const int kb = lane >> 4, j = lane & 15;
+    (wbase + lay.dinv)[(size_t)kb * 256 + 17 * j] = LIm[lt(kb, kb) * kTS + j * 17 + j];
+  }
   if (lane == 0) {
     if (status == GAPRO_OK && !isfinite(last_loss) && opt.training_iter > 0) status = GAPRO_ERR_NOT_FINITE;
     o_status[desc.slot] = status;

@@ -15,7 +15,7 @@ from .gen_ps_utils import _pick_device, _pipeline
 
 
 def fit_gp_spp_batch(feats_spp, problems, training_iter=50, init_mean=None, device=None, keep_debug=False,
-                     return_status=False, **pipe_kw):
+                     return_status=False, reproducibility_probe=False, **pipe_kw):
     """Fit many independent GPs in one launch.
 
     feats_spp  f32[S,D] (torch or numpy); problems = list of (b1_inds, b2_inds, intersect_inds).
@@ -25,6 +25,10 @@ def fit_gp_spp_batch(feats_spp, problems, training_iter=50, init_mean=None, devi
     jitter retries of gpytorch's psd_safe_cholesky) raises GaproError, as gpytorch raises there; with
     ``return_status=True`` nothing is raised and the per-fit gapro_status array (0 = ok) comes back as the last
     value: a failed fit does not affect the other fits of the launch.
+    The raw result dict carries ``cond``, a per-fit conditioning figure of the last Cholesky factor (a diagnostic), and
+    with ``reproducibility_probe=True`` (implies keep_debug; twice the work) ``repro_dv`` / ``repro_dp``: how far each
+    fit's sigma^2 (relative) and p (absolute) move when the initial variational mean is perturbed by 1e-13 -- beyond
+    pipeline.REPRO_SOFT (1e-6) a fit's variances are reproducible by no float64 implementation to 1e-4.
     """
     dev = _pick_device(feats_spp, device)
     pipe = _pipeline(dev, training_iter, **pipe_kw)
@@ -52,8 +56,11 @@ def fit_gp_spp_batch(feats_spp, problems, training_iter=50, init_mean=None, devi
         oo += len(it)
     h_idx = np.ascontiguousarray(np.concatenate(idx)) if idx else np.zeros(1, np.int32)
     h_init = np.concatenate(init) if init else None
+    keep_debug = keep_debug or reproducibility_probe
     res = pipe.fit_descs(f, descs, n, h_idx, oo, init_mean=h_init, keep_debug=keep_debug,
                          raise_on_failure=not return_status)
+    if reproducibility_probe:
+        res["repro_dv"], res["repro_dp"] = pipe.reproducibility_probe(f, descs, n, h_idx, oo, res=res, init_mean=h_init)
     outs = []
     for i in range(n):
         a, b = descs[i].out_offset, descs[i].out_offset + descs[i].t

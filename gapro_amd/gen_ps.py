@@ -294,17 +294,26 @@ class Worker:
         self.queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
         self.chunks = _chunks(filenames, args, self.queue)
         self.chunks_done = False
-        # torch FIRST, then the library: libgapro_hip.so binds to the HIP runtime that is already in the process (torch
-        # ships its own); loaded the other way round, torch.cuda.is_available() comes up False.  So a worker cannot start
-        # reading before its 1.2 s of `import torch` -- only the parent of a --devices run is spared it.
+        # Round 6: a worker runs on the library's own arena, streams and events (devmem.NativeBackend) and never imports
+        # torch -- 0.75 s of `import torch` + its HIP start-up stood in front of every worker's first read, for a job
+        # whose share of an eight-GPU node is 0.64 s of GPU work.  torch is still what the options
+        # that do tensor arithmetic in Python need (--eval_pslabel, --broadcast_mu_var, the host-only measurement mode)
+        # and what GAPRO_BACKEND=torch selects; then it comes FIRST: libgapro_hip.so binds to the HIP runtime already in
+        # the process, and loaded the other way round torch.cuda.is_available() comes up False.
         self.pipe = None
+        self.backend = None
         if not dry:
+            want = os.environ.get("GAPRO_BACKEND", "").strip().lower()
+            needs_torch = bool(args.eval_pslabel or args.broadcast_mu_var or os.environ.get("GAPRO_DRIVER_HOST_ONLY"))
+            self.backend = "torch" if (needs_torch or want == "torch") else "native"
+            if self.backend == "torch":
+                self._torch_threads = torch.get_num_threads()
+                torch.set_num_threads(1)  # restored by run(): tests and notebooks call main() in-process
             from .pipeline import Pipeline, make_job
 
             self.make_job = make_job
-            self._torch_threads = torch.get_num_threads()
-            torch.set_num_threads(1)  # restored by run(): tests and notebooks call main() in-process
-            self.pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed)
+            self.pipe = Pipeline(device=device_index, training_iter=50, init_mean_std=args.init_mean_std, seed=args.seed,
+                                 backend=self.backend)
             self.pipe.strict = False  # a scene that cannot be processed is reported and skipped, the rest is written
             if os.environ.get("GAPRO_DRIVER_TIMES"):
                 self.pipe.trace = []  # host-side stage timeline of the pipeline (printed at the end)
@@ -344,7 +353,7 @@ class Worker:
         batch_bytes = sum(sizes[:nb]) if self.queue is not None else 1.2 * nb * sum(sizes) / len(sizes)
         est = int(batch_bytes / 91.0 * 330.0 * 1.3)
         try:
-            free = torch.cuda.mem_get_info(self.dev)[0]
+            free = self.pipe.be.mem_get_info()[0]
         except Exception:  # noqa: BLE001
             free = 64 << 30
         est = min(est, 64 << 30, free // 3)
@@ -394,10 +403,11 @@ class Worker:
         if self.dry:
             bid, recs = self.feeder.upload(n, 0, 0)
             return recs, None, bid
-        slab = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.dev)
-        # the slab comes from the caching allocator on this stream: the feed's copies (its own stream) wait for what is
-        # queued here, e.g. the kernels of the block's previous owner
-        cur = torch.cuda.current_stream(self.dev).cuda_stream
+        be = self.pipe.be
+        slab = be.empty(max(nbytes, 256))
+        # the slab comes from a caching allocator (torch's, or the library's arena) on this stream: the feed's copies (its
+        # own stream) wait for what is queued here, e.g. the kernels of the block's previous owner
+        cur = be.current_stream().cuda_stream
         bid, recs = self.feeder.upload(n, slab.data_ptr(), nbytes, cur)
         self.feeder.batch_wait(bid, cur)
         return recs, slab, bid
@@ -421,15 +431,16 @@ class Worker:
         def view(off, nbytes, dtype, shape):
             return slab[off:off + nbytes].view(dtype).reshape(shape)
 
-        sc = dict(scan_name=_scan_name(r.filename), coords_float=view(oc, 24 * n, torch.float64, (n, 3)),
-                  mask_feats=view(of, 4 * d * n, torch.float32, (n, d)), spp=view(os_, 8 * n, torch.int64, (n,)),
-                  semantic_label=view(osem, 8 * n, torch.float64, (n,)),
-                  instance_label=view(oinst, 8 * n, torch.float64, (n,)))
+        be = self.pipe.be
+        sc = dict(scan_name=_scan_name(r.filename), coords_float=view(oc, 24 * n, be.f64, (n, 3)),
+                  mask_feats=view(of, 4 * d * n, be.f32, (n, d)), spp=view(os_, 8 * n, be.i64, (n,)),
+                  semantic_label=view(osem, 8 * n, be.f64, (n,)),
+                  instance_label=view(oinst, 8 * n, be.f64, (n,)))
         wall_box, wall_vol = self._walls(r.filename)
         sc["job"] = self.make_job(sc["coords_float"], sc["mask_feats"], sc["spp"], r.instance_cls, r.instance_box,
                              r.instance_box_volume, wall_box, wall_vol, instance_classes=18, ground_h=0.1,
                              thresh_spp_occu=0.999, device=self.dev,  # :106-110
-                             scene_key=zlib.crc32(sc["scan_name"].encode()))
+                             scene_key=zlib.crc32(sc["scan_name"].encode()), backend=be)
         return sc
 
     def _job_fallback(self, fn):
@@ -439,11 +450,14 @@ class Worker:
         sc = load_scene(fn, a.data_root, a.use_deepfeat, a.deepfeat_folder)
         if sc is None:
             return None
-        sc = scene_to_device(sc, self.dev)
+        if self.backend == "torch":
+            sc = scene_to_device(sc, self.dev)
+        # (native backend: make_job uploads the host arrays itself; the file was read with CPU torch, which is all that
+        # the reference's own loaders need)
         sc["job"] = self.make_job(sc["coords_float"], sc["mask_feats"], sc["spp"], sc["instance_cls"], sc["instance_box"],
                              sc["instance_box_volume"], sc["wall_box"], sc["wall_box_volume"], instance_classes=18,
                              ground_h=0.1, thresh_spp_occu=0.999, device=self.dev,
-                             scene_key=zlib.crc32(sc["scan_name"].encode()))
+                             scene_key=zlib.crc32(sc["scan_name"].encode()), backend=self.pipe.be)
         return sc
 
     def batches(self):
@@ -499,7 +513,8 @@ class Worker:
 
     def _export(self, scenes, jobs, outs, slab):
         a = self.args
-        ready = torch.cuda.current_stream(self.dev).record_event()  # run_stream ordered the outputs on this stream
+        be = self.pipe.be
+        ready = be.current_stream().record_event()  # run_stream ordered the outputs on this stream
         items, alive = [], [outs, slab, ready]
         for s, job, o in zip(scenes, jobs, outs):
             if o is None:  # Pipeline.strict = False: this scene could not be processed, the others could
@@ -518,7 +533,7 @@ class Worker:
                 print("miou", ious)
                 self.miou[s["scan_name"]] = ious.float().cpu().numpy()  # :125 ious_arr.append(ious)
             sem, ins, prob, mu, var = o
-            if sem.dtype != torch.int32 or ins.dtype != torch.int32:
+            if sem.dtype != be.i32 or ins.dtype != be.i32:
                 sem, ins = sem.int(), ins.int()
                 alive += [sem, ins]
             if a.broadcast_mu_var:
@@ -529,7 +544,7 @@ class Worker:
                           prob.data_ptr(), mu.data_ptr(), var.data_ptr(), sem.numel(), mu.numel()))
             self.done += 1
         if a.eval_pslabel or a.broadcast_mu_var:
-            ready = torch.cuda.current_stream(self.dev).record_event()
+            ready = be.current_stream().record_event()
             alive.append(ready)
         self.feeder.export(items, ready.cuda_event)
         self.keep.append((self.feeder.exported, alive))
@@ -635,9 +650,11 @@ class Worker:
         # the interpreter / library loads of a worker take a noticeable part of that
         t_first = self.t_first
         print("[gen_ps] device %d: start-up %.1f s (process start -> generator ready), first batch out after %.1f s more, "
-              "%d loader threads, %d loader processes, %s file I/O%s"
+              "%d loader threads, %d loader processes, %s file I/O, %s%s"
               % (dev_i, t0 - _T_IMPORT, (t_first - t0) if t_first else 0.0, self.n_threads, 0,
                  "native feeder (gapro_feed_*)" if native else "torch.load / torch.save",
+                 ("device plumbing: %s" % ("the library's own arena, streams and events" if self.backend == "native"
+                                           else "torch")) if self.backend else "no device",
                  ", dry run (no GPU)" if self.dry else (", host-only measurement mode" if host_only else "")))
         t_end = t0 + dt
         if t_first is not None and done > self.n_first and t_end > t_first:

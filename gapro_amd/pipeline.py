@@ -10,7 +10,9 @@ number of scenes share each device launch:
   stage E  gapro_schedule_merge      ordered merge, fallback, label tables        (host, C++)
   stage F  gapro_broadcast_labels    superpoint -> point                          (device)
 
-torch is used only to own device memory and streams; all arithmetic happens in libgapro_hip.so.
+All arithmetic happens in libgapro_hip.so.  Device memory, streams and events come from a backend (devmem.py): torch's
+(default: the Python API shims take and return torch tensors) or the library's own arena ("native": the gen_ps workers,
+which then never import torch -- round 6).
 """
 from __future__ import annotations
 
@@ -21,26 +23,27 @@ from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
 import numpy as np
-import torch
 
 from . import _lib
 from ._lib import Context, FitDesc, SceneHeader, SceneTask, ScheduleCounts
 
 
+# A fit is "soft" when its outputs move by more than this (sigma^2 relative, p absolute) under a 1e-13 perturbation of the
+# initial variational mean: fifty Adam steps amplify last-bit differences ~1e9-fold on such a fit, in ANY float64
+# implementation -- the other fits move by float32 rounding (6e-8) at most
+REPRO_SOFT = 1.0e-6
+
+
 def _ptr(t) -> C.c_void_p:
     if t is None:
         return C.c_void_p(0)
-    if isinstance(t, torch.Tensor):
+    if hasattr(t, "data_ptr"):  # torch.Tensor / devmem buffer
         return C.c_void_p(t.data_ptr())
     return C.c_void_p(t.ctypes.data)
 
 
-def _stream_handle(device: torch.device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-
-
 def _to_np(x, dtype):
-    if isinstance(x, torch.Tensor):
+    if hasattr(x, "detach"):  # torch.Tensor
         x = x.detach().cpu().numpy()
     return np.ascontiguousarray(np.asarray(x), dtype=dtype)
 
@@ -72,9 +75,9 @@ class LazyViews(dict):
 @dataclass
 class SceneJob:
     """Inputs of one gen_pseudo_label_gaussian_process call (reference gen_ps_utils.py:293-307)."""
-    coords: torch.Tensor  # f64[N,3] device
-    feats: torch.Tensor  # f32[N,D] device
-    spp: torch.Tensor  # i64[N] device
+    coords: object  # f64[N,3] device (torch.Tensor or devmem.DevBuf)
+    feats: object  # f32[N,D] device
+    spp: object  # i64[N] device
     instance_cls: np.ndarray  # i64[Bi]
     instance_box: np.ndarray  # f32[Bi,6]
     instance_box_volume: np.ndarray  # f32[Bi]
@@ -116,18 +119,32 @@ class SceneJob:
 
 def make_job(coords_float, mask_feats, spp, instance_cls, instance_box, instance_box_volume, wall_box,
              wall_box_volume, instance_classes=18, ground_h=0.1, thresh_spp_occu=0.8, device=None,
-             scene_key: int = 0) -> SceneJob:
-    device = torch.device(device if device is not None else "cuda:0")
+             scene_key: int = 0, backend=None) -> SceneJob:
+    """backend: a devmem.NativeBackend (arrays are its device buffers or host arrays; no torch), else torch."""
+    if backend is not None and backend.name == "native":
+        def dev(x, dtype):
+            if backend.is_device_array(x):
+                if x.dtype != np.dtype(dtype):
+                    raise ValueError("device buffer of dtype %s where %s is expected" % (x.dtype, np.dtype(dtype)))
+                return x
+            return backend.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=dtype))
 
-    def dev(x, dtype):
-        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
-        return t.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+        f64, f32, i64 = np.float64, np.float32, np.int64
+    else:
+        import torch
 
-    coords = dev(coords_float, torch.float64)
-    feats = dev(mask_feats, torch.float32)  # mask_feats.float()  gen_ps_utils.py:315
+        device = torch.device(device if device is not None else "cuda:0")
+
+        def dev(x, dtype):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+            return t.to(device=device, dtype=dtype, non_blocking=True).contiguous()
+
+        f64, f32, i64 = torch.float64, torch.float32, torch.int64
+    coords = dev(coords_float, f64)
+    feats = dev(mask_feats, f32)  # mask_feats.float()  gen_ps_utils.py:315
     if feats.dim() != 2 or coords.dim() != 2 or coords.shape[1] != 3 or feats.shape[0] != coords.shape[0]:
         raise ValueError("coords_float must be [N,3] and mask_feats [N,D]")
-    sp = dev(spp, torch.int64).reshape(-1)
+    sp = dev(spp, i64).reshape(-1)
     if sp.shape[0] != coords.shape[0]:
         raise ValueError("spp must have one id per point")
     ibox = _to_np(instance_box, np.float32).reshape(-1, 6)
@@ -211,13 +228,18 @@ class FitTiming:
 
 class Pipeline:
     def __init__(self, device=0, training_iter=50, init_mean_std=0.0, seed=0, eval_stale_chol=False,
-                 spp_range_cap=None, force_staged=False, precision="f64", cluster_all=False):
-        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
-        if not torch.cuda.is_available():
-            raise RuntimeError("gapro_amd needs a HIP device (torch.cuda.is_available() is False); "
-                               "there is no CPU fallback")
-        torch.cuda.set_device(self.device)
-        self.ctx = Context.get(self.device.index)
+                 spp_range_cap=None, force_staged=False, precision="f64", cluster_all=False, backend="torch"):
+        from .devmem import make_backend
+
+        if not isinstance(device, int):
+            import torch
+
+            device = torch.device(device).index or 0
+        # backend: "torch" (tensors in, tensors out) or "native" (the library's arena, no torch in the process);
+        # either raises when there is no HIP device -- there is no CPU fallback
+        self.be = make_backend(backend, device)
+        self.device = self.be.device
+        self.ctx = self.be.ctx
         self.lib = self.ctx.lib
         self.opt = _lib.default_fit_options(training_iter)
         self.opt.eval_stale_chol = 1 if eval_stale_chol else 0
@@ -249,6 +271,7 @@ class Pipeline:
         # factorisation) is run once more on the single-workgroup route before its scene is given up
         self.retry_timeouts = True
         self.timeout_retries = 0  # fits that went through the retry, over the life of this object
+
         self.init_mean_std = float(init_mean_std)
         self.seed = int(seed)
         self.spp_range_cap = spp_range_cap
@@ -277,6 +300,10 @@ class Pipeline:
         self._ws = {}  # slot -> fit workspace (device, float64)
         self._keep = {}
 
+    def _sh(self) -> C.c_void_p:
+        """raw handle of the backend's current stream"""
+        return C.c_void_p(self.be.current_stream().cuda_stream)
+
     # ------------------------------------------------------------------ batched partition plumbing
     def _task_array(self, jobs: Sequence[SceneJob]):
         """One gapro_scene_task per scene (host ctypes array + its device mirror), created once per batch and
@@ -285,7 +312,7 @@ class Pipeline:
         for t, job in zip(tasks, jobs):
             t.n_points = job.n_points
             t.coords, t.feats, t.spp = job.coords.data_ptr(), job.feats.data_ptr(), job.spp.data_ptr()
-        d_tasks = torch.empty(len(jobs) * C.sizeof(SceneTask), dtype=torch.uint8, device=self.device)
+        d_tasks = self.be.empty(len(jobs) * C.sizeof(SceneTask))
         return tasks, d_tasks
 
     @staticmethod
@@ -300,14 +327,14 @@ class Pipeline:
     def _part_event(self, jobs, name):
         if not self.profile_fit:
             return None
-        e0 = torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream(self.device))
+        e0 = self.be.event(enable_timing=True)
+        e0.record(self.be.current_stream())
         return dict(name=name, start=e0, points=sum(j.n_points for j in jobs), feat_dim=int(jobs[0].feats.shape[1]))
 
     def _part_event_end(self, ev):
         if ev is not None:
-            ev["end"] = torch.cuda.Event(enable_timing=True)
-            ev["end"].record(torch.cuda.current_stream(self.device))
+            ev["end"] = self.be.event(enable_timing=True)
+            ev["end"].record(self.be.current_stream())
             self.part_events.append(ev)
 
     # ------------------------------------------------------------------ stage A
@@ -348,28 +375,28 @@ class Pipeline:
 
     def _prepare_all(self, jobs: Sequence[SceneJob]):
         """Scene statistics + dense superpoint ranks of every scene: one launch per kernel, one sync."""
-        lib, devc = self.lib, self.device
+        lib, be = self.lib, self.be
         tasks, d_tasks = self._task_array(jobs)
         D = int(jobs[0].feats.shape[1])
         caps = [int(self.spp_range_cap) if self.spp_range_cap else max(4 * j.n_points, 1 << 20) for j in jobs]
         ws_off, ws_tot = self._carve([lib.gapro_partition_prepare_workspace_bytes(j.n_points, c)
                                       for j, c in zip(jobs, caps)])
-        prep_ws = torch.empty(ws_tot, dtype=torch.uint8, device=devc)
+        prep_ws = be.empty(ws_tot)
         inv_off, inv_tot = self._carve([4 * j.n_points for j in jobs])
-        spp_inv_all = torch.empty(inv_tot, dtype=torch.uint8, device=devc)
+        spp_inv_all = be.empty(inv_tot)
         hsz = C.sizeof(SceneHeader)
-        d_headers = torch.empty(len(jobs) * hsz, dtype=torch.uint8, device=devc)
-        pinned = self._pinned("headers%x" % int(torch.cuda.current_stream(devc).cuda_stream), len(jobs) * hsz)
+        d_headers = be.empty(len(jobs) * hsz)
+        pinned = self._pinned("headers%x" % int(be.current_stream().cuda_stream), len(jobs) * hsz)
         for t, job, cap, wo, io in zip(tasks, jobs, caps, ws_off, inv_off):
-            t.spp_inv = job.dev.spec("spp_inv", spp_inv_all, io, 4 * job.n_points, torch.int32, (job.n_points,))
+            t.spp_inv = job.dev.spec("spp_inv", spp_inv_all, io, 4 * job.n_points, be.i32, (job.n_points,))
             dict.__setitem__(job.host, "range_cap", cap)
             t.prepare_ws, t.spp_range_cap = prep_ws.data_ptr() + wo, cap
         ev = self._part_event(jobs, "prepare")
         self.ctx.check(lib.gapro_partition_prepare_batch(
-            self.ctx.handle, _stream_handle(devc), len(jobs), D, C.cast(tasks, C.c_void_p), _ptr(d_tasks),
+            self.ctx.handle, self._sh(), len(jobs), D, C.cast(tasks, C.c_void_p), _ptr(d_tasks),
             _ptr(d_headers), _ptr(pinned)))
         self._part_event_end(ev)
-        torch.cuda.current_stream(devc).synchronize()  # one sync for the whole batch
+        be.current_stream().synchronize()  # one sync for the whole batch
         raw = pinned.numpy()
         for i, job in enumerate(jobs):
             self._prepare_finish(job, SceneHeader.from_buffer_copy(raw[i * hsz:(i + 1) * hsz].tobytes()))
@@ -379,64 +406,63 @@ class Pipeline:
             for k, i in enumerate(good):
                 tasks2[k] = tasks[i]
             tasks = tasks2
-            d_tasks = torch.empty(max(len(good), 1) * C.sizeof(SceneTask), dtype=torch.uint8, device=devc)
+            d_tasks = be.empty(max(len(good), 1) * C.sizeof(SceneTask))
         return tasks, d_tasks
 
     # ------------------------------------------------------------------ stage B
-    def _pool(self, job: SceneJob, feats_spp_all: torch.Tensor, stage: Optional[torch.Tensor] = None, off: int = 0):
+    def _pool(self, job: SceneJob, feats_spp_all, stage=None, off: int = 0):
         """Single-scene form (tests)."""
         tasks, d_tasks = self._task_array([job])
         tasks[0].spp_inv = job.spp_inv.data_ptr()
         self._pool_all([job], tasks, d_tasks, feats_spp_all, stage)
 
-    def _pool_all(self, jobs: Sequence[SceneJob], tasks, d_tasks, feats_spp_all: torch.Tensor,
-                  stage: Optional[torch.Tensor] = None):
+    def _pool_all(self, jobs: Sequence[SceneJob], tasks, d_tasks, feats_spp_all, stage=None):
         """Fused membership + pooling of every scene: one launch per kernel; the two small tables the host
         scheduler needs (occ_bits, n_bbs) of all scenes come back in ONE device-to-host copy (no sync here)."""
-        lib, devc = self.lib, self.device
+        lib, be = self.lib, self.be
         D = int(jobs[0].feats.shape[1])
         # boxes of every scene: one pinned staging buffer, one upload
         box_off, box_tot = self._carve([j.boxes.nbytes for j in jobs], 64)
-        slot = "%x" % int(torch.cuda.current_stream(devc).cuda_stream)
+        slot = "%x" % int(be.current_stream().cuda_stream)
         h_boxes = self._pinned("boxes" + slot, box_tot)
         hb = h_boxes.numpy()
         for job, bo in zip(jobs, box_off):
             hb[bo:bo + job.boxes.nbytes] = job.boxes.view(np.uint8).reshape(-1)
-        d_boxes = torch.empty(box_tot, dtype=torch.uint8, device=devc)
+        d_boxes = be.empty(box_tot)
         d_boxes.copy_(h_boxes[:box_tot], non_blocking=True)
         # host-visible tables [occ_bits | n_bbs] per scene, laid out exactly like the pinned staging area
         tab_sizes = [j.n_spps * (((j.n_boxes + 63) // 64) * 8 + 4) for j in jobs]
         tab_off, tab_tot = self._carve(tab_sizes, 16)
-        d_tables = torch.empty(tab_tot, dtype=torch.uint8, device=devc)
+        d_tables = be.empty(tab_tot)
         # integer tallies [feat_sum i64 | occ_count i32 | point_count i32] per scene
         tal_sizes = [j.n_spps * (8 * D + 4 * j.n_boxes + 4) for j in jobs]
         tal_off, tal_tot = self._carve(tal_sizes, 16)
-        d_tallies = torch.empty(tal_tot, dtype=torch.uint8, device=devc)
+        d_tallies = be.empty(tal_tot)
         if stage is None:
-            stage = torch.empty(tab_tot, dtype=torch.uint8, pin_memory=True)
+            stage = be.pinned(tab_tot)
         fbase, fstride = feats_spp_all.data_ptr(), 4 * D
         for t, job, bo, to, ao in zip(tasks, jobs, box_off, tab_off, tal_off):
             S, B = job.n_spps, job.n_boxes
             W = (B + 63) // 64
             d = job.dev
-            t.boxes = d.spec("boxes", d_boxes, bo, job.boxes.nbytes, torch.float64, (B, 6))
-            t.feat_sum = d.spec("feat_sum", d_tallies, ao, 8 * S * D, torch.int64, (S, D))
-            t.occ_count = d.spec("occ_count", d_tallies, ao + 8 * S * D, 4 * S * B, torch.int32, (S, B))
-            t.point_count = d.spec("point_count", d_tallies, ao + 8 * S * D + 4 * S * B, 4 * S, torch.int32, (S,))
-            t.occ_bits = d.spec("occ_bits", d_tables, to, 8 * S * W, torch.int64, (S, W))
-            t.n_bbs = d.spec("n_bbs", d_tables, to + 8 * S * W, 4 * S, torch.int32, (S,))
+            t.boxes = d.spec("boxes", d_boxes, bo, job.boxes.nbytes, be.f64, (B, 6))
+            t.feat_sum = d.spec("feat_sum", d_tallies, ao, 8 * S * D, be.i64, (S, D))
+            t.occ_count = d.spec("occ_count", d_tallies, ao + 8 * S * D, 4 * S * B, be.i32, (S, B))
+            t.point_count = d.spec("point_count", d_tallies, ao + 8 * S * D + 4 * S * B, 4 * S, be.i32, (S,))
+            t.occ_bits = d.spec("occ_bits", d_tables, to, 8 * S * W, be.i64, (S, W))
+            t.n_bbs = d.spec("n_bbs", d_tables, to + 8 * S * W, 4 * S, be.i32, (S,))
             t.feats_spp = fbase + job.feats_row_base * fstride
             dict.__setitem__(d, "feats_spp", None)
-            d._specs["feats_spp"] = (feats_spp_all.view(torch.uint8).view(-1), job.feats_row_base * fstride, S * fstride,
-                                     torch.float32, (S, D))
+            d._specs["feats_spp"] = (feats_spp_all.view(be.u8).view(-1), job.feats_row_base * fstride, S * fstride,
+                                     be.f32, (S, D))
             dict.pop(d, "feats_spp", None)
             t.n_boxes, t.n_spps = B, S
             t.fixed_shift, t.thresh_spp_occu = int(job.header.fixed_shift), float(job.thresh_spp_occu)
             h = job.host
-            h.spec("occ_bits_pin", stage, to, 8 * S * W, torch.int64, (S, W))
-            h.spec("n_bbs_pin", stage, to + 8 * S * W, 4 * S, torch.int32, (S,))
+            h.spec("occ_bits_pin", stage, to, 8 * S * W, be.i64, (S, W))
+            h.spec("n_bbs_pin", stage, to + 8 * S * W, 4 * S, be.i32, (S,))
         ev = self._part_event(jobs, "pool")
-        self.ctx.check(lib.gapro_partition_pool_batch(self.ctx.handle, _stream_handle(devc), len(jobs), D,
+        self.ctx.check(lib.gapro_partition_pool_batch(self.ctx.handle, self._sh(), len(jobs), D,
                                                       C.cast(tasks, C.c_void_p), _ptr(d_tasks)))
         self._part_event_end(ev)
         stage[:tab_tot].copy_(d_tables, non_blocking=True)
@@ -473,7 +499,7 @@ class Pipeline:
 
     def _ensure_streams(self):
         if not hasattr(self, "_streams"):
-            self._streams = [torch.cuda.Stream(self.device) for _ in range(self.kSlots)]
+            self._streams = [self.be.new_stream() for _ in range(self.kSlots)]
             for st in self._streams:
                 self._ws.setdefault("s%x" % int(st.cuda_stream), None)
 
@@ -490,12 +516,12 @@ class Pipeline:
         outs = []
         # inputs produced on the caller's stream are ordered before both pipeline streams ONCE: an event on
         # the (legacy default) stream recorded per batch would also wait for every blocking stream
-        ready = torch.cuda.current_stream(self.device).record_event()
+        ready = self.be.current_stream().record_event()
         for st in self._streams:
             st.wait_event(ready)
         outs = list(self._stream_batches(iter(batches)))
         for st in self._streams:
-            torch.cuda.current_stream(self.device).wait_stream(st)
+            self.be.current_stream().wait_stream(st)
         return outs
 
     def warmup(self):
@@ -504,7 +530,7 @@ class Pipeline:
         allocator's first blocks -- ~0.2 s that would otherwise sit in front of the first batch."""
         rng = np.random.default_rng(0)
         sizes = [4, 12, 20, 30, 50, 75, 150, 280]
-        feats = torch.from_numpy(rng.normal(size=(2 * sum(sizes), 6)).astype(np.float32)).to(self.device)
+        feats = self.be.from_numpy(rng.normal(size=(2 * sum(sizes), 6)).astype(np.float32))
         descs = (FitDesc * len(sizes))()
         idx, io, oo, base = [], 0, 0, 0
         for k, m in enumerate(sizes):
@@ -527,17 +553,17 @@ class Pipeline:
         """Allocate the fit workspace ahead of its first use (a driver calls this from a helper thread while the first
         scenes are still being read: the hipMalloc + clear of ~25 GB takes 1.2 .. 2.4 s, a third of what a worker needs
         for the whole ScanNet train split).  A later need beyond this size grows it as usual."""
-        with torch.cuda.device(self.device):
+        with self.be.device_ctx():
             self._workspace(slot, max(1, int(n_bytes) // 8), headroom=1.0)
 
-    def _workspace(self, slot: str, n_doubles: int, headroom: Optional[float] = None) -> torch.Tensor:
+    def _workspace(self, slot: str, n_doubles: int, headroom: Optional[float] = None):
         """Grow-only fit workspace per pipeline slot.  Every registered slot grows together and new memory is
         touched once here: a slot first used inside a timed region would otherwise pay the allocation and the
         first-touch mapping of several GB inside its fit kernel."""
         with self._ws_lock:
             return self._workspace_locked(slot, n_doubles, headroom)
 
-    def _workspace_locked(self, slot: str, n_doubles: int, headroom: Optional[float]) -> torch.Tensor:
+    def _workspace_locked(self, slot: str, n_doubles: int, headroom: Optional[float]):
         self._ws.setdefault(slot, None)
         cur = self._ws[slot]
         if cur is None or cur.numel() < n_doubles:
@@ -550,8 +576,8 @@ class Pipeline:
             # whatever step first exceeds the old size (bench.py's sporadic 980 ms steps against 760 ms launches)
             size = int(n_doubles * (self.workspace_headroom if headroom is None else headroom)) + 1024
             if slot.endswith("retry"):  # a handful of timed-out fits: exactly their need, for one launch
-                self._ws[slot] = torch.zeros(n_doubles + 1024, dtype=torch.float64, device=self.device)
-                torch.cuda.current_stream(self.device).synchronize()
+                self._ws[slot] = self.be.zeros(n_doubles + 1024, self.be.f64)
+                self.be.current_stream().synchronize()
                 return self._ws[slot][:n_doubles]
             if self.trace is not None:
                 import time as _time
@@ -561,10 +587,10 @@ class Pipeline:
                     continue
                 if self._ws[k] is None or self._ws[k].numel() < size:
                     self._ws[k] = None  # release before growing
-                    self._ws[k] = torch.zeros(size, dtype=torch.float64, device=self.device)
+                    self._ws[k] = self.be.zeros(size, self.be.f64)
             # the fill runs on the allocating thread's stream; the fit kernels that use this memory run on other
             # streams (another pipeline slot's, the library's): nobody may get the tensor before the fill is done
-            torch.cuda.current_stream(self.device).synchronize()
+            self.be.current_stream().synchronize()
             if self.trace is not None:
                 import time as _time
                 self.trace.append((_time.perf_counter(), 0, "workspace ready"))
@@ -575,11 +601,11 @@ class Pipeline:
         every batch, in order, one batch behind the one being launched.  The consumer may use the yielded
         tensors on the current stream right away (they are ordered after the pipeline's streams)."""
         self._ensure_streams()
-        ready = torch.cuda.current_stream(self.device).record_event()
+        ready = self.be.current_stream().record_event()
         for st in self._streams:
             st.wait_event(ready)
         for i, out in enumerate(self._stream_batches(iter(batches))):
-            torch.cuda.current_stream(self.device).wait_stream(self._streams[i % self.kSlots])
+            self.be.current_stream().wait_stream(self._streams[i % self.kSlots])
             yield out
 
     def _stream_batches(self, it):
@@ -599,7 +625,7 @@ class Pipeline:
         S = self.kSlots
 
         def on(k, fn, *a):
-            with torch.cuda.stream(self._streams[k % S]):
+            with self.be.stream(self._streams[k % S]):
                 return fn(*a)
 
         # a batch is pulled from the iterator under the pipeline stream that will process it: whatever device work
@@ -634,11 +660,11 @@ class Pipeline:
             i += 1
         yield on(i - 1, self._finish, prev_state, True)
 
-    def _pinned(self, tag: str, nbytes: int) -> torch.Tensor:
+    def _pinned(self, tag: str, nbytes: int):
         """Growable page-locked staging buffers, reused across batches (hipHostMalloc is slow)."""
         buf = self._pin_cache.get(tag)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, pin_memory=True)
+            buf = self.be.pinned(max(nbytes, 1 << 16))
             self._pin_cache[tag] = buf
         return buf
 
@@ -657,7 +683,7 @@ class Pipeline:
             if self.trace is not None:  # host-side timeline, no synchronisation added
                 self.trace.append((_time.perf_counter(), id(jobs) & 0xFFFF, name))
             if self.profile_stages:
-                torch.cuda.synchronize(self.device)
+                self.be.synchronize()
                 now = _time.perf_counter()
                 self.stage_times[name] = self.stage_times.get(name, 0.0) + (now - t[0])
                 t[0] = now
@@ -666,9 +692,8 @@ class Pipeline:
 
     def _partition(self, jobs: Sequence[SceneJob], keep_debug: bool = False):
         """Stages A-B on the current stream: superpoint ids, pooled features, occupancy tables on the host."""
-        devc = self.device
         _mark = self._marker(jobs)
-        stream = torch.cuda.current_stream(devc)
+        stream = self.be.current_stream()
         slot = "s%x" % int(stream.cuda_stream)
         _mark("start")
         all_jobs = list(jobs)
@@ -685,7 +710,7 @@ class Pipeline:
                 raise ValueError("all scenes of a batch must share the feature dimension")
             job.feats_row_base = base
             base += job.n_spps
-        feats_spp_all = torch.empty((base, D), dtype=torch.float32, device=devc)
+        feats_spp_all = self.be.empty_typed((base, D), self.be.f32)
         # one pinned staging area for the tables the host scheduler needs from every scene
         need = sum(job.n_spps * (((job.n_boxes + 63) // 64) * 8 + 4) + 16 for job in jobs)
         stage = self._pinned(slot + "tables", need)
@@ -741,7 +766,7 @@ class Pipeline:
     def _finish(self, state, sync: bool = True):
         """Stages E-F: wait for the fit results, ordered merge on the host, broadcast on the device.  With
         sync=False the broadcast kernels are only enqueued (the outputs are ordered on the current stream)."""
-        lib, ctx, devc = self.lib, self.ctx, self.device
+        lib, ctx, be = self.lib, self.ctx, self.be
         jobs, keep_debug, _mark = state["jobs"], state["keep_debug"], state["mark"]
         _mark("finish")
         if not jobs:  # every scene of the batch was rejected (non-strict mode)
@@ -767,7 +792,7 @@ class Pipeline:
         busy = self._pin_events.pop(state["slot"] + "labels", None)
         if busy is not None:
             busy.synchronize()  # the previous batch of this slot has uploaded its label tables
-        d_tables = torch.empty(tot_s * 20, dtype=torch.uint8, device=devc)
+        d_tables = be.empty(tot_s * 20)
         tab_np = tables.numpy()
         views, off = [], 0
         offs = []
@@ -804,32 +829,32 @@ class Pipeline:
                 merge_one(arg)
         views = offs
         d_tables.copy_(tables[:tot_s * 20], non_blocking=True)  # one H2D copy for the whole batch
-        self._pin_events[state["slot"] + "labels"] = torch.cuda.current_stream(devc).record_event()
+        self._pin_events[state["slot"] + "labels"] = be.current_stream().record_event()
         tasks, d_tasks = state["tasks"], state["d_tasks"]
         out_off, out_tot = self._carve([12 * job.n_points for job in jobs], 16)
-        d_out = torch.empty(out_tot, dtype=torch.uint8, device=devc)  # [sem | inst | prob] per scene
+        d_out = be.empty(out_tot)  # [sem | inst | prob] per scene
         for t, job, off, oo in zip(tasks, jobs, views, out_off):
             S, n = job.n_spps, job.n_points
-            sem = d_out[oo:oo + 4 * n].view(torch.int32)
-            ins = d_out[oo + 4 * n:oo + 8 * n].view(torch.int32)
-            prb = d_out[oo + 8 * n:oo + 12 * n].view(torch.float32)
+            sem = d_out[oo:oo + 4 * n].view(be.i32)
+            ins = d_out[oo + 4 * n:oo + 8 * n].view(be.i32)
+            prb = d_out[oo + 8 * n:oo + 12 * n].view(be.f32)
             t.sem_spp = d_tables.data_ptr() + off
             t.inst_spp = d_tables.data_ptr() + off + 4 * S
             t.prob_spp = d_tables.data_ptr() + off + 8 * S
             t.sem, t.inst, t.prob = sem.data_ptr(), ins.data_ptr(), prb.data_ptr()
-            job.outputs = (sem, ins, prb, d_tables[off + 12 * S:off + 16 * S].view(torch.float32),
-                           d_tables[off + 16 * S:off + 20 * S].view(torch.float32))
+            job.outputs = (sem, ins, prb, d_tables[off + 12 * S:off + 16 * S].view(be.f32),
+                           d_tables[off + 16 * S:off + 20 * S].view(be.f32))
             if not keep_debug:
                 lib.gapro_schedule_free(job.schedule)
                 job.schedule = None
         ev = self._part_event(jobs, "broadcast")
-        ctx.check(lib.gapro_broadcast_labels_batch(ctx.handle, _stream_handle(devc), len(jobs),
+        ctx.check(lib.gapro_broadcast_labels_batch(ctx.handle, self._sh(), len(jobs),
                                                    C.cast(tasks, C.c_void_p), _ptr(d_tasks)))
         self._part_event_end(ev)
         # the task array must outlive the (possibly delayed) upload enqueued above
         self._keep[state["slot"]] = (tasks, d_tasks)
         if sync:
-            torch.cuda.current_stream(devc).synchronize()
+            be.current_stream().synchronize()
         _mark("E+F merge/broadcast")
         self.last_stats = dict(n_fits=state["n_fits"], n_fit_out=state["n_out"], fit=res)
         for j in jobs:
@@ -838,7 +863,7 @@ class Pipeline:
         return [j.outputs if j.error is None else None for j in state["all_jobs"]]
 
     # ------------------------------------------------------------------ stage D
-    def fit_descs(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
+    def fit_descs(self, feats_spp, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
                   init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, raise_on_failure: bool = True):
         """Launch a batch of fits and wait for the results (numpy arrays)."""
         res = self.fit_collect(self.fit_launch(feats_spp, descs, n_fits, h_idx, n_out, init_mean, keep_debug),
@@ -848,6 +873,31 @@ class Pipeline:
             bad = int(np.nonzero(res["status"])[0][0])
             raise _lib.GaproError(int(res["status"][bad]), "fit %d of %d failed" % (bad, n_fits))
         return res
+
+    def reproducibility_probe(self, feats_spp, descs, n_fits: int, h_idx: np.ndarray, n_out: int, res=None,
+                              init_mean: Optional[np.ndarray] = None, eps: float = 1e-13, seed: int = 12345):
+        """How far do a fit's outputs move when nothing but rounding changes?  The same fits once more with the initial
+        variational mean perturbed by eps * N(0, 1) (gpytorch itself starts from 1e-3 * randn: SURVEY B.1), compared
+        with `res` (the unperturbed run; computed here when not given).  Returns (dv, dp) per fit: the largest relative
+        change of sigma^2 and absolute change of p over the fit's test superpoints.  Well-behaved fits come back at
+        float32 rounding (<= 6e-8); a fit beyond REPRO_SOFT is one whose sigma^2 NO float64 implementation reproduces
+        to north_star's 1e-4 -- the reference against itself on another BLAS included.  Twice the work of the fits:
+        a caller's choice (fit_gp_spp_batch(..., reproducibility_probe=True)), not the default."""
+        if res is None:
+            res = self.fit_descs(feats_spp, descs, n_fits, h_idx, n_out, init_mean=init_mean, raise_on_failure=False)
+        rng = np.random.default_rng(seed)
+        base = np.zeros(len(h_idx)) if init_mean is None else np.asarray(init_mean, dtype=np.float64)
+        r2 = self.fit_descs(feats_spp, descs, n_fits, h_idx, n_out, init_mean=base + eps * rng.standard_normal(len(h_idx)),
+                            raise_on_failure=False)
+        dv, dp = np.zeros(n_fits), np.zeros(n_fits)
+        for k in range(n_fits):
+            d = descs[k]
+            a, b = int(d.out_offset), int(d.out_offset) + int(d.t)
+            if b > a:
+                v1, v2 = res["var"][a:b].astype(np.float64), r2["var"][a:b].astype(np.float64)
+                dv[k] = float(np.max(np.abs(v1 - v2) / np.maximum(np.abs(v1), 1e-30)))
+                dp[k] = float(np.max(np.abs(res["probs"][a:b].astype(np.float64) - r2["probs"][a:b].astype(np.float64))))
+        return dv, dp
 
     def _retry_timeouts(self, res, feats_spp, descs, h_idx, n_out, init_mean=None, slot="s0", scene_keys=None):
         """Fits whose status is GAPRO_ERR_TIMEOUT are launched once more with the cluster kernel switched off (debug
@@ -883,14 +933,15 @@ class Pipeline:
                 res[key][a:b] = r2[key][a:b]
             res["status"][i] = r2["status"][k]
             res["loss"][i] = r2["loss"][k]
+            res["cond"][i] = r2["cond"][k]
         self.timeout_retries += len(bad)
         res["retried"] = [int(i) for i in bad]
         return res
 
-    def fit_launch(self, feats_spp: torch.Tensor, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
+    def fit_launch(self, feats_spp, descs, n_fits: int, h_idx: np.ndarray, n_out: int,
                    init_mean: Optional[np.ndarray] = None, keep_debug: bool = False, slot: str = "s0",
                    scene_keys: Optional[Sequence[int]] = None):
-        lib, ctx, devc = self.lib, self.ctx, self.device
+        lib, ctx, be = self.lib, self.ctx, self.be
         D = int(feats_spp.shape[1])
         ws_bytes = int(lib.gapro_fit_plan_workspace(C.cast(descs, C.c_void_p), n_fits, D))
         if init_mean is None and self.init_mean_std > 0.0:
@@ -904,10 +955,9 @@ class Pipeline:
                 rng = np.random.default_rng([self.seed, key & 0xFFFFFFFF, int(d.b1), int(d.b2)])
                 m = int(d.m1 + d.m2)
                 init_mean[d.idx_offset:d.idx_offset + m] = self.init_mean_std * rng.standard_normal(m)
-        d_descs = torch.empty(n_fits * C.sizeof(FitDesc), dtype=torch.uint8, device=devc)
-        d_idx = torch.from_numpy(h_idx).to(devc)
-        d_init = torch.from_numpy(np.ascontiguousarray(init_mean, dtype=np.float64)).to(devc) \
-            if init_mean is not None else None
+        d_descs = be.empty(n_fits * C.sizeof(FitDesc))
+        d_idx = be.from_numpy(h_idx)
+        d_init = be.from_numpy(np.ascontiguousarray(init_mean, dtype=np.float64)) if init_mean is not None else None
         # ONE workspace for all pipeline slots while launches are serialised (round 4): launch i + 1 starts on the device
         # when launch i has ended, nothing on the host reads a workspace (results leave through `out` / `stat`), and every
         # kernel initialises what it reads -- slots were already reused by other fits every third launch.  A worker's
@@ -918,15 +968,16 @@ class Pipeline:
         ws = self._workspace(ws_slot, ws_bytes // 8)
         no = max(n_out, 1)
         # per-test-superpoint outputs in one device block: probs f32 | probs_new f32 | mu f32 | var f32 | labels u8
-        out = torch.empty(no * 17, dtype=torch.uint8, device=devc)
-        probs = out[0:4 * no].view(torch.float32)
-        probs_new = out[4 * no:8 * no].view(torch.float32)
-        mu = out[8 * no:12 * no].view(torch.float32)
-        var = out[12 * no:16 * no].view(torch.float32)
+        out = be.empty(no * 17)
+        probs = out[0:4 * no].view(be.f32)
+        probs_new = out[4 * no:8 * no].view(be.f32)
+        mu = out[8 * no:12 * no].view(be.f32)
+        var = out[12 * no:16 * no].view(be.f32)
         labels = out[16 * no:17 * no]
-        stat = torch.empty(n_fits * 12, dtype=torch.uint8, device=devc)  # loss f64[n] | status i32[n]
-        loss = stat[0:8 * n_fits].view(torch.float64)
-        status = stat[8 * n_fits:12 * n_fits].view(torch.int32)
+        stat = be.empty(n_fits * 20)  # loss f64[n] | cond f64[n] | status i32[n]
+        loss = stat[0:8 * n_fits].view(be.f64)
+        cond = stat[8 * n_fits:16 * n_fits].view(be.f64)
+        status = stat[16 * n_fits:20 * n_fits].view(be.i32)
         if self.profile_fit:
             tm = C.c_void_p()
             ctx.check(lib.gapro_fit_timing_create(ctx.handle, C.byref(tm)))
@@ -938,12 +989,13 @@ class Pipeline:
         # (bench.py --steps 20: cluster kernels of 1.2 .. 1.5 s beside the usual 0.23 s, launches 12 % longer).
         prev = self._last_fit_done if self.serialize_fits else None
         if prev is not None:
-            torch.cuda.current_stream(devc).wait_event(prev)
-        ctx.check(lib.gapro_svgp_fit_batch(
-            ctx.handle, _stream_handle(devc), n_fits, D, _ptr(feats_spp), _ptr(d_idx), C.cast(descs, C.c_void_p),
+            be.current_stream().wait_event(prev)
+        # (_ex: the per-fit conditioning figure travels with the status)
+        ctx.check(lib.gapro_svgp_fit_batch_ex(
+            ctx.handle, self._sh(), n_fits, D, _ptr(feats_spp), _ptr(d_idx), C.cast(descs, C.c_void_p),
             _ptr(d_descs), _ptr(d_init),
             C.byref(self.opt), _ptr(ws), ws_bytes, _ptr(probs), _ptr(probs_new), _ptr(labels), _ptr(mu), _ptr(var),
-            _ptr(status), _ptr(loss)))
+            _ptr(status), _ptr(loss), _ptr(cond)))
         if self.profile_fit:
             each = fit_flops_each(descs, n_fits, D, int(self.opt.training_iter))
             raw = _desc_table(descs, n_fits)
@@ -972,15 +1024,15 @@ class Pipeline:
                                              float(each[is_wave].sum())))
             self.last_fit_m = m
         # the next launch is ordered behind THIS launch's kernels only, not behind the copies below
-        kern_done = torch.cuda.Event()
-        kern_done.record(torch.cuda.current_stream(devc))
+        kern_done = be.event()
+        kern_done.record(be.current_stream())
         # results travel to pinned host memory on the same stream; nobody waits here
         h_out = self._pinned(slot + "fit_out", no * 17)
-        h_stat = self._pinned(slot + "fit_stat", n_fits * 12)
+        h_stat = self._pinned(slot + "fit_stat", n_fits * 20)
         h_out[:no * 17].copy_(out, non_blocking=True)
-        h_stat[:n_fits * 12].copy_(stat, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(devc))
+        h_stat[:n_fits * 20].copy_(stat, non_blocking=True)
+        done = be.event()
+        done.record(be.current_stream())
         # The next launch stays ordered behind the result COPIES of this one, as in round 3.  ADVICE r03 suggested the
         # kernels' end instead (so that the host blocks for less inside the next gapro_svgp_fit_batch); measured, same
         # box, alternating, 10 steps: 322.8 / 327.3 scenes/s with it against 331.3 / 336.7 without (-2.7 %): the next
@@ -999,14 +1051,15 @@ class Pipeline:
         no, n_fits = p["no"], p["n_fits"]
         raw = p["h_out"].numpy()
         st_raw = p["h_stat"].numpy()
-        st = st_raw[8 * n_fits:12 * n_fits].view(np.int32).copy()
+        st = st_raw[16 * n_fits:20 * n_fits].view(np.int32).copy()
         if raise_on_failure and (st != 0).any():
             bad = int(np.nonzero(st)[0][0])
             raise _lib.GaproError(int(st[bad]), "fit %d of %d failed" % (bad, n_fits))
         res = dict(probs=raw[0:4 * no].view(np.float32).copy(), probs_new=raw[4 * no:8 * no].view(np.float32).copy(),
                    mu=raw[8 * no:12 * no].view(np.float32).copy(), var=raw[12 * no:16 * no].view(np.float32).copy(),
                    labels=raw[16 * no:17 * no].copy(), loss=st_raw[0:8 * n_fits].view(np.float64).copy(), status=st,
-                   ws_bytes=p["ws_bytes"])
+                   # (max L_jj / min L_jj)^2 of every fit's last factorisation (a diagnostic: see reproducibility_probe)
+                   cond=st_raw[8 * n_fits:16 * n_fits].view(np.float64).copy(), ws_bytes=p["ws_bytes"])
         if p["ws"] is not None:
             res["workspace"] = p["ws"].clone()  # the slot's workspace is reused by the next launch
             res["descs"] = p["descs"]

@@ -376,6 +376,20 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t f
                          double* d_workspace,
                          size_t workspace_bytes, float* d_probs, float* d_probs_new, uint8_t* d_labels,
                          float* d_mu, float* d_var, int32_t* d_fit_status, double* d_fit_loss);
+/* The same launch with one more optional per-fit output (round 6): d_fit_cond[n_fits] (double, device; NULL = not wanted)
+ * receives a conditioning figure of each fit's LAST Cholesky factorisation, (max_j L_jj / min_j L_jj)^2 over the fit's M
+ * rows -- a lower bound of cond_2(K_ZZ + jitter I), read from the diagonal-block inverses the kernels keep anyway.  A
+ * diagnostic, NOT a predictor of which fits are numerically soft: on the S3DIS-shaped test scene the two fits whose
+ * sigma^2 no float64 implementation reproduces to 1e-4 rank 38th and 55th of 66 by this figure (and 35th / 61st by the
+ * true cond_2 at the initial hyper-parameters); what identifies them is a perturbation probe -- the fits once more with
+ * the initial mean moved by 1e-13 (Pipeline.reproducibility_probe).  Status, outputs and arithmetic
+ * are those of gapro_svgp_fit_batch. */
+int gapro_svgp_fit_batch_ex(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t feat_dim,
+                            const float* d_feats_spp, const int32_t* d_idx, const gapro_fit_desc* h_descs,
+                            gapro_fit_desc* d_descs, const double* d_init_mean, const gapro_fit_options* opt,
+                            double* d_workspace,
+                            size_t workspace_bytes, float* d_probs, float* d_probs_new, uint8_t* d_labels,
+                            float* d_mu, float* d_var, int32_t* d_fit_status, double* d_fit_loss, double* d_fit_cond);
 
 /* Which kernel gapro_svgp_fit_batch routes a fit of m = m1 + m2 inducing points to: 0 = strip-streaming
  * kernel (64 < M_p <= 128), 1 = LDS-staged kernel (128 < M_p < 512 while Z and X fit the LDS: M_p <= 192 at
@@ -547,6 +561,37 @@ int gapro_feed_export(gapro_feed* f, int32_t n, const gapro_feed_out* items, voi
  * when n_done > k, whatever later exports have finished already */
 int gapro_feed_export_wait(gapro_feed* f, int64_t until_done, int32_t timeout_ms, int64_t* n_done, int64_t* n_failed);
 int gapro_feed_export_error(gapro_feed* f, int32_t index, char* buf, int32_t cap);
+
+/* ------------------------------------------------------------------------------------------
+ * Device memory, streams, events owned by the library (round 6; csrc/devmem.hip).  SURVEY.md 8b: "library owns an
+ * opaque ctx: device, stream, workspace arena".  A caller without torch (the gen_ps workers: gapro_amd/devmem.py) gets
+ * everything the path needs from here; the torch-tensor API shims keep using torch's allocator and streams.
+ * The reference has no counterpart: its tensors come from torch (gen_ps.py:79-89).
+ * ---------------------------------------------------------------------------------------- */
+/* Caching arena with stream-ordered reuse: a block is allocated FOR a stream (hipStream_t; NULL = the default stream)
+ * and, once freed, is only handed out again for that stream, so gapro_dev_free never waits for the device.  A block
+ * used on a second stream must be ordered by events before it is freed. */
+int gapro_dev_alloc(gapro_ctx* ctx, size_t bytes, void* stream, void** out);
+int gapro_dev_free(gapro_ctx* ctx, void* p);
+int gapro_dev_trim(gapro_ctx* ctx);   /* give every cached block back to the driver (synchronises the device) */
+int gapro_dev_stats(gapro_ctx* ctx, int64_t* reserved_bytes, int64_t* in_use_bytes, int64_t* device_free_bytes,
+                    int64_t* device_total_bytes);   /* any pointer may be NULL */
+int gapro_host_alloc(gapro_ctx* ctx, size_t bytes, void** out);   /* page-locked host memory */
+int gapro_host_free(gapro_ctx* ctx, void* p);
+int gapro_stream_create(gapro_ctx* ctx, void** out);              /* non-blocking stream on the context's device */
+int gapro_stream_destroy(gapro_ctx* ctx, void* stream);
+int gapro_stream_sync(gapro_ctx* ctx, void* stream);
+int gapro_device_sync(gapro_ctx* ctx);
+int gapro_event_create(gapro_ctx* ctx, int32_t timing, void** out);
+int gapro_event_destroy(gapro_ctx* ctx, void* ev);
+int gapro_event_record(gapro_ctx* ctx, void* ev, void* stream);
+int gapro_stream_wait_event(gapro_ctx* ctx, void* stream, void* ev);
+int gapro_event_sync(gapro_ctx* ctx, void* ev);
+int gapro_event_query(gapro_ctx* ctx, void* ev);                  /* 1 complete, 0 not yet, < 0 gapro_status */
+int gapro_event_elapsed_ms(gapro_ctx* ctx, void* ev_start, void* ev_end, float* out_ms);
+/* kind: 0 host -> device, 1 device -> host, 2 device -> device */
+int gapro_memcpy_async(gapro_ctx* ctx, void* dst, const void* src, size_t bytes, int32_t kind, void* stream);
+int gapro_memset_async(gapro_ctx* ctx, void* dst, int32_t value, size_t bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Inspection (tests): where a fit's trained parameters live in its workspace.  The measurement / self-test entry points

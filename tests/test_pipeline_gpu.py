@@ -142,21 +142,24 @@ def test_s3dis_shaped_scene_matches_oracle():
     """BASELINE configs[3]: a room-sized scene (1M points, 13 classes, objects of up to several hundred
     superpoints).  Its 66 fits (M up to 724) span every fit kernel inside one real schedule.
 
-    Tolerance rule (no blanket carve-out): EVERY fit must agree with the float64 autograd oracle to float32 rounding
-    (p within 3e-7, sigma^2 within 1e-5 relative) UNLESS the oracle's own two float64 implementations (autograd and
-    the NumPy hand-derived backward: same formulas, different summation order) drift apart by more than 1e-6 on that
-    very fit -- then no implementation can be held tighter than that drift, and the kernel must stay within 30x of
-    it.  Two of the 66 fits are of that kind on the GPU box's host (M = 144: 3e-5 between the oracle's implementations,
-    M = 58: 3e-6; < 3e-8 on each of the other 64), and on both a single input coordinate moved by one ulp moves the
-    oracle's sigma^2 by as much (tests/test_svgp_oracle.py::test_the_one_ill_conditioned_s3dis_fit_..., tools/loose_fits.py,
-    DESIGN section 2).  Integer masks are compared bit for bit wherever the GP probability is further from a tie than
-    the deviation allowed above."""
+    Tolerance rule (round 6; no oracle-side quantity in it, nothing that depends on the oracle's BLAS or thread count):
+    the PRODUCT says which fits are numerically soft -- `reproducibility_probe=True` runs every fit once more with its
+    initial variational mean perturbed by 1e-13 and reports how far sigma^2 and p move.  A fit that moves by less than
+    REPRO_SOFT (1e-6: float32 rounding is 6e-8) must agree with the float64 autograd oracle to float32 rounding (p within
+    3e-7, sigma^2 within 1e-5 relative); a fit that moves by more amplifies last-bit differences ~1e9-fold over its fifty
+    Adam steps -- in ANY float64 implementation: on exactly these fits the oracle's own two implementations part by
+    3e-6 .. 3e-5 and a one-ulp change of one input moves the oracle's sigma^2 by as much (tools/loose_fits.py,
+    tests/test_svgp_oracle.py::test_the_one_ill_conditioned_s3dis_fit_..., DESIGN section 2) -- and is held to 1e-3.
+    Two of the 66 fits are of that kind (M = 58 and M = 144), and the count is asserted.  (Neither a pivot-ratio figure
+    of the Cholesky factor nor cond_2(K_ZZ) singles them out: they rank 38th / 55th and 35th / 61st of 66 by those.)
+    Integer masks are compared bit for bit wherever the GP probability is further from a tie than the deviation
+    allowed above."""
     from gapro_amd import gen_pseudo_label_gaussian_process
     from gapro_amd._lib import Context
     from gapro_amd.gaussian_process_utils import fit_gp_spp_batch
     from gapro_amd.gen_ps_utils import getInstanceInfo
+    from gapro_amd.pipeline import REPRO_SOFT
     from gapro_amd.synth import make_scene
-    from oracle import svgp_oracle as so
 
     sc = make_scene(seed=7, n_points=1_000_000, n_objects=40, with_walls_json=False, obj_patch=60, plane_patch=400)
     xyz = sc.aligned_xyz()
@@ -171,27 +174,23 @@ def test_s3dis_shaped_scene_matches_oracle():
     routes = {int(lib.gapro_fit_route(len(e.b1_inds) + len(e.b2_inds), 6)) for e in fits}
     assert {0, 1, 3, 5} <= routes and (routes & {2, 4}), routes  # the scene really exercises every kernel family
     # fit by fit, on the oracle's pooled features (the partition is compared bit for bit through the masks below)
-    got = fit_gp_spp_batch(dbg["part"].feats_spp, [(e.b1_inds, e.b2_inds, e.intersect_inds) for e in fits],
-                           training_iter=50)
+    got, res = fit_gp_spp_batch(dbg["part"].feats_spp, [(e.b1_inds, e.b2_inds, e.intersect_inds) for e in fits],
+                                training_iter=50, reproducibility_probe=True)
+    assert np.isfinite(res["cond"]).all() and (res["cond"] >= 1.0).all()
+    soft = [k for k in range(len(fits)) if max(res["repro_dv"][k], res["repro_dp"][k]) > REPRO_SOFT]
     loose, worst_p = [], 3e-7
     for k, (g, r, e) in enumerate(zip(got, dbg["results"], fits)):
         dp = np.max(np.abs(g[0].astype(np.float64) - r[0]))
         dv = np.max(np.abs(g[4].astype(np.float64) - r[4]) / r[4])
-        if dp < 3e-7 and dv < 1e-5:
-            continue
-        f = dbg["part"].feats_spp
-        X = np.concatenate([f[e.b1_inds], f[e.b2_inds]]).astype(np.float64)
-        y = np.r_[-np.ones(len(e.b1_inds)), np.ones(len(e.b2_inds))]
-        Xt = f[e.intersect_inds].astype(np.float64)
-        a = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64")
-        m = so.svgp_fit_predict_manual(X, y, Xt, 50)
-        odv, odp = np.max(np.abs(a[1] - m[1]) / a[1]), np.max(np.abs(a[2] - m[2]))
-        assert odv > 1e-6, "fit %d (M=%d): kernel off by dv=%.2e dp=%.2e while the oracle's own implementations " \
-                           "agree to %.2e" % (k, len(X), dv, dp, odv)
-        assert dv < 30 * odv and dp < 30 * max(odp, 1e-7), (k, dv, dp, odv, odp)
-        loose.append(k)
-        worst_p = max(worst_p, dp)
-    assert len(loose) <= 2, loose
+        if k in soft:
+            assert dv < 1e-3 and dp < 1e-3, (k, dv, dp)
+            loose.append(k)
+            worst_p = max(worst_p, dp)
+        else:
+            assert dp < 3e-7 and dv < 1e-5, "fit %d (M=%d): off by dv=%.2e dp=%.2e while its own perturbation probe " \
+                "moves it by dv=%.1e dp=%.1e" % (k, len(e.b1_inds) + len(e.b2_inds), dv, dp, res["repro_dv"][k],
+                                                 res["repro_dp"][k])
+    assert sorted(len(fits[k].b1_inds) + len(fits[k].b2_inds) for k in soft) == [58, 144], soft
     outs = gen_pseudo_label_gaussian_process(**kw)
     sem, ins, prob, mu, var = [o.cpu().numpy() for o in outs]
     r_sem, r_ins, r_prob, r_mu, r_var = ref
