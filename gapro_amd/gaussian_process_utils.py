@@ -27,8 +27,8 @@ def fit_gp_spp_batch(feats_spp, problems, training_iter=50, init_mean=None, devi
     value: a failed fit does not affect the other fits of the launch.
     The raw result dict carries ``cond``, a per-fit conditioning figure of the last Cholesky factor (a diagnostic), and
     with ``reproducibility_probe=True`` (implies keep_debug; twice the work) ``repro_dv`` / ``repro_dp``: how far each
-    fit's sigma^2 (relative) and p (absolute) move when the initial variational mean is perturbed by 1e-13 -- beyond
-    pipeline.REPRO_SOFT (1e-6) a fit's variances are reproducible by no float64 implementation to 1e-4.
+    fit's sigma^2 (relative) and p (absolute) move when the jitter on K_ZZ is scaled by (1 + 1e-11) -- beyond
+    pipeline.REPRO_SOFT (1e-5) a fit's variances are reproducible by no float64 implementation to 1e-4.
     """
     dev = _pick_device(feats_spp, device)
     pipe = _pipeline(dev, training_iter, **pipe_kw)

@@ -382,7 +382,7 @@ int gapro_svgp_fit_batch(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t f
  * diagnostic, NOT a predictor of which fits are numerically soft: on the S3DIS-shaped test scene the two fits whose
  * sigma^2 no float64 implementation reproduces to 1e-4 rank 38th and 55th of 66 by this figure (and 35th / 61st by the
  * true cond_2 at the initial hyper-parameters); what identifies them is a perturbation probe -- the fits once more with
- * the initial mean moved by 1e-13 (Pipeline.reproducibility_probe).  Status, outputs and arithmetic
+ * the jitter on K_ZZ's diagonal scaled by (1 + 1e-11) (Pipeline.reproducibility_probe).  Status, outputs and arithmetic
  * are those of gapro_svgp_fit_batch. */
 int gapro_svgp_fit_batch_ex(gapro_ctx* ctx, void* stream, int32_t n_fits, int32_t feat_dim,
                             const float* d_feats_spp, const int32_t* d_idx, const gapro_fit_desc* h_descs,

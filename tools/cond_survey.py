@@ -39,7 +39,7 @@ def main():
         dv = np.max(np.abs(g[4].astype(np.float64) - r[4]) / r[4])
         rows.append((float(res["cond"][k]), k, len(e.b1_inds) + len(e.b2_inds), dv, dp, res["repro_dv"][k], res["repro_dp"][k]))
     for c, k, m, dv, dp, rv, rp in sorted(rows, reverse=True):
-        print("fit %2d  M = %4d  cond %.3e  vs oracle dv %.2e dp %.2e  | own probe (init mean + 1e-13 randn) dv %.2e dp %.2e"
+        print("fit %2d  M = %4d  cond %.3e  vs oracle dv %.2e dp %.2e  | own probe (jitter x (1 + 1e-11)) dv %.2e dp %.2e"
               % (k, m, c, dv, dp, rv, rp))
 
 
