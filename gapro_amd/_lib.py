@@ -179,6 +179,7 @@ SIGNATURES = {
     "gapro_feed_export": (C.c_int, [_P, C.c_int32, _P, _P]),
     "gapro_feed_export_wait": (C.c_int, [_P, C.c_int64, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gapro_feed_export_error": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
+    "gapro_feed_stats": (C.c_int, [_P, _P]),
     "gapro_scene_default_feats": (C.c_int, [_P, _P, C.c_int64, _P]),
     "gapro_scene_instance_boxes": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P,
                                              C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

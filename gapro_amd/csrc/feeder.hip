@@ -90,6 +90,10 @@ struct gapro_feed {
   int exp_active = 0;          // writers between taking an export and finishing it
   int budget_waiters = 0;      // loaders whose turn it is and whom only the byte budget holds back
   bool failed = false;         // an upload failed half way: the feed's order is gone, every later call reports it
+  // where the loaders' time goes (gapro_feed_stats; GAPRO_DRIVER_TIMES=1 prints it)
+  std::atomic<int64_t> st_pin_us{0}, st_pin_n{0}, st_pin_bytes{0}, st_load_us{0}, st_load_n{0}, st_wait_us{0}, st_write_us{0}, st_write_n{0};
+  std::chrono::steady_clock::time_point t_create = std::chrono::steady_clock::now();
+  std::atomic<int64_t> st_first_loaded_us{-1};
   std::vector<std::string> exp_errors;
   bool stop = false, closed = false;
   // pinned block pool
@@ -174,11 +178,15 @@ Block take_block(gapro_feed* f, int64_t need, std::unique_lock<std::mutex>& lk, 
   f->pool_bytes += sz;
   lk.unlock();  // the allocation itself (page pinning) runs outside the lock, in parallel on the loader threads
   void* p = nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
   if (use_gpu(f)) {
     if (hipHostMalloc(&p, (size_t)sz, hipHostMallocDefault) != hipSuccess) p = nullptr;
   } else {
     if (posix_memalign(&p, 4096, (size_t)sz) != 0) p = nullptr;
   }
+  f->st_pin_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp0).count();
+  f->st_pin_n += 1;
+  f->st_pin_bytes += sz;
   lk.lock();
   if (!p) {
     f->pool_bytes -= sz;
@@ -431,7 +439,10 @@ void worker(gapro_feed* f) {
       ++f->exp_active;
       lk.unlock();
       std::string err;
+      const auto tw0 = std::chrono::steady_clock::now();
       write_labels(f, w, st, &err);
+      f->st_write_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tw0).count();
+      f->st_write_n += 1;
       lk.lock();
       --f->exp_active;
       ++f->exp_done;
@@ -452,7 +463,12 @@ void worker(gapro_feed* f) {
     Item& it = *f->items[i - f->base];
     it.state = 1;
     lk.unlock();
+    const auto tl0 = std::chrono::steady_clock::now();
     load_scene(f, i, it, tmp, rgb);
+    const auto tl1 = std::chrono::steady_clock::now();
+    f->st_load_us += std::chrono::duration_cast<std::chrono::microseconds>(tl1 - tl0).count();
+    f->st_load_n += 1;
+    if (i == 0) f->st_first_loaded_us = std::chrono::duration_cast<std::chrono::microseconds>(tl1 - f->t_create).count();
     lk.lock();
     if (it.rec.status != GAPRO_OK && it.blk.p) {  // a failed scene holds no staging memory
       give_block(f, it.blk, it.image_bytes);
@@ -597,8 +613,10 @@ int gapro_feed_poll(gapro_feed* f, int32_t min_ready, int32_t max_scenes, int32_
     // The byte budget is smaller than what `want` scenes need (deep features, --batch_scenes 512, S3DIS
     // rooms): the loader whose turn it is waits for room that only THIS caller can make, by taking what is loaded.
     // Nothing else will return memory: no upload is in flight (its blocks come back when its copy is done) and no label
-    // file is being written (its block comes back when it is on disk).
-    return have >= 1 && f->budget_waiters > 0 && f->batches.empty() && f->exp_active == 0 && f->exports.empty();
+    // file is being written (its block comes back when it is on disk).  Label files that are QUEUED do not count: with
+    // every thread parked as a loader behind the budget nobody is left to write them, and waiting for them here was a
+    // second, rarer form of the same deadlock (one run in six of the budget test under CPU load).
+    return have >= 1 && f->budget_waiters > 0 && f->batches.empty() && f->exp_active == 0;
   };
   // (a timed wait: uploads whose copies complete raise no condition variable, and their blocks are what the loaders wait for)
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms);
@@ -778,6 +796,19 @@ int gapro_feed_export_wait(gapro_feed* f, int64_t until_done, int32_t timeout_ms
   }
   if (n_done) *n_done = f->exp_prefix;
   if (n_failed) *n_failed = f->exp_failed;
+  return GAPRO_OK;
+}
+
+int gapro_feed_stats(gapro_feed* f, double* out8) {
+  if (!f || !out8) return GAPRO_ERR_BAD_ARG;
+  out8[0] = 1e-6 * (double)f->st_pin_us;      // seconds inside hipHostMalloc / posix_memalign, summed over threads
+  out8[1] = (double)f->st_pin_n;              // blocks allocated
+  out8[2] = (double)f->st_pin_bytes;          // bytes allocated
+  out8[3] = 1e-6 * (double)f->st_load_us;     // seconds inside load_scene (incl. the waits for a block), summed
+  out8[4] = (double)f->st_load_n;
+  out8[5] = 1e-6 * (double)f->st_write_us;    // seconds inside write_labels, summed
+  out8[6] = (double)f->st_write_n;
+  out8[7] = 1e-6 * (double)f->st_first_loaded_us;  // first scene loaded, seconds after gapro_feed_create (< 0: none yet)
   return GAPRO_OK;
 }
 

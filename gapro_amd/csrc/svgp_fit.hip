@@ -1907,7 +1907,13 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     __syncthreads();
   };
 
+#ifdef GAPRO_STEP_FN
+  // A/B build (round 6, profiles/r06_spill_traffic.md): one Adam step as ONE out-of-line function with the products
+  // inlined into it -- the callee-saved registers are saved once per step instead of once per product call
+  auto step_fn = [&](int step) __attribute__((noinline)) {
+#else
   for (int step = 1; step <= opt.training_iter; ++step) {
+#endif
     refresh_hypers();
     const double s = sh.s, ell = sh.ell, inv_l2 = sh.inv_l2, c = sh.c;
     const bool last = step == opt.training_iter;
@@ -2155,7 +2161,13 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
     }
     __syncthreads();
     stamp(16);
+  #ifdef GAPRO_STEP_FN
+  };
+#pragma nounroll
+  for (int step = 1; step <= opt.training_iter; ++step) step_fn(step);
+#else
   }
+#endif
 
   // ------------------------------- prediction ------------------------------
   refresh_hypers();

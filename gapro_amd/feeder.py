@@ -139,6 +139,12 @@ class NativeFeeder:
                 out.append(buf.value.decode(errors="replace"))
         return out
 
+    def stats(self):
+        out = (C.c_double * 8)()
+        self._check(self.lib.gapro_feed_stats(self.handle, out))
+        return dict(pin_s=out[0], pin_blocks=int(out[1]), pin_GB=out[2] / 1e9, load_s=out[3], loads=int(out[4]),
+                    write_s=out[5], writes=int(out[6]), first_loaded_s=out[7])
+
     def destroy(self, process_is_exiting: bool = False):
         if self.handle:
             if process_is_exiting:

@@ -635,6 +635,11 @@ class Worker:
             if th is not None:
                 th.join()
             t_fin = time.time()
+            if os.environ.get("GAPRO_DRIVER_TIMES"):
+                try:
+                    print("[gen_ps] feeder threads: %r" % (self.feeder.stats(),))
+                except Exception:  # noqa: BLE001
+                    pass
             self.feeder.destroy(process_is_exiting=_EXIT_AFTER_MAIN[0])
             self.keep = []
             if getattr(self, "_torch_threads", None):

@@ -561,6 +561,9 @@ int gapro_feed_export(gapro_feed* f, int32_t n, const gapro_feed_out* items, voi
  * when n_done > k, whatever later exports have finished already */
 int gapro_feed_export_wait(gapro_feed* f, int64_t until_done, int32_t timeout_ms, int64_t* n_done, int64_t* n_failed);
 int gapro_feed_export_error(gapro_feed* f, int32_t index, char* buf, int32_t cap);
+/* where the feeder threads' time went, summed over threads: out8 = {s inside the staging allocations, blocks, bytes,
+ * s inside scene loads, scenes, s inside label writes, files, s from create to the first loaded scene} */
+int gapro_feed_stats(gapro_feed* f, double* out8);
 
 /* ------------------------------------------------------------------------------------------
  * Device memory, streams, events owned by the library (round 6; csrc/devmem.hip).  SURVEY.md 8b: "library owns an
