@@ -24,6 +24,8 @@
 // The arithmetic is the reference's, bit for bit: features are float32(xyz | rgb) of the UN-aligned points; the
 // alignment is np.dot([x y z 1], A^T) = fma-accumulated in k order (OpenBLAS dgemm's order: tests/test_feeder.py holds
 // it to np.dot bitwise); the boxes are getInstanceInfo's min / max per instance id.
+#include <sys/mman.h>
+
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -48,6 +50,7 @@ inline int64_t up(int64_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
 struct Block {
   void* p = nullptr;
   int64_t bytes = 0;
+  bool pinned = false;  // page-locked (hipHostRegister) yet?  See pin_block.
 };
 
 struct Item {  // one submitted scene
@@ -120,6 +123,12 @@ bool use_gpu(const gapro_feed* f) { return f->device >= 0; }
 // scene has taken (or given up) its block
 void reap_batches(gapro_feed* f, bool wait_all);
 
+void release_block(const Block& b) {
+  if (!b.p) return;
+  if (b.pinned) (void)hipHostUnregister(b.p);
+  free(b.p);
+}
+
 Block take_block(gapro_feed* f, int64_t need, std::unique_lock<std::mutex>& lk, long long turn = -1) {
   // wait for room in the in-flight budget (one scene is always admitted), then first fit from the pool.  The pinned
   // blocks of uploaded batches come back through reap_batches, which round 5 ran on the consumer's thread only: a
@@ -170,21 +179,20 @@ Block take_block(gapro_feed* f, int64_t need, std::unique_lock<std::mutex>& lk, 
     f->free_blocks.erase(f->free_blocks.begin() + sm);
     f->pool_bytes -= d.bytes;
     lk.unlock();
-    if (use_gpu(f)) (void)hipHostFree(d.p);
-    else free(d.p);
+    release_block(d);
     lk.lock();
   }
   const int64_t sz = (std::max<int64_t>(need, 4 << 20) + (2 << 20) - 1) / (2 << 20) * (2 << 20);
   f->pool_bytes += sz;
   lk.unlock();  // the allocation itself (page pinning) runs outside the lock, in parallel on the loader threads
+  // Plain memory now, page-locked later by whoever has filled it (pin_block).  Round 5 took staging blocks from
+  // hipHostMalloc, which allocates, clears and pins at 6 .. 7 GB/s whatever the block size or the number of calling
+  // threads (tools/probes/pin_rate.hip): the loaders of a fresh worker spent 58 % of their first second inside it -- 14 s
+  // of thread time for 5.6 GB -- and that, not the disk, set the pace at which the first batches arrived.  Registering
+  // memory that is already touched runs at ~100 GB/s, and the touching is the decoder's own writes, on 15 threads at once.
   void* p = nullptr;
-  const auto tp0 = std::chrono::steady_clock::now();
-  if (use_gpu(f)) {
-    if (hipHostMalloc(&p, (size_t)sz, hipHostMallocDefault) != hipSuccess) p = nullptr;
-  } else {
-    if (posix_memalign(&p, 4096, (size_t)sz) != 0) p = nullptr;
-  }
-  f->st_pin_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp0).count();
+  if (posix_memalign(&p, 2 << 20, (size_t)sz) != 0) p = nullptr;
+  else (void)madvise(p, (size_t)sz, MADV_HUGEPAGE);
   f->st_pin_n += 1;
   f->st_pin_bytes += sz;
   lk.lock();
@@ -196,6 +204,18 @@ Block take_block(gapro_feed* f, int64_t need, std::unique_lock<std::mutex>& lk, 
   b.p = p;
   b.bytes = sz;
   return b;
+}
+
+// page-lock a block once its pages exist (the caller has just filled it; what is left untouched -- the rounding tail, a
+// fresh label block -- is faulted in by the registration itself)
+bool pin_block(gapro_feed* f, Block& b) {
+  if (!use_gpu(f) || b.pinned || !b.p) return true;
+  const auto tp0 = std::chrono::steady_clock::now();
+  const bool ok = hipHostRegister(b.p, (size_t)b.bytes, hipHostRegisterDefault) == hipSuccess;
+  if (!ok) (void)hipGetLastError();  // the copies still work from pageable memory, only slower
+  b.pinned = ok;
+  f->st_pin_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tp0).count();
+  return ok;
 }
 
 void give_block(gapro_feed* f, Block b, int64_t need) {  // lock held
@@ -365,6 +385,7 @@ void load_scene(gapro_feed* f, size_t index, Item& it, std::vector<char>& tmp, s
   r.inst_box = it.box.data();
   r.inst_cls = it.cls.data();
   r.inst_vol = it.vol.data();
+  (void)pin_block(f, it.blk);  // (a recycled block is pinned already; a fresh one: every page of the image is touched)
   done(GAPRO_OK);
 }
 
@@ -384,6 +405,7 @@ void write_labels(gapro_feed* f, OutItem& w, hipStream_t st, std::string* err) {
   }
   char* h = (char*)b.p;
   bool ok = true;
+  (void)pin_block(f, b);
   if (use_gpu(f)) {
     if (w.ready) ok = hipStreamWaitEvent(st, w.ready, 0) == hipSuccess;
     ok = ok && hipMemcpyAsync(h, o.d_sem, 4 * n, hipMemcpyDeviceToHost, st) == hipSuccess &&
@@ -430,10 +452,28 @@ void worker(gapro_feed* f) {
   std::vector<double> rgb;
   std::unique_lock<std::mutex> lk(f->mu);
   for (;;) {
-    // label files first: they free device memory and are what the run is measured by
-    f->cv_work.wait(lk, [&] { return f->stop || !f->exports.empty() || f->next_load < f->base + f->items.size(); });
+    // Label files first: they free device memory and are what the run is measured by -- but only files whose arrays
+    // are READY.  Round 5 took an export as soon as it was queued and then sat in hipStreamSynchronize behind the
+    // caller's event, i.e. behind the broadcast kernels of a batch that wait for the running fit launch to drain: with a
+    // batch of 256 files queued, all 15 threads parked there for 0.3 .. 0.6 s per batch (16 ms per file of thread time for
+    // 1.4 ms of work: gapro_feed_stats) and nothing was READ meanwhile -- which is why the reads ran at 250 scenes/s beside
+    // a running generator and at 850 without one.  Now a thread looks at the front export's event and, while it has not
+    // completed, loads scenes instead (or naps 1 ms when there is nothing to load).
+    bool export_ready = false;
+    for (;;) {
+      if (f->stop) break;
+      export_ready = false;
+      if (!f->exports.empty()) {
+        const hipEvent_t ev = f->exports.front().ready;
+        export_ready = !use_gpu(f) || !ev || hipEventQuery(ev) != hipErrorNotReady;
+      }
+      const bool can_load = f->next_load < f->base + f->items.size();
+      if (export_ready || can_load) break;
+      if (!f->exports.empty()) f->cv_work.wait_for(lk, std::chrono::milliseconds(1));  // an event completes silently
+      else f->cv_work.wait(lk);
+    }
     if (f->stop) break;
-    if (!f->exports.empty()) {
+    if (export_ready) {
       OutItem w = std::move(f->exports.front());
       f->exports.pop_front();
       ++f->exp_active;
@@ -548,10 +588,7 @@ void gapro_feed_destroy(gapro_feed* f) {
     if (use_gpu(f)) reap_batches(f, true);
     for (auto& it : f->items)
       if (it->blk.p) f->free_blocks.push_back(it->blk);
-    for (Block& b : f->free_blocks) {
-      if (use_gpu(f)) (void)hipHostFree(b.p);
-      else free(b.p);
-    }
+    for (Block& b : f->free_blocks) release_block(b);
   }
   if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
   delete f;
@@ -801,7 +838,7 @@ int gapro_feed_export_wait(gapro_feed* f, int64_t until_done, int32_t timeout_ms
 
 int gapro_feed_stats(gapro_feed* f, double* out8) {
   if (!f || !out8) return GAPRO_ERR_BAD_ARG;
-  out8[0] = 1e-6 * (double)f->st_pin_us;      // seconds inside hipHostMalloc / posix_memalign, summed over threads
+  out8[0] = 1e-6 * (double)f->st_pin_us;      // seconds inside hipHostRegister, summed over threads
   out8[1] = (double)f->st_pin_n;              // blocks allocated
   out8[2] = (double)f->st_pin_bytes;          // bytes allocated
   out8[3] = 1e-6 * (double)f->st_load_us;     // seconds inside load_scene (incl. the waits for a block), summed

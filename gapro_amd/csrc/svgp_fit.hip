@@ -329,16 +329,22 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) d2 lds_d2;
 typedef __attribute__((address_space(1))) d2 g_d2;
 
-#ifdef GAPRO_GEMM_INLINE  // A/B build (round 6, profiles/r06_spill_traffic.md): no call, no callee-saved register traffic
-#define GAPRO_GEMM_ATTR __forceinline__
-#else
-#define GAPRO_GEMM_ATTR __noinline__
+// Round 6 (profiles/r06_spill_traffic.md): every out-of-line product saved and restored the 41 callee-saved VGPRs it
+// uses -- ~410 scratch stores and as many loads per wave and Adam step, 8 .. 15 % of the HBM-side traffic of the
+// two-per-CU staged fits, which sit on the memory roof.  Inlining the products into the KERNEL was 3 % slower (the
+// register allocator then carries the kernel's long-lived values through every k loop); inlining them into ONE
+// out-of-line function per Adam step (step_fn in fit_body, through gemm_tn_in) pays the callee-saved traffic once per
+// step: M = 160 -3.3 %, 200 -1.7 %, 256 +0.7 %, 320 / 384 +-0 in time, bit-identical.  The strip kernels' tail products keep
+// the out-of-line form (their caller holds 80 accumulator registers across them).  -DGAPRO_NO_STEP_FN restores the
+// per-product calls everywhere.
+#ifndef GAPRO_NO_STEP_FN
+#define GAPRO_STEP_FN
 #endif
 template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, bool TRIM = false, int PK = 0, int QK = 0,
           typename KRange, typename Epi>
-__device__ GAPRO_GEMM_ATTR void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
-                                     const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
-                                     Epi epi) {
+__device__ __forceinline__ void gemm_tn_body(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
+                                          const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+                                          Epi epi) {
   mo_tiles = uni(mo_tiles);
   no_tiles = uni(no_tiles);
   lower_only = uni((int)lower_only) != 0;
@@ -498,6 +504,27 @@ __device__ GAPRO_GEMM_ATTR void gemm_tn(int mo_tiles, int no_tiles, bool lower_o
     }
     tile(std::integral_constant<int, TU>{}, 16 * TU * ti, 16 * TU * tj);
   }
+}
+
+// the product as a function of its own (the strip kernels' tail products, the debug engines) ...
+template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, bool TRIM = false, int PK = 0, int QK = 0,
+          typename KRange, typename Epi>
+__device__ __noinline__ void gemm_tn(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
+                                     const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+                                     Epi epi) {
+  gemm_tn_body<TU, SCALE, KS, ORD, TRIM, PK, QK>(mo_tiles, no_tiles, lower_only, P, Q, ld, qscale, kr, epi);
+}
+// ... and inlined into its caller (the staged kernel's step function)
+template <int TU, bool SCALE, int KS = 2, int ORD = ORD_ROWMAJOR, bool TRIM = false, int PK = 0, int QK = 0,
+          typename KRange, typename Epi>
+__device__ __forceinline__ void gemm_tn_in(int mo_tiles, int no_tiles, bool lower_only, const gd* __restrict__ P,
+                                        const gd* __restrict__ Q, int ld, const gd* __restrict__ qscale, KRange kr,
+                                        Epi epi) {
+#ifdef GAPRO_STEP_FN
+  gemm_tn_body<TU, SCALE, KS, ORD, TRIM, PK, QK>(mo_tiles, no_tiles, lower_only, P, Q, ld, qscale, kr, epi);
+#else
+  gemm_tn<TU, SCALE, KS, ORD, TRIM, PK, QK>(mo_tiles, no_tiles, lower_only, P, Q, ld, qscale, kr, epi);
+#endif
 }
 
 // ---- TN-form MFMA product, workgroup-tiled through an LDS ring (round 3) ---------------------------------
@@ -1650,7 +1677,7 @@ template <int WG, int TU, bool SCALE, int ORD, int PK = 0, int QK = 0, typename 
 __device__ inline void product(int mo, int no, bool lower, const gd* __restrict__ P, const gd* __restrict__ Q, int ld,
                                const gd* __restrict__ qs, KRange kr, Epi epi, ldsd* ring) {
   if constexpr (WG == 0) {
-    gemm_tn<TU, SCALE, 2, ORD, true, PK, QK>(mo, no, lower, P, Q, ld, qs, kr, epi);
+    gemm_tn_in<TU, SCALE, 2, ORD, true, PK, QK>(mo, no, lower, P, Q, ld, qs, kr, epi);
   } else {
     // Workgroup-tiled products take the part of the output that whole 128 x 128 tiles cover; what is left at the
     // matrix edge (an L of up to 96 rows / columns, M_p a multiple of 32) goes to the per-wave products as 32 x 32
@@ -1668,7 +1695,7 @@ __device__ inline void product(int mo, int no, bool lower, const gd* __restrict_
       constexpr int TUS = decltype(tu_tag)::value;  // 2: 32 x 32 wave tiles, 4: 64 x 64 (extents in half tiles)
       if (nr <= 0 || nc <= 0) return;
       // (row-major tile order: the shell order of some products enumerates SQUARE tile grids only)
-      gemm_tn<TUS, SCALE, 2, ORD_ROWMAJOR, true, PK, QK>(
+      gemm_tn_in<TUS, SCALE, 2, ORD_ROWMAJOR, true, PK, QK>(
           nr / (8 * TUS), nc / (8 * TUS), low, PK ? P + (size_t)r0 * ld : P + r0, QK ? Q + (size_t)c0 * ld : Q + c0, ld, qs,
           [=](int i0, int j0, int* lo, int* hi) {
             int l0, h0, l1, h1;  // a wave tile's range: the hull of its 16 x 16 blocks' (kr is monotone; gemm_tn trims hi)
@@ -1908,8 +1935,8 @@ __device__ void fit_body(const gapro_fit_options& opt, ldsd* Zt, ldsd* Pt, ldsd*
   };
 
 #ifdef GAPRO_STEP_FN
-  // A/B build (round 6, profiles/r06_spill_traffic.md): one Adam step as ONE out-of-line function with the products
-  // inlined into it -- the callee-saved registers are saved once per step instead of once per product call
+  // one Adam step as ONE out-of-line function with the products inlined into it: the callee-saved registers are saved
+  // once per step instead of once per product call (see gemm_tn_in)
   auto step_fn = [&](int step) __attribute__((noinline)) {
 #else
   for (int step = 1; step <= opt.training_iter; ++step) {
