@@ -294,6 +294,8 @@ class Worker:
         self.queue = ClaimQueue(filenames, args.claim_dir) if getattr(args, "claim_dir", None) else None
         self.chunks = _chunks(filenames, args, self.queue)
         self.chunks_done = False
+        # scenes this worker will process, when that is known up front (no claim queue): see _take
+        self.n_static = len(pending_scenes(filenames, args.save_folder)) if self.queue is None else None
         # Round 6: a worker runs on the library's own arena, streams and events (devmem.NativeBackend) and never imports
         # torch -- 0.75 s of `import torch` + its HIP start-up stood in front of every worker's first read, for a job
         # whose share of an eight-GPU node is 0.64 s of GPU work.  torch is still what the options
@@ -391,13 +393,21 @@ class Worker:
         if left <= 0:
             return None
         want = min(a.batch_scenes, left)
+        cap = a.batch_scenes
+        if self.n_static is not None and not first:
+            # a static list (one worker, or a static shard): what is left is known, so it goes out in EQUAL batches -- the
+            # first batch is whatever was loaded after 0.2 s, and fixed 256s behind it end in a launch of a dozen scenes
+            # that lasts as long as its largest fit (0.3 s of a 4 s job)
+            rem = max(self.n_static - self.feeder.taken, 1)
+            nb = -(-rem // a.batch_scenes)
+            want = cap = max(1, min(-(-rem // nb), left))
         if first:
             wait_ms = int(1000 * max(0.0, self.first_window - (time.time() - self.t0)))
             n, nbytes = self.feeder.poll(want, a.batch_scenes, wait_ms)
             if n < min(self.first_min, want):
                 n, nbytes = self.feeder.poll(min(self.first_min, want), a.batch_scenes, -1)
         else:
-            n, nbytes = self.feeder.poll(want, a.batch_scenes, -1)
+            n, nbytes = self.feeder.poll(want, cap, -1)
         if n <= 0:
             return None
         if self.dry:
