@@ -67,11 +67,13 @@ struct WaveLds {
   static constexpr int oTmp = oGv + Mp;         // [Mp]
   static constexpr int oGh = oTmp + Mp;         // Gauss-Hermite nodes [10] and weights [10]
   static constexpr int oSc = oGh + 20;          // c, rho_s, rho_l [3] (their Adam moments: registers of lanes 61..63)
+  static constexpr int oRs = oSc + 10;          // wide features: row sums of the kernel-gradient weights [Mp] ...
+  static constexpr int oCen = oRs + Mp;         // ... and the centre the points are taken relative to [DC]
 #ifdef GAPRO_PROFILE
-  static constexpr int oProf = oSc + 10;        // phase clocks of the diagnostic build [16] + the last stamp
+  static constexpr int oProf = oCen + DC;       // phase clocks of the diagnostic build [16] + the last stamp
   static constexpr int total = (oProf + 18) / 2 * 2;
 #else
-  static constexpr int total = (oSc + 9 + 1) / 2 * 2;
+  static constexpr int total = (oCen + DC + 1) / 2 * 2;
 #endif
 };
 
@@ -316,6 +318,16 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
   ldsd* vtmp = L + W::oTmp;
   ldsd* gh = L + W::oGh;
   ldsd* sc = L + W::oSc;
+  ldsd* vrs = L + W::oRs;
+  ldsd* cen = L + W::oCen;
+  // Wide features (D = 32): G_Z as the product  rowsum_k (Z_k - c) - W (P - c)  on the matrix cores, relative to a centre c
+  // (training point 0) -- the per-dimension register accumulators of the difference form are 64 NB registers at D = 32
+  // (887 spilled registers at NB = 2, and the fit slower than on the workgroup kernel).  The plain product form,
+  // rowsum_k Z_k - W P, cancels digits in proportion to |Z| / |Z_k - P_n| (the trap of the narrow path's comment: 5e-6 in
+  // mu at M = 3); with the centre taken out what is left is the points' spread over the kernel's reach, one digit or
+  // two of sixteen.
+  constexpr bool kWide = DC > 8;
+  constexpr int NDB = (DC + 15) / 16;  // 16-column blocks of the feature dimension
   const Layout lay = make_layout(M, T, DC);
   double* wbase = ws + desc.ws_offset;
   int status = GAPRO_OK;
@@ -360,6 +372,11 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
     gh[10 + lane] = kGhW[lane];
   }
   if (lane < 3) sc[lane] = 0.0;
+  if (kWide) {
+    wsync();
+    for (int d = lane; d < DC; d += 64) cen[d] = Xt[d * Mp];
+    if (lane < Mp) vrs[lane] = 0.0;
+  }
   double mm1 = 0.0, mm2 = 0.0;  // Adam moments of m[lane]
   // Adam moments of tril(L_S): the one piece of state that is touched once per step and nowhere else, so it lives in
   // the fit's workspace slab (B_MLS, B_VLS) in tile order [tile][r][lane] -- 512-byte rows, read at the start of the
@@ -534,7 +551,19 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
     // (rowsum_k Z_k - W P) it loses digits to cancellation, and on tiny fits (M = 3) Adam turns that into 5e-6 in mu.
     // This lane accumulates column k = 16 kb + lr over the rows n of transposed tiles (n-major: W^T, or the symmetric
     // W_zz as it is); the four row groups are summed at the end.
-    double gz[NB][DC];
+    double gz[NB][kWide ? 1 : DC];
+    // wide features: T = W_zx (X - c) + 2 W_zz (Z - c) as tiles (point block k, feature block db), row sums of the weights
+    d4 GZT[NB][kWide ? NDB : 1];
+    double rs_part[NB];
+    // tile (n, db) of the points P ([d][i] in LDS) relative to the centre: rows = points 16 n + lq + 4 r, column = feature
+    auto pc_tile = [&](const ldsd* Pt_, int n, int db) {
+      const int d = 16 * db + lr;
+      const double cd = d < DC ? cen[d] : 0.0;
+      d4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = d < DC ? Pt_[d * Mp + 16 * n + lq + 4 * r] - cd : 0.0;
+      return v;
+    };
 #pragma unroll
     for (int t = 0; t < NL; ++t) {
       GLS[t] = zero4();
@@ -543,8 +572,11 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       gm_part[k] = 0.0;
+      rs_part[k] = 0.0;
 #pragma unroll
-      for (int d = 0; d < DC; ++d) gz[k][d] = 0.0;
+      for (int d = 0; d < (kWide ? 1 : DC); ++d) gz[k][d] = 0.0;
+#pragma unroll
+      for (int db = 0; db < (kWide ? NDB : 1); ++db) GZT[k][db] = zero4();
     }
     double e_part = 0.0, gc_part = 0.0, gvs_part = 0.0, wsum = 0.0, gl = 0.0;
 #pragma unroll 1
@@ -553,11 +585,13 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
       const bool on = col < M;
       // KX, A = LI KX, At = A^T
       d4 KX[NB], A[NB], At[NB];
+      d4 KXD[kWide ? NB : 1];  // wide features: the squared distances of the KX tiles (the narrow path recomputes them)
 #pragma unroll
       for (int k = 0; k < NB; ++k) {
         const RbfTile kx = rbf_tile<DC, Mp>(Zt, k, Xt, n, -0.5 * inv_l2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) KX[k][r] = (16 * k + lq + 4 * r < M && on) ? s * kx.e[r] : 0.0;
+        if (kWide) KXD[k] = kx.d2;
       }
       stamp(2);
       forward_a(KX, A, nullptr);
@@ -650,20 +684,31 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 #pragma unroll
         for (int r = 0; r < 4; ++r) g[r] *= KX[k][r];
         const d4 wt = transpose_tile(g, t0);  // rows n = 16 n + lq + 4 r, column k = 16 k + lr
-        double zk[DC];
+        if constexpr (kWide) {
 #pragma unroll
-        for (int d = 0; d < DC; ++d) zk[d] = Zt[d * Mp + 16 * k + lr];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double s2 = 0.0;
-#pragma unroll
-          for (int d = 0; d < DC; ++d) {
-            const double t = zk[d] - Xt[d * Mp + 16 * n + lq + 4 * r];
-            s2 += t * t;
-            gz[k][d] += wt[r] * t;
+          for (int r = 0; r < 4; ++r) {
+            wsum += g[r];
+            gl += g[r] * KXD[k][r];
+            rs_part[k] += wt[r];  // this lane's rows of column k: summed over the row groups before the update
           }
-          wsum += wt[r];
-          gl += wt[r] * s2;
+#pragma unroll
+          for (int db = 0; db < NDB; ++db) GZT[k][db] = tn(GZT[k][db], wt, pc_tile(Xt, n, db));
+        } else {
+          double zk[DC];
+#pragma unroll
+          for (int d = 0; d < DC; ++d) zk[d] = Zt[d * Mp + 16 * k + lr];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double s2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DC; ++d) {
+              const double t = zk[d] - Xt[d * Mp + 16 * n + lq + 4 * r];
+              s2 += t * t;
+              gz[k][d] += wt[r] * t;
+            }
+            wsum += wt[r];
+            gl += wt[r] * s2;
+          }
         }
       }
       stamp(7);
@@ -759,6 +804,22 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
           }
           const RbfTile kz = rbf_tile<DC, Mp>(Zt, n, Zt, k, -0.5 * inv_l2);
           const int cj = 16 * k + lr;
+          if constexpr (kWide) {
+            d4 w2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * n + lq + 4 * r;
+              const bool in = row < M && cj < M;
+              const double gsym = in ? 0.5 * (sv[r] + st[r]) : 0.0;
+              const double w = gsym * s * kz.e[r];
+              gs += gsym * kz.e[r];
+              gl += w * kz.d2[r];
+              w2[r] = 2.0 * w;
+              rs_part[k] += w2[r];
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) GZT[k][db] = tn(GZT[k][db], w2, pc_tile(Zt, n, db));
+          } else {
           double zk[DC];
 #pragma unroll
           for (int d = 0; d < DC; ++d) zk[d] = Zt[d * Mp + cj];
@@ -773,6 +834,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 #pragma unroll
             for (int d = 0; d < DC; ++d) gz[k][d] += 2.0 * w * (zk[d] - Zt[d * Mp + row]);
           }
+          }
         }
       }
     }
@@ -782,6 +844,35 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
 
     // ---- Adam on Z: the four row groups of column k are summed; row group lq then updates d = lq, lq + 4, ...
     wsync();  // every read of Z of this step is done
+    if constexpr (kWide) {
+      // G_Z[k][d] = -(rowsum_k (Z_k[d] - c[d]) - T[k][d]) / l^2: the row sums travel through LDS (summed per column lane,
+      // needed per row of the tiles); every lane then owns the elements (point 16 k + lq + 4 r, feature 16 db + lr)
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const double v = red_lq(rs_part[k]);
+        if (lq == 0) vrs[16 * k + lr] = v;
+      }
+      wsync();
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pt = 16 * k + lq + 4 * r, d = 16 * db + lr;
+            const bool act = d < DC && pt < M;
+            const int o = act ? d * Mp + pt : 0;
+            const double zc = Zt[o] - cen[act ? d : 0];
+            const double grad = -inv_l2 * (vrs[act ? pt : 0] * zc - GZT[k][db][r]);
+            double m1 = mZ[o], m2 = vZ[o];
+            const double zn = adam(Zt[o], m1, m2, grad, step_size, bc2s);
+            if (act) {
+              Zt[o] = zn;
+              mZ[o] = m1;
+              vZ[o] = m2;
+            }
+          }
+    } else {
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       double mine[(DC + 3) / 4];
@@ -807,6 +898,7 @@ __device__ inline void fit_wave(ldsd* L, const gapro_fit_desc& desc, const gapro
           vZ[o] = m2;
         }
       }
+    }
     }
 
     // ---- Adam on m, c, rho_s, rho_l: ONE update per lane -- lanes < M hold m (M <= 48), lanes 61, 62, 63 the three
@@ -952,9 +1044,12 @@ __global__ __launch_bounds__(64, WPE) void k_svgp_fit_wave(int n_fits, const flo
 }  // namespace
 
 // Largest padded size the wave kernel takes at this feature width (0: none).  NB = 3 runs one wave per SIMD.
-int gapro_fit_wave_max_mp(int feat_dim) { return feat_dim == 6 ? 48 : 0; }
+// Deep features (D = 32, the --use_deepfeat workflow, gen_ps.py:48-53; round 6): M_p <= 32 -- the points of three row
+// blocks and their Adam moments (4 x 32 x 48 doubles) leave room for one fit per CU.
+int gapro_fit_wave_max_mp(int feat_dim) { return feat_dim == 6 ? 48 : feat_dim == 32 ? 32 : 0; }
 
 size_t gapro_fit_wave_lds_bytes(int nb, int feat_dim) {
+  if (feat_dim == 32) return nb == 1 ? 8 * (size_t)WaveLds<1, 32>::total : nb == 2 ? 8 * (size_t)WaveLds<2, 32>::total : 0;
   if (feat_dim != 6) return 0;
   return 8 * (size_t)(nb == 1 ? WaveLds<1, 6>::total : nb == 2 ? WaveLds<2, 6>::total : WaveLds<3, 6>::total);
 }
@@ -963,7 +1058,8 @@ size_t gapro_fit_wave_lds_bytes(int nb, int feat_dim) {
 int gapro_fit_wave_per_cu(int nb, int feat_dim) {
   const size_t lds = gapro_fit_wave_lds_bytes(nb, feat_dim);
   if (!lds) return 0;
-  const int by_lds = (int)((160 * 1024) / lds), by_reg = nb <= 1 ? 8 : 4;
+  // D = 32: the per-dimension register arrays (G_Z accumulators, a column's coordinates) take the whole register file
+  const int by_lds = (int)((160 * 1024) / lds), by_reg = (nb <= 1 && feat_dim == 6) ? 8 : 4;
   return by_lds < by_reg ? by_lds : by_reg;
 }
 
@@ -973,15 +1069,23 @@ int gapro_launch_fit_wave(hipStream_t stream, int nb, int n_fits, int n_wg, unsi
                           const double* d_init_mean, const gapro_fit_options& opt, double* d_workspace, float* d_probs,
                           float* d_probs_new, unsigned char* d_labels, float* d_mu, float* d_var, int* d_fit_status,
                           double* d_fit_loss) {
-  if (feat_dim != 6 || nb < 1 || nb > 3) return GAPRO_ERR_BAD_ARG;
+  if ((feat_dim != 6 && feat_dim != 32) || nb < 1 || nb > (feat_dim == 6 ? 3 : 2)) return GAPRO_ERR_BAD_ARG;
   const size_t lds = gapro_fit_wave_lds_bytes(nb, feat_dim);
-#define GAPRO_WAVE_LAUNCH(NBV, WPEV)                                                                              \
-  hipLaunchKernelGGL((k_svgp_fit_wave<NBV, 6, WPEV>), dim3(n_wg), dim3(64), lds, stream, n_fits, d_feats_spp, d_idx,  \
-                     d_descs, d_init_mean, opt, d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, \
-                     d_fit_loss, d_ticket)
-  if (nb == 1) GAPRO_WAVE_LAUNCH(1, 2);
-  else if (nb == 2) GAPRO_WAVE_LAUNCH(2, 1);
-  else GAPRO_WAVE_LAUNCH(3, 1);
+#define GAPRO_WAVE_LAUNCH(NBV, DV, WPEV)                                                                          \
+  do {                                                                                                            \
+    auto kern = k_svgp_fit_wave<NBV, DV, WPEV>;                                                                   \
+    if (lds > 48 * 1024 &&                                                                                        \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+      return GAPRO_ERR_HIP;                                                                                       \
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64), lds, stream, n_fits, d_feats_spp, d_idx, d_descs, d_init_mean, opt, \
+                       d_workspace, d_probs, d_probs_new, d_labels, d_mu, d_var, d_fit_status, d_fit_loss, d_ticket); \
+  } while (0)
+  if (feat_dim == 32) {
+    if (nb == 1) GAPRO_WAVE_LAUNCH(1, 32, 1);
+    else GAPRO_WAVE_LAUNCH(2, 32, 1);
+  } else if (nb == 1) GAPRO_WAVE_LAUNCH(1, 6, 2);
+  else if (nb == 2) GAPRO_WAVE_LAUNCH(2, 6, 1);
+  else GAPRO_WAVE_LAUNCH(3, 6, 1);
 #undef GAPRO_WAVE_LAUNCH
   return hipGetLastError() == hipSuccess ? GAPRO_OK : GAPRO_ERR_HIP;
 }

@@ -34,6 +34,8 @@ CASES = {
     "m22_d32": (906, 10, 12, 75, 32, 0.3),
     "m90_d32": (907, 40, 50, 33, 32, 0.3),
     "m190_d32": (908, 90, 100, 20, 32, 0.3),
+    "m44_d32": (911, 20, 24, 30, 32, 0.3),    # round 6: M_p = 48, the small-fit strip kernel at D = 32 (m22_d32 now runs
+                                              # on the wave-per-fit kernel, which takes M_p <= 32 at this width)
 }
 
 
@@ -41,7 +43,10 @@ def main():
     import torch
 
     torch.set_num_threads(1)  # one summation order
+    only = set(sys.argv[1:])  # names: write only these (the others stay as committed)
     for name, (seed, m1, m2, t, d, std) in CASES.items():
+        if only and name not in only:
+            continue
         feats, b1, b2, it = make_gp_problem(seed, m1, m2, t, d, std=std)
         X = np.concatenate([feats[b1], feats[b2]]).astype(np.float64)
         y = np.r_[-np.ones(m1), np.ones(m2)]

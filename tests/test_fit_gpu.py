@@ -487,10 +487,13 @@ def test_three_staged_launches_of_one_batch_match_the_oracle():
         _compare(out, _oracle(f, b1, b2, it, 50))
 
 
-@pytest.mark.parametrize("m1,m2,t,route", [(20, 28, 12, 3), (40, 50, 33, 0), (90, 100, 40, 1), (120, 136, 25, 4),
+@pytest.mark.parametrize("m1,m2,t,route", [(1, 2, 3, 5), (5, 7, 9, 5), (8, 8, 40, 5), (14, 18, 70, 5), (9, 8, 1, 5),
+                                           (20, 28, 12, 3), (40, 50, 33, 0), (90, 100, 40, 1), (120, 136, 25, 4),
                                            (120, 136, 25, 2), (250, 262, 30, 4)])
 def test_fit_matches_oracle_with_deep_features_on_every_route(m1, m2, t, route):
-    """D = 32 (--use_deepfeat) against the float64 oracle on each kernel: small-fit strip (3), 512-thread strip (0),
+    """D = 32 (--use_deepfeat) against the float64 oracle on each kernel: wave-per-fit (5; round 6: M_p <= 32, with G_Z
+    as a centred product on the matrix cores instead of the narrow path's per-dimension differences), small-fit strip
+    (3), 512-thread strip (0),
     LDS-staged (1), the cluster kernel (4: on ONE workgroup for 192 < M_p < 512, where 2 x 32 x M_p staged point
     coordinates do not fit the LDS beside the Cholesky block column, and over 4 at M_p = 512) and the generic kernel
     (2, debug bit 3), 50 Adam steps, the tolerances of D = 6."""
