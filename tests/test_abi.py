@@ -85,7 +85,7 @@ def test_padding_and_route_agree_for_every_size_and_feature_width():
             if r in (0, 3):
                 assert mp <= 128
             if r == 5:
-                assert mp <= 48 and d == 6
+                assert (mp <= 48 and d == 6) or (mp <= 32 and d == 32)  # round 6: the wave kernel at D = 32 too
             if r == 2:
                 assert d > 32, (m, d, mp)  # nothing the reference's feature widths produce reaches the generic kernel
             if d > 32:

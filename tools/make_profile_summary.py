@@ -61,7 +61,8 @@ def main():
                       ("cluster_prof.log", "_cluster_phases.txt"), ("strip_prof.log", "_strip_phases.txt"),
                       ("fit_sizes.log", "_fit_sizes.txt"), ("host_ceiling.json", "_host_ceiling.json"),
                       ("wgloop_peak.txt", "_wgloop_peak.txt"), ("kernel_resources.txt", "_kernel_resources.txt"),
-                      ("sq_counters.txt", "_sq_counters.txt"), ("wave_phases.txt", "_wave_phases.txt")):
+                      ("sq_counters.txt", "_sq_counters.txt"), ("wave_phases.txt", "_wave_phases.txt"),
+                      ("cond_survey.txt", "_cond_survey.txt"), ("staged_traffic.txt", "_staged_traffic.txt")):
         pth = os.path.join(src, name)
         if os.path.exists(pth):
             with open(pth) as fh:

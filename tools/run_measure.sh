@@ -29,7 +29,21 @@ python tools/bench_fit.py --profile --sizes 64,80,96,128 --fits 512 --reps 1 > $
 python tools/bench_fit.py --profile --sizes 16,32,48 --fits 2048 --reps 1 > $O/wave_phases.txt 2>&1
 python tools/fit_timeline.py --fit-m $O/train_split_fit_m.npy > $O/fit_timeline.txt 2>&1; grep -v amdgpu $O/fit_timeline.txt | head -12
 python tools/bench_fit.py --sizes 16,32,48 --fits 4096 --reps 2 > $O/fit_sizes.log 2>&1
-python tools/bench_fit.py --sizes 64,80,96,128,160,200,256,320,384,448 --fits 512 --reps 2 >> $O/fit_sizes.log 2>&1; grep "^M=" $O/fit_sizes.log
+python tools/bench_fit.py --sizes 64,80,96,128,160,200,256,320,384,448 --fits 512 --reps 2 >> $O/fit_sizes.log 2>&1
+# round 6: the deep-feature workflow's small fits (wave-per-fit at M_p <= 32) and their neighbours on the workgroup kernels
+python tools/bench_fit.py --d 32 --sizes 16,32 --fits 4096 --reps 2 >> $O/fit_sizes.log 2>&1
+python tools/bench_fit.py --d 32 --sizes 48,64,128 --fits 512 --reps 2 >> $O/fit_sizes.log 2>&1; grep "^M=" $O/fit_sizes.log
+# round 6: the reproducibility probe and the conditioning figure over the S3DIS-shaped scene's 66 fits
+python tools/cond_survey.py > $O/cond_survey.txt 2>&1
+# round 6: HBM-side traffic of the two-per-CU staged build on its own (profiles/r06_spill_traffic.md), after the step function
+cd /tmp
+for SZ in 160 200 256; do
+  for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VMEM_WR; do
+    timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/staged_m${SZ}_$C -o fit --output-format csv -- python3 $R/tools/bench_fit.py --sizes $SZ --fits 512 --reps 1 > $O/staged_m${SZ}_$C.log 2>&1
+  done
+done
+cd $R
+for SZ in 160 200 256; do echo "== M=$SZ"; grep "^M=" $O/staged_m${SZ}_FETCH_SIZE.log; python tools/pmc_summary.py $O/staged_m${SZ}_FETCH_SIZE $O/staged_m${SZ}_WRITE_SIZE $O/staged_m${SZ}_SQ_INSTS_VMEM_WR | grep "k_svgp"; done > $O/staged_traffic.txt 2>&1
 python tools/mfma_peak.py > $O/wgloop_peak.txt 2>&1
 python tools/host_ceiling.py --workers 1,2,4,8 --json $O/host_ceiling.json > $O/host_ceiling.txt 2>&1; grep "^workers" $O/host_ceiling.txt
 python tools/host_probe.py > $O/host_probe.txt 2>&1
