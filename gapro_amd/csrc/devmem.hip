@@ -40,6 +40,10 @@ size_t round_size(size_t n) {
   return (n + g - 1) / g * g;
 }
 
+// Every entry point runs on the context's device whatever the calling thread's current device is: the workers' helper
+// threads (workspace pre-allocation, host pools) start on device 0, and a worker of `--devices 0,..,7` owns another one.
+#define GAPRO_ON_DEVICE(ctx) GAPRO_HIP_CHECK(ctx, hipSetDevice((ctx)->device))
+
 Arena* arena_of(gapro_ctx* ctx) {
   static std::mutex mk;
   std::lock_guard<std::mutex> lk(mk);
@@ -80,6 +84,7 @@ int gapro_dev_alloc(gapro_ctx* ctx, size_t bytes, void* stream, void** out) {
       return GAPRO_OK;
     }
   }
+  GAPRO_ON_DEVICE(ctx);
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, need);
   if (e != hipSuccess) {  // out of memory: give the cached blocks back and try once more
@@ -125,7 +130,10 @@ int gapro_dev_trim(gapro_ctx* ctx) {
     }
     for (auto& d : drop) a->reserved -= d.first;
   }
-  if (!drop.empty()) (void)hipDeviceSynchronize();  // a cached block may still be in use by its stream's queued work
+  if (!drop.empty()) {
+    GAPRO_ON_DEVICE(ctx);
+    (void)hipDeviceSynchronize();
+  }  // a cached block may still be in use by its stream's queued work
   for (auto& d : drop) (void)hipFree(d.second);
   return GAPRO_OK;
 }
@@ -141,6 +149,7 @@ int gapro_dev_stats(gapro_ctx* ctx, int64_t* reserved_bytes, int64_t* in_use_byt
   }
   if (device_free_bytes || device_total_bytes) {
     size_t fr = 0, tot = 0;
+    GAPRO_ON_DEVICE(ctx);
     GAPRO_HIP_CHECK(ctx, hipMemGetInfo(&fr, &tot));
     if (device_free_bytes) *device_free_bytes = (int64_t)fr;
     if (device_total_bytes) *device_total_bytes = (int64_t)tot;
@@ -151,6 +160,7 @@ int gapro_dev_stats(gapro_ctx* ctx, int64_t* reserved_bytes, int64_t* in_use_byt
 int gapro_host_alloc(gapro_ctx* ctx, size_t bytes, void** out) {
   if (!ctx || !out) return GAPRO_ERR_BAD_ARG;
   *out = nullptr;
+  GAPRO_ON_DEVICE(ctx);
   GAPRO_HIP_CHECK(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
   return GAPRO_OK;
 }
@@ -178,6 +188,7 @@ int gapro_stream_destroy(gapro_ctx* ctx, void* stream) {
 
 int gapro_stream_sync(gapro_ctx* ctx, void* stream) {
   if (!ctx) return GAPRO_ERR_BAD_ARG;
+  GAPRO_ON_DEVICE(ctx);
   GAPRO_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
   return GAPRO_OK;
 }
@@ -206,12 +217,14 @@ int gapro_event_destroy(gapro_ctx* ctx, void* ev) {
 
 int gapro_event_record(gapro_ctx* ctx, void* ev, void* stream) {
   if (!ctx || !ev) return GAPRO_ERR_BAD_ARG;
+  GAPRO_ON_DEVICE(ctx);
   GAPRO_HIP_CHECK(ctx, hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
   return GAPRO_OK;
 }
 
 int gapro_stream_wait_event(gapro_ctx* ctx, void* stream, void* ev) {
   if (!ctx || !ev) return GAPRO_ERR_BAD_ARG;
+  GAPRO_ON_DEVICE(ctx);
   GAPRO_HIP_CHECK(ctx, hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0));
   return GAPRO_OK;
 }
@@ -245,6 +258,7 @@ int gapro_memcpy_async(gapro_ctx* ctx, void* dst, const void* src, size_t bytes,
   if (!ctx || kind < 0 || kind > 2 || (bytes && (!dst || !src))) return GAPRO_ERR_BAD_ARG;
   if (!bytes) return GAPRO_OK;
   const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  GAPRO_ON_DEVICE(ctx);
   GAPRO_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
   return GAPRO_OK;
 }
@@ -252,6 +266,7 @@ int gapro_memcpy_async(gapro_ctx* ctx, void* dst, const void* src, size_t bytes,
 int gapro_memset_async(gapro_ctx* ctx, void* dst, int32_t value, size_t bytes, void* stream) {
   if (!ctx || (bytes && !dst)) return GAPRO_ERR_BAD_ARG;
   if (!bytes) return GAPRO_OK;
+  GAPRO_ON_DEVICE(ctx);
   GAPRO_HIP_CHECK(ctx, hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
   return GAPRO_OK;
 }

@@ -402,7 +402,11 @@ class Worker:
             nb = -(-rem // a.batch_scenes)
             want = cap = max(1, min(-(-rem // nb), left))
         if first:
-            wait_ms = int(1000 * max(0.0, self.first_window - (time.time() - self.t0)))
+            # (a static list that fits ONE batch is waited for as a whole, within reason: two launches of 120 and 30
+            # scenes last twice as long as one of 150 -- a launch is as long as its largest fit)
+            window = max(self.first_window, 0.6) if (self.n_static is not None and self.n_static <= a.batch_scenes) \
+                else self.first_window
+            wait_ms = int(1000 * max(0.0, window - (time.time() - self.t0)))
             n, nbytes = self.feeder.poll(want, a.batch_scenes, wait_ms)
             if n < min(self.first_min, want):
                 n, nbytes = self.feeder.poll(min(self.first_min, want), a.batch_scenes, -1)
