@@ -204,15 +204,16 @@ _dbg: Optional[C.CDLL] = None
 
 
 def source_build_id() -> str:
-    """Identity of the kernel sources this tree holds (sha256 over csrc/*.hip|h|cc|cpp and include/*.h, 16 hex digits):
-    bench.py prints it and the committed PMC passes carry it, so that a traffic figure is only ever attached to a
-    bench line of the SAME build."""
+    """Identity of the DEVICE KERNELS this tree holds (sha256 over the kernel sources and the headers they include, 16
+    hex digits): bench.py prints it and the committed PMC passes carry it, so that a traffic figure is only ever
+    attached to a bench line of the SAME kernels.  Host-only sources (file I/O, feeder, arena,
+    scheduler) are left out: they move no byte of a kernel's traffic."""
     import glob
     import hashlib
 
     h = hashlib.sha256()
     files = []
-    for pat in ("csrc/*.hip", "csrc/*.h", "csrc/*.cc", "csrc/*.cpp", "../include/*.h"):
+    for pat in ("csrc/svgp_fit*.hip", "csrc/partition.hip", "csrc/labels.hip", "csrc/consumer.hip", "csrc/*.h"):
         files += glob.glob(os.path.join(_HERE, pat))
     for fn in sorted(files, key=os.path.basename):
         h.update(os.path.basename(fn).encode())

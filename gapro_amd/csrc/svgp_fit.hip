@@ -330,8 +330,8 @@ typedef __attribute__((address_space(3))) d2 lds_d2;
 typedef __attribute__((address_space(1))) d2 g_d2;
 
 // Round 6 (profiles/r06_spill_traffic.md): every out-of-line product saved and restored the 41 callee-saved VGPRs it
-// uses -- ~410 scratch stores and as many loads per wave and Adam step, 8 .. 15 % of the HBM-side traffic of the
-// two-per-CU staged fits, which sit on the memory roof.  Inlining the products into the KERNEL was 3 % slower (the
+// uses -- ~410 scratch stores and as many loads per wave and Adam step; the stores are 9 % of the bytes the two-per-CU
+// staged fits write at M = 160 (the reloads are served by L2), and those fits sit on the memory roof.  Inlining the products into the KERNEL was 3 % slower (the
 // register allocator then carries the kernel's long-lived values through every k loop); inlining them into ONE
 // out-of-line function per Adam step (step_fn in fit_body, through gemm_tn_in) pays the callee-saved traffic once per
 // step: M = 160 -3.3 %, 200 -1.7 %, 256 +0.7 %, 320 / 384 +-0 in time, bit-identical.  The strip kernels' tail products keep

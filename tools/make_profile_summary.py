@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--feat-dim", type=int, default=6)
     ap.add_argument("--workload", default="stream")
     ap.add_argument("--distinct", type=int, default=64)
+    ap.add_argument("--build-id", default="", help="kernel build id of the pass when the box did not record it")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -85,7 +86,9 @@ def main():
     from gapro_amd._lib import source_build_id
 
     # the kernels these counters belong to: bench.py attaches the figure only to lines of the same build
-    traffic = {"build": bench.get("build_id") or source_build_id(),
+    bid_file = os.path.join(src, "build_id.txt")  # written on the box by tools/run_measure.sh
+    traffic = {"build": (open(bid_file).read().strip() if os.path.exists(bid_file) else None) or a.build_id
+                        or source_build_id(),
                "workload": {"name": a.workload, "scenes_per_step": a.scenes_per_step, "points": a.points,
                             "feat_dim": a.feat_dim, "distinct": a.distinct},
                "calibration": {"kernel": "k_stream_calib (one double per lane, grid-stride, 512 MiB per pass)",

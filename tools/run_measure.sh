@@ -9,6 +9,7 @@ TAG=${1:-meas}
 R=$PWD
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+python -c "from gapro_amd._lib import source_build_id; print(source_build_id())" > $O/build_id.txt
 ( time timeout 1500 python bench.py > $O/bench.json 2> $O/bench.err ) 2> $O/bench.time; tail -3 $O/bench.time; tail -c 600 $O/bench.json; echo
 LIGHT="--no-cpu-baseline --no-fixed-line --no-driver-line --no-extra-lines"
 GAPRO_DUMP_FIT_M=$O/train_split_fit_m.npy timeout 400 python bench.py $LIGHT --stage-times --steps 5 --warmup 1 > $O/bench_stages.json 2> $O/bench_stages.err; tail -2 $O/bench_stages.err
