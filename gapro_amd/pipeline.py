@@ -645,17 +645,22 @@ class Pipeline:
         on(0, self._launch, cur_state)
         nxt = on(1, next, it, None)
         prev_state = None
+        finish_late = bool(os.environ.get("GAPRO_FINISH_LATE"))  # A/B: round 5's order (merge after the pull)
         while cur_state is not None:
             nxt_state = on(i + 1, self._partition, nxt, False) if nxt is not None else None
             if i > 0:
                 on(i, self._launch, cur_state)
-            # everything below is host work that runs while the fit just launched occupies the GPU: fetching the
-            # batch after next from the iterator (building jobs, reading / uploading scenes), the schedule of the
-            # next batch, the merge of the previous one
+            # everything below is host work that runs while the fit just launched occupies the GPU: the merge of the
+            # previous batch, fetching the batch after next from the iterator (building jobs, reading / uploading
+            # scenes), the schedule of the next batch.  The merge comes FIRST (round 6): fit(i-1) has ended -- the
+            # partition kernels above only ran once it had drained -- and the pull can block for a whole batch of
+            # reads, which in a worker's first second kept finished labels waiting for 0.3 .. 0.5 s
+            if prev_state is not None and not finish_late:
+                yield on(i - 1, self._finish, prev_state, False)
             nxt = on(i + 2, next, it, None) if nxt is not None else None
             if nxt_state is not None:
                 on(i + 1, self._schedule_all, nxt_state)
-            if prev_state is not None:
+            if prev_state is not None and finish_late:
                 yield on(i - 1, self._finish, prev_state, False)
             prev_state, cur_state = cur_state, nxt_state
             i += 1

@@ -350,3 +350,43 @@ def test_cli_files_equal_the_oracle_end_to_end(tmp_path):
         np.testing.assert_allclose(mu[gp], ref[3][gp], rtol=1e-4, atol=1e-6)
         n_gp += int(gp.sum())
     assert n_gp > 0, "no GP-labelled superpoint in the fixture scenes"
+
+
+@pytest.mark.gpu
+def test_cli_use_deepfeat_equals_the_python_loader_path(tmp_path):
+    """`--use_deepfeat --deepfeat_folder DIR` (reference gen_ps.py:48-53: the step-4 workflow, D = 32 features read from
+    files): the CLI -- native feeder reading the feature files, torch-free worker, wave-per-fit / strip / staged kernels at
+    D = 32 -- against the Python mirror of gen_ps.py:37-111 on the same files, array for array."""
+    import subprocess
+    import sys
+
+    from gapro_amd.gen_ps import load_scene, save_scene
+    from gapro_amd.pipeline import Pipeline, make_job
+
+    root, scenes = _dataset(tmp_path, 3)
+    deep = str(tmp_path / "deep")
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    os.makedirs(a)
+    pipe = Pipeline(device=0, training_iter=50)
+    jobs = []
+    for s in scenes:
+        sc = load_scene(os.path.join(root, "train", s.scan_name + "_inst_nostuff.pth"), root, True, deep)
+        assert sc["mask_feats"].shape[1] == 32
+        jobs.append(make_job(sc["coords_float"], sc["mask_feats"], sc["spp"], sc["instance_cls"], sc["instance_box"],
+                             sc["instance_box_volume"], sc["wall_box"], sc["wall_box_volume"], instance_classes=18,
+                             ground_h=0.1, thresh_spp_occu=0.999, device="cuda:0"))
+    for s, job, o in zip(scenes, jobs, pipe.run(jobs)):
+        save_scene(os.path.join(a, s.scan_name + ".pth"), o)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "gapro_amd.gen_ps", "--save_folder", b, "--data_root", root,
+                        "--batch_scenes", "2", "--use_deepfeat", "--deepfeat_folder", deep],
+                       cwd=repo, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "3 scenes written" in r.stdout and "the library's own arena" in r.stdout
+    for s in scenes:
+        x = torch.load(os.path.join(a, s.scan_name + ".pth"), weights_only=False)
+        y = torch.load(os.path.join(b, s.scan_name + ".pth"), weights_only=False)
+        assert len(x) == len(y) == 5
+        for u, v in zip(x, y):
+            assert u.dtype == v.dtype
+            np.testing.assert_array_equal(u, v)
