@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -238,6 +239,9 @@ def load_debug() -> C.CDLL:
     return lib
 
 
+_TORCH_FIRST = [True]  # was torch already in the process when the library was loaded (or never imported)?
+
+
 def load() -> C.CDLL:
     """Load libgapro_hip.so; raises (never falls back) if it is absent or lacks a symbol."""
     global _lib
@@ -246,6 +250,7 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError("libgapro_hip.so not built: run gapro_amd/csrc/build.sh (or __graft_entry__.build()); "
                           "expected at " + LIB_PATH)
+    _TORCH_FIRST[0] = "torch" in sys.modules
     lib = C.CDLL(LIB_PATH)
     default = os.path.join(_HERE, "libgapro_hip.so")
     host_only = None  # A/B tools point LIB_PATH at a variant build that may predate a host-side helper
@@ -275,7 +280,10 @@ class Context:
         h = _P()
         rc = self.lib.gapro_ctx_create(int(device), C.byref(h))
         if rc != GAPRO_OK:
-            raise GaproError(rc, "gapro_ctx_create(device=%d): no usable HIP device" % device)
+            raise GaproError(rc, "gapro_ctx_create(device=%d): no usable HIP device%s" % (device, (
+                " (torch was imported AFTER libgapro_hip.so was loaded: the process now holds two HIP runtimes, torch's "
+                "bundled one and /opt/rocm's -- import torch first, or use the torch-free backend)"
+                if ("torch" in sys.modules and not _TORCH_FIRST[0]) else "")))
         self.handle = h
         self.device = int(device)
 

@@ -30,6 +30,13 @@ def errs(out, ref):
     return dv, dm, dp, flips
 
 
+def bf16_round(x):
+    """float32 array rounded to bfloat16 (round to nearest even) and widened again: what a bf16 input tensor holds"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(x))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sizes", default="64,128,512,1024,2048")
@@ -59,25 +66,28 @@ def main():
         feats = np.concatenate(parts)
         launch = [probs[i % 4] for i in range(args.fits)]
         res = {}
-        for mode in ("f64", "mixed"):
-            fit_gp_spp_batch(feats, launch[:4], training_iter=2, precision=mode, cluster_all=True)  # warm
+        for mode in ("f64", "mixed", "bf16in"):
+            # round 6: "bf16in" = the device's MIXED kernel fed with bfloat16-rounded features (config 5's third leg as a
+            # HIP run, not only as an oracle study)
+            fin, prec = (bf16_round(feats), "mixed") if mode == "bf16in" else (feats, mode)
+            fit_gp_spp_batch(fin, launch[:4], training_iter=2, precision=prec, cluster_all=True)  # warm
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            out = fit_gp_spp_batch(feats, launch, training_iter=50, precision=mode, cluster_all=True)
+            out = fit_gp_spp_batch(fin, launch, training_iter=50, precision=prec, cluster_all=True)
             torch.cuda.synchronize()
             res[mode] = (out, time.perf_counter() - t0)
         flops = args.fits * (50 * (8.33 * m ** 3 + 12 * 6 * m * m) + m ** 3 / 3 + 2 * m * m * args.t + 12 * (m * m + m * args.t))
         row = {"M": m}
         ref = None
         if m <= args.oracle_max:
-            worst = {"f64": [0, 0, 0, 0], "mixed": [0, 0, 0, 0]}
+            worst = {"f64": [0, 0, 0, 0], "mixed": [0, 0, 0, 0], "bf16in": [0, 0, 0, 0]}
             for k in range(4):
                 b1, b2, it = probs[k]
                 X = np.concatenate([feats[b1], feats[b2]]).astype(np.float64)
                 y = np.r_[-np.ones(m1), np.ones(m2)]
                 Xt = feats[it].astype(np.float64)
                 ref = so.svgp_fit_predict_autograd(X, y, Xt, 50, "f64")
-                for mode in ("f64", "mixed"):
+                for mode in ("f64", "mixed", "bf16in"):
                     e = errs(res[mode][0][k], ref)
                     worst[mode] = [max(a, b) for a, b in zip(worst[mode], e)]
                 if m <= args.cpu_study_max and k == 0:
@@ -88,14 +98,15 @@ def main():
                             row["cpu_" + cm] = errs(fake, ref)
                         except Exception as ex:  # noqa: BLE001 - e.g. float32 Cholesky not positive definite
                             row["cpu_" + cm] = "failed: %s" % str(ex)[:40]
-            row["gpu_f64"], row["gpu_mixed"] = worst["f64"], worst["mixed"]
+            row["gpu_f64"], row["gpu_mixed"], row["gpu_bf16in"] = worst["f64"], worst["mixed"], worst["bf16in"]
         else:  # no oracle at this size: the split against the float64 kernel (which matches the oracle elsewhere)
-            worst = [0, 0, 0, 0]
+            worst, worst_b = [0, 0, 0, 0], [0, 0, 0, 0]
             for k in range(4):
                 o64 = res["f64"][0][k]
-                e = errs(res["mixed"][0][k], (o64[3].astype(np.float64), o64[4].astype(np.float64), o64[0].astype(np.float64)))
-                worst = [max(a, b) for a, b in zip(worst, e)]
-            row["gpu_mixed_vs_gpu_f64"] = worst
+                r64 = (o64[3].astype(np.float64), o64[4].astype(np.float64), o64[0].astype(np.float64))
+                worst = [max(a, b) for a, b in zip(worst, errs(res["mixed"][0][k], r64))]
+                worst_b = [max(a, b) for a, b in zip(worst_b, errs(res["bf16in"][0][k], r64))]
+            row["gpu_mixed_vs_gpu_f64"], row["gpu_bf16in_vs_gpu_f64"] = worst, worst_b
         for mode in ("f64", "mixed"):
             row["ms_" + mode] = 1e3 * res[mode][1]
             row["tf_" + mode] = flops / res[mode][1] / 1e12
@@ -105,21 +116,23 @@ def main():
             row["bitwise_" + mode] = all(np.array_equal(a, b) for i in range(4, args.fits) for a, b in zip(o[i], o[i % 4]))
         rows.append(row)
         print(row, flush=True)
-    lines = ["# Precision sweep of the GP fit (BASELINE configs[4]) -- MI355X, round 2", "",
+    lines = ["# Precision sweep of the GP fit (BASELINE configs[4]) -- MI355X, round 6 (round 2's table + the bfloat16-input "
+             "leg as a device run)", "",
              "%d concurrent fits per size (4 distinct two-blob problems x %d), T = %d test superpoints, D = 6, 50 Adam steps, "
              "all through the cluster kernel (`gapro_fit_options.reserved` bit 4).  Errors are maxima over the 4 problems "
              "against the float64 autograd oracle (`oracle/svgp_oracle.py`, PARITY UNPINNED against gpytorch): "
              "relative error of sigma^2, error of mu relative to max|mu|, absolute error of p, label flips." % (args.fits, args.fits // 4, args.t), "",
-             "| M | kernel float64: sigma^2 / mu / p / flips | kernel mixed (reference split) | launch ms f64 -> mixed | TFLOP/s f64 -> mixed | copies bitwise equal |",
-             "|---|---|---|---|---|---|"]
+             "| M | kernel float64: sigma^2 / mu / p / flips | kernel mixed (reference split) | kernel mixed on bfloat16-rounded features | launch ms f64 -> mixed | TFLOP/s f64 -> mixed | copies bitwise equal |",
+             "|---|---|---|---|---|---|---|"]
     fmt = lambda e: "%.1e / %.1e / %.1e / %d" % tuple(e)  # noqa: E731
     for r in rows:
         if "gpu_f64" in r:
-            a, b = fmt(r["gpu_f64"]), fmt(r["gpu_mixed"])
+            a, b, c = fmt(r["gpu_f64"]), fmt(r["gpu_mixed"]), fmt(r["gpu_bf16in"])
         else:
             a, b = "(no oracle at this size)", "vs float64 kernel: " + fmt(r["gpu_mixed_vs_gpu_f64"])
-        lines.append("| %d | %s | %s | %.0f -> %.0f | %.1f -> %.1f | %s / %s |" % (
-            r["M"], a, b, r["ms_f64"], r["ms_mixed"], r["tf_f64"], r["tf_mixed"], r["bitwise_f64"], r["bitwise_mixed"]))
+            c = "vs float64 kernel: " + fmt(r["gpu_bf16in_vs_gpu_f64"])
+        lines.append("| %d | %s | %s | %s | %.0f -> %.0f | %.1f -> %.1f | %s / %s |" % (
+            r["M"], a, b, c, r["ms_f64"], r["ms_mixed"], r["tf_f64"], r["tf_mixed"], r["bitwise_f64"], r["bitwise_mixed"]))
     lines += ["", "CPU study with the oracle (problem 0 of each size; not kernel modes): the split restated in torch, float32 "
                   "everywhere including the Cholesky factorisation, and the split on bfloat16-rounded features.", "",
               "| M | oracle mixed | oracle all-float32 | oracle bfloat16 inputs |", "|---|---|---|---|"]
