@@ -5,6 +5,9 @@
 # with matrix-pipe busy shares, the per-phase profiles of the cluster / strip / small kernels and the CU-time split of one
 # launch of the train-split mix per kernel (diagnostic builds: GAPRO_BUILD_PROFILE=1 and the profsplit variant).
 # Outputs under gpurun_out/$TAG; copy what is to be judged to profiles/ (tools/make_profile_summary.py).
+# Needs the two diagnostic libraries in the tree (they are not kept there between passes -- they ride along in every push
+# to the GPU box otherwise):
+#   GAPRO_BUILD_PROFILE=1 GAPRO_VARIANT=profsplit GAPRO_VARIANT_FLAGS="-DGAPRO_PROFILE -DGAPRO_PROFILE_SPLIT" bash gapro_amd/csrc/build.sh
 TAG=${1:-meas}
 R=$PWD
 O=$R/gpurun_out/$TAG
